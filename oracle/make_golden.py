@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (feihoo87/waveforms 2.2.3).
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container, where
+/root/reference exists.  The reference's Python/Cython sources are copied to a
+scratch directory under /tmp, built there (`setup.py build_ext --inplace`), and
+imported with a stub for the absent `antlr4` package.
+Nothing from the reference is written into this repository: only numeric
+input/output vectors derived by *running* it.
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+
+Outputs
+  tests/golden/frontend.json      reference tolist() for every case in tests/cases.py
+  tests/golden/samples.npz        reference wav(t) per case (+ searchsorted indices)
+  tests/golden/sample_api.npz     reference wav.sample() per sos_case
+  tests/golden/big.npz            C2 / C3 / C4: strided subsets, piece indices, sums
+  tests/golden/fir.npz            distortion.predistort(sig, ker=...) vectors
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SCRATCH = '/tmp/oracle'
+REF = '/root/reference'
+
+
+def import_reference():
+    so_ok = os.path.isdir(f'{SCRATCH}/waveforms') and any(
+        f.startswith('_waveform.') and f.endswith('.so')
+        for f in os.listdir(f'{SCRATCH}/waveforms'))
+    if not so_ok:
+        shutil.rmtree(SCRATCH, ignore_errors=True)
+        os.makedirs(SCRATCH)
+        shutil.copytree(f'{REF}/waveforms', f'{SCRATCH}/waveforms')
+        for f in ('setup.py', 'pyproject.toml'):
+            shutil.copy(f'{REF}/{f}', SCRATCH)
+        subprocess.run(['chmod', '-R', 'u+w', SCRATCH], check=True)
+        subprocess.run([sys.executable, 'setup.py', 'build_ext', '--inplace'],
+                       cwd=SCRATCH, check=True, stdout=subprocess.DEVNULL)
+    a = types.ModuleType('antlr4')
+    a.CommonTokenStream = a.InputStream = object
+    e = types.ModuleType('antlr4.error')
+    el = types.ModuleType('antlr4.error.ErrorListener')
+    el.ErrorListener = object
+    sys.modules.update({'antlr4': a, 'antlr4.error': e,
+                        'antlr4.error.ErrorListener': el})
+    sys.path.insert(0, SCRATCH)
+    import waveforms
+    import waveforms.distortion
+    from waveforms.waveform import WaveVStack
+    waveforms.WaveVStack = WaveVStack
+    assert waveforms.__file__.startswith(SCRATCH)
+    return waveforms
+
+
+def enc(v):
+    """JSON-encode one flat-list element, keeping its Python type family."""
+    if v is None or isinstance(v, (bool, str)):
+        return v
+    if isinstance(v, (tuple, list)):
+        return {'t': [enc(x) for x in v]}
+    if isinstance(v, (complex, np.complexfloating)):
+        return {'c': [float(v.real), float(v.imag)]}
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    return float(v)
+
+
+def main():
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    ref = import_reference()
+    import cases
+    from waveforms_amd import workloads as wl
+    from waveforms.waveform import WaveVStack
+
+    gold = os.path.join(REPO, 'tests', 'golden')
+    os.makedirs(gold, exist_ok=True)
+
+    frontend, samples = {}, {}
+    for name, (build, grid) in cases.CASES.items():
+        w = build(ref)
+        t = wl.make_grid(grid)
+        y = w(t)
+        frontend[name] = [enc(v) for v in w.tolist()]
+        samples[name + '.y'] = y
+        if isinstance(w, WaveVStack):
+            idx = [np.searchsorted(t - w.shift if w.shift != 0 else t, b)
+                   for b, _ in w.wlist]
+            samples[name + '.idx'] = (np.concatenate(idx) if idx else
+                                      np.zeros(0, np.int64))
+        else:
+            samples[name + '.idx'] = np.searchsorted(t, w.bounds)
+    with open(os.path.join(gold, 'frontend.json'), 'w') as f:
+        json.dump(frontend, f)
+    np.savez_compressed(os.path.join(gold, 'samples.npz'), **samples)
+
+    api = {}
+    for name, (build, start, stop, rate) in cases.sos_cases().items():
+        w = build(ref)
+        w.start, w.stop, w.sample_rate = start, stop, rate
+        api[name] = w.sample()
+    np.savez_compressed(os.path.join(gold, 'sample_api.npz'), **api)
+
+    # ---- big configs: subsets only -------------------------
+    big = {}
+
+    def subset(name, w, grid, stride):
+        t = wl.make_grid(grid)
+        y = w(t)
+        if isinstance(w, WaveVStack):
+            edges = np.unique(np.concatenate(
+                [np.searchsorted(t, b) for b, _ in w.wlist]))
+        else:
+            edges = np.searchsorted(t, w.bounds)
+            big[name + '.idx'] = edges
+        near = np.unique(np.clip(
+            (edges[:, None] + np.arange(-3, 4)[None, :]).ravel(), 0,
+            len(t) - 1))
+        pick = np.unique(np.concatenate([np.arange(0, len(t), stride), near]))
+        big[name + '.pick'] = pick
+        big[name + '.y'] = y[pick]
+        big[name + '.sum'] = np.array([y.sum(), np.abs(y).sum(),
+                                       np.sqrt((y * y).sum()), np.abs(y).max()])
+        return y
+
+    subset('c2', wl.c2_channel(ref), wl.c2_grid(), 997)
+    subset('c2_duty30', wl.c2_channel(ref, True), wl.c2_grid(duty30=True), 997)
+    for c in (0, 1, 255):
+        subset(f'c3_{c}', wl.vstack_channel(ref, 20, 100 + c), wl.c3_grid(), 499)
+    # C4 (FIR on a sampled channel) at 1e6 points so the fixture stays small
+    ker = wl.c4_kernel()
+    for c in (0, 7):
+        w = wl.sum_channel(ref, 100, 1000 + c)
+        grid = ('linspace', 0.0, 100 * wl.SPAN, 10**6, False)
+        y = subset(f'c4_{c}', w, grid, 499)
+        z = ref.distortion.predistort(y, ker=ker)
+        big[f'c4_{c}.fir'] = z[big[f'c4_{c}.pick']]
+        big[f'c4_{c}.firsum'] = np.array([z.sum(), np.abs(z).sum()])
+    np.savez_compressed(os.path.join(gold, 'big.npz'), **big)
+
+    # ---- FIR vectors (reference distortion.py:323-337; untested upstream) ----
+    fir = {}
+    rng = np.random.default_rng(42)
+    for i, (n, k) in enumerate([(1, 1), (5, 3), (64, 8), (100, 7), (1000, 64),
+                                (777, 1024), (4096, 1024), (20000, 1023),
+                                (30000, 1024), (9, 20)]):
+        sig = rng.normal(size=n)
+        kr = rng.normal(size=k)
+        fir[f'{i}.sig'] = sig
+        fir[f'{i}.ker'] = kr
+        fir[f'{i}.out'] = ref.distortion.predistort(sig, ker=kr)
+    np.savez_compressed(os.path.join(gold, 'fir.npz'), **fir)
+    for f in sorted(os.listdir(gold)):
+        print(f, os.path.getsize(os.path.join(gold, f)))
+
+
+if __name__ == '__main__':
+    main()

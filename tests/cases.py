@@ -1,0 +1,171 @@
+"""Pulse scripts shared by the golden-vector generator (run against the imported
+reference, oracle/make_golden.py) and by the parity tests (run against
+waveforms_amd).  Each case: name -> (builder(ns) -> Waveform | WaveVStack, grid).
+
+Grid descriptors: ('linspace', a, b, n, endpoint) | ('arange', a, b, step).
+Cases mirror what the reference's own tests sample (tests/test_waveform.py,
+tests/test_wavevstack.py in the reference) plus edge cases for every built-in
+primitive, clip, complex amplitudes, powers and piece-boundary alignment.
+"""
+import numpy as np
+from numpy import pi
+
+from waveforms_amd import workloads as wl
+
+LIN = ('linspace', -10.0, 10.0, 1001, True)
+
+
+def _ref_tolist_case(ns):          # reference tests/test_waveform.py:38-48
+    p = ns.gaussian(10) >> 5
+    p += ns.gaussian(10) >> 50
+    return p * ns.cos(200)
+
+
+def _vstack4(ns):                  # reference tests/test_wavevstack.py:10-26
+    return ns.WaveVStack([ns.cos(1), ns.sin(2), ns.gaussian(3),
+                          ns.poly([1, -1 / 2, 1 / 6, -1 / 12])])
+
+
+def _vstack_ops(ns):               # reference tests/test_wavevstack.py:46-88
+    w = _vstack4(ns)
+    return ((w * ns.sin(2) + 3) >> 0.6) + ns.sin(2)
+
+
+def _vstack_shift(ns):
+    return _vstack4(ns) << 1.4
+
+
+def _complex_amp(ns):              # reference tests/test_waveform.py:89-93
+    return 1j * (ns.cos(9) >> 1) + 1 * (ns.cos(9) >> 2) - 1j * (ns.cos(9) >> 3)
+
+
+def _exp_complex(ns):              # reference tests/test_waveform.py:96-105
+    return 2 * (ns.exp(1.01 + 22j)**2 << 1) * ns.exp(1.01 + 22j)
+
+
+def _clip(ns):
+    w = ns.cut(3 * ns.gaussian(4) * ns.cos(5), start=-2.5, stop=2.0, min=-0.7,
+               max=1.1)
+    return w
+
+
+def _readme_x(ns):
+    return wl.readme_xy(ns)[0]
+
+
+def _readme_y(ns):
+    return wl.readme_xy(ns)[1]
+
+
+def _mix_block(ns):
+    I, Q = ns.mixing(ns.gaussian(30e-9) >> 40e-9, ns.cosPulse(30e-9) >> 40e-9,
+                     freq=37e6, phase=0.4, phaseDiff=0.05, ratioIQ=0.9,
+                     block_freq=-150e6)
+    return I + 0.5 * Q
+
+
+def _mix_env(ns):
+    I, Q = ns.mixing(ns.square(50e-9, edge=10e-9) >> 40e-9, phase=1.1,
+                     DRAGScaling=3e-9)
+    return I - Q
+
+
+CASES = {
+    # --- reference-test mirrors -------------------------------------------
+    'cos1': (lambda ns: ns.cos(1), LIN),
+    'sin1': (lambda ns: ns.sin(1), LIN),
+    'gauss2': (lambda ns: ns.gaussian(2), LIN),
+    'gauss2_shift3': (lambda ns: ns.gaussian(2) >> 3, LIN),
+    'poly': (lambda ns: ns.poly([1, -1 / 2, 1 / 6, -1 / 12]), LIN),
+    'square_shift': (lambda ns: ns.square(20e-9) >> 40e-9,
+                     ('linspace', 0.0, 2000e-9, 8000, True)),
+    'ref_tolist': (_ref_tolist_case, ('linspace', -5.0, 60.0, 2601, True)),
+    'op_add': (lambda ns: ns.cos(1) + ns.sin(2), LIN),
+    'op_sub': (lambda ns: ns.cos(1) - ns.sin(2), LIN),
+    'op_mul': (lambda ns: ns.cos(1) * ns.sin(2), LIN),
+    'op_div': (lambda ns: ns.cos(1) / 2, LIN),
+    'trig3': (lambda ns: ns.cos(1) * ns.sin(2) * ns.cos(3, 4), LIN),
+    'complex_amp': (_complex_amp, ('linspace', -2.0, 2.0, 1001, True)),
+    'exp_complex': (_exp_complex, ('linspace', -2.0, 2.0, 1001, True)),
+    'chirp_lin': (lambda ns: ns.chirp(1, 2, 10, 4, 'linear'),
+                  ('linspace', 0.0, 10.0, 1000, False)),
+    'chirp_exp': (lambda ns: ns.chirp(1, 2, 10, 4, 'exponential'),
+                  ('linspace', 0.0, 10.0, 1000, False)),
+    'chirp_hyp': (lambda ns: ns.chirp(1, 2, 10, 4, 'hyperbolic'),
+                  ('linspace', 0.0, 10.0, 1000, False)),
+    'vstack4': (_vstack4, LIN),
+    'vstack_ops': (_vstack_ops, LIN),
+    'vstack_shift': (_vstack_shift, LIN),
+    'vstack_empty': (lambda ns: ns.WaveVStack([]) + 1.5, LIN),
+    # --- primitives & constructors ------------------------------------------
+    'step_erf': (lambda ns: ns.step(2.0) >> 1, LIN),
+    'step_cos': (lambda ns: ns.step(2.0, 'cos') >> 1, LIN),
+    'step_lin': (lambda ns: ns.step(2.0, 'linear') >> 1, LIN),
+    'step0': (lambda ns: ns.step(0) >> 0.5, LIN),
+    'sign': (lambda ns: ns.sign(), LIN),
+    'square_erf': (lambda ns: ns.square(8, edge=2), LIN),
+    'square_cos': (lambda ns: ns.square(8, edge=2, type='cos'), LIN),
+    'square_lin': (lambda ns: ns.square(8, edge=2, type='linear'), LIN),
+    'gauss_plateau': (lambda ns: ns.gaussian(4, plateau=6), LIN),
+    'dgauss2': (lambda ns: ns.gaussian(6, d=2), LIN),
+    'dgauss3_plateau': (lambda ns: ns.gaussian(4, plateau=3, d=3), LIN),
+    'cospulse': (lambda ns: ns.cosPulse(7) >> 1.5, LIN),
+    'cospulse_plateau': (lambda ns: ns.cosPulse(4, plateau=5), LIN),
+    'coshpulse': (lambda ns: ns.coshPulse(9, eps=2.5), LIN),
+    'coshpulse_plateau': (lambda ns: ns.coshPulse(6, eps=1.0, plateau=4), LIN),
+    'sinc': (lambda ns: ns.sinc(0.8) >> 0.3,
+             ('linspace', -70.0, 70.0, 2801, True)),
+    'exp_real': (lambda ns: ns.exp(-0.3) * ns.step(0), LIN),
+    'cosh_sinh': (lambda ns: 0.01 * ns.cosh(0.4) - 0.02 * ns.sinh(0.35), LIN),
+    'mollifier0': (lambda ns: ns.mollifier(12.0), LIN),
+    'mollifier1': (lambda ns: ns.mollifier(12.0, d=1), LIN),
+    'mollifier2_plateau': (lambda ns: ns.mollifier(8.0, plateau=4.0, d=2), LIN),
+    'general_cosine': (lambda ns: ns.general_cosine(16.0, 1.0, 0.3, 0.1), LIN),
+    't_lin': (lambda ns: 0.5 * ns.poly([1, 0.5]) + 1, LIN),
+    'drag_plain': (lambda ns: ns.drag(0.4, 12.0, t0=-6.0), LIN),
+    'drag_block': (lambda ns: ns.drag(0.4, 12.0, delta=0.05, block_freq=0.9,
+                                      phase=0.3, t0=-7.0), LIN),
+    'drag_plateau': (lambda ns: ns.drag(0.4, 6.0, plateau=5.0, delta=0.02,
+                                        block_freq=-0.5, t0=-8.0), LIN),
+    'sampling_points': (lambda ns: ns.samplingPoints(
+        -4.0, 6.0, [0.0, 1.0, -0.5, 2.0, 0.25, -1.0, 0.0]), LIN),
+    # --- algebra -------------------------------------------------------------
+    'pow2': (lambda ns: (ns.cos(1.3) + 0.5)**2, LIN),
+    'pow3_term': (lambda ns: (ns.gaussian(9) * ns.cos(2))**3, LIN),
+    'pow_frac': (lambda ns: (ns.gaussian(9) >> 1)**0.5, LIN),
+    'pow_neg': (lambda ns: (ns.cosh(0.2))**-2, LIN),
+    'deriv2': (lambda ns: ns.D(ns.gaussian(8) * ns.cos(3), 2), LIN),
+    'deriv_erf': (lambda ns: ns.D(ns.square(8, edge=2)), LIN),
+    'deriv_misc': (lambda ns: ns.D(ns.exp(-0.2) * ns.sinh(0.1) +
+                                   ns.chirp(0.1, 0.3, 10, 1.0)), LIN),
+    'clip': (_clip, LIN),
+    'clip_min_pos': (lambda ns: ns.cut(ns.gaussian(6), min=0.2, max=0.8), LIN),
+    # --- mixing / DRAG -------------------------------------------------------
+    'readme_x': (_readme_x, wl.readme_grid()),
+    'readme_y': (_readme_y, wl.readme_grid()),
+    'mix_block': (_mix_block, ('linspace', 0.0, 100e-9, 4001, True)),
+    'mix_env': (_mix_env, ('linspace', -20e-9, 100e-9, 3001, False)),
+    'c2_small': (lambda ns: wl.sum_channel(ns, 7, 3),
+                 ('linspace', 0.0, 7 * wl.SPAN, 5000, False)),
+    'c3_small': (lambda ns: wl.vstack_channel(ns, 5, 101),
+                 ('linspace', 0.0, 5 * wl.SPAN, 4000, False)),
+    'c2_duty30': (lambda ns: wl.sum_channel(ns, 5, 4, 100e-9),
+                  ('arange', 0.0, 500e-9, 0.125e-9)),
+    # --- grid edge cases -----------------------------------------------------
+    'single_point': (lambda ns: ns.gaussian(2) * ns.cos(3),
+                     ('linspace', 0.25, 0.25, 1, True)),
+    'all_outside': (lambda ns: ns.gaussian(2) >> 100, LIN),
+    'tiny_pieces': (lambda ns: wl.sum_channel(ns, 40, 9, 2e-9),
+                    ('linspace', 0.0, 100e-9, 777, True)),
+}
+
+
+def sos_cases():
+    """Waveform.sample() (np.arange grid) cases: name -> (builder, start, stop, rate)."""
+    return {
+        'sample_cos': (lambda ns: ns.cos(1), -10, 10.02, 50),
+        'sample_readme': (_readme_x, -1e-6, 9e-6, 1e9),
+        'sample_vstack': (_vstack4, -10, 10.02, 50),
+        'sample_odd': (lambda ns: ns.gaussian(3) * ns.cos(7) >> 0.1, -4.0, 4.3,
+                       123.456),
+    }

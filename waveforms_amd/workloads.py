@@ -1,0 +1,106 @@
+"""Synthetic workloads of BASELINE.json's configs C1..C5.
+
+Every builder takes a namespace `ns` exposing the reference's public names
+(`cosPulse`, `gaussian`, `mixing`, `zero`, `WaveVStack`, ...).  With
+`ns = waveforms_amd` they build this package's trees; the golden-vector script
+(oracle/make_golden.py) passes the imported reference instead, so both sides
+run the *same* pulse script.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+W = 20e-9          # gaussian(W): support +-0.75 W
+SPAN = 1.5 * W     # contiguous pulses => 100 % duty
+
+
+def readme_xy(ns):
+    """C1: the README 3-pulse cosPulse + mixing sequence (README.md:28-53)."""
+    pulse = ns.cosPulse(20e-9)
+    x_wav, y_wav = ns.zero(), ns.zero()
+    I, Q = ns.mixing(0.5 * pulse, freq=-20e6, DRAGScaling=0.2)
+    x_wav += I
+    y_wav += Q
+    I, Q = ns.mixing(pulse >> 1e-6, freq=-20e6, phase=np.pi / 2,
+                     DRAGScaling=0.2)
+    x_wav += I
+    y_wav += Q
+    I, Q = ns.mixing((0.5 * pulse) >> 2e-6, freq=-20e6, DRAGScaling=0.2)
+    x_wav += I
+    y_wav += Q
+    return x_wav, y_wav
+
+
+def readme_grid():
+    return ('linspace', -1e-6, 9e-6, 10001, True)
+
+
+def pulses(ns, nseg: int, seed: int, spacing: float = SPAN):
+    """`nseg` gaussian+DRAG pulses, SSB-mixed; parameters drawn in the order
+    A, f, phi from default_rng(seed) (SURVEY.md §8(d) shared pulse builder)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(nseg):
+        A = rng.uniform(0.1, 1)
+        f = rng.uniform(-200e6, 200e6)
+        phi = rng.uniform(0, 2 * np.pi)
+        I, _ = ns.mixing(A * ns.gaussian(W) >> ((k + 0.5) * spacing), freq=f,
+                         phase=phi, DRAGScaling=1e-10)
+        out.append(I)
+    return out
+
+
+def sum_channel(ns, nseg: int, seed: int, spacing: float = SPAN):
+    """One `Waveform` channel: the pulses summed symbolically (C2, C4, C5)."""
+    # pairwise tree sum keeps the host-side merge O(P log P) instead of O(P^2)
+    ws = pulses(ns, nseg, seed, spacing)
+    while len(ws) > 1:
+        nxt = [ws[i] + ws[i + 1] for i in range(0, len(ws) - 1, 2)]
+        if len(ws) % 2:
+            nxt.append(ws[-1])
+        ws = nxt
+    return ws[0]
+
+
+def vstack_channel(ns, nseg: int, seed: int):
+    """One `WaveVStack` channel (C3)."""
+    return ns.WaveVStack(pulses(ns, nseg, seed))
+
+
+def c2_channel(ns, duty30: bool = False):
+    return sum_channel(ns, 100, 0, 100e-9 if duty30 else SPAN)
+
+
+def c2_grid(n=10**7, duty30: bool = False):
+    span = 100e-9 if duty30 else SPAN
+    return ('linspace', 0.0, 100 * span, n, False)
+
+
+def c3_channels(ns, nch=256):
+    return [vstack_channel(ns, 20, 100 + c) for c in range(nch)]
+
+
+def c3_grid(n=10**6):
+    return ('linspace', 0.0, 20 * SPAN, n, False)
+
+
+def c4_channels(ns, nch=256, nseg=100):
+    return [sum_channel(ns, nseg, 1000 + c) for c in range(nch)]
+
+
+def c4_kernel(K=1024):
+    ker = np.random.default_rng(1).normal(size=K)
+    ker /= abs(ker).sum()
+    return ker
+
+
+def make_grid(desc):
+    """Materialise a grid descriptor with NumPy (host reference grid)."""
+    kind = desc[0]
+    if kind == 'linspace':
+        _, a, b, n, endpoint = desc
+        return np.linspace(a, b, n, endpoint=endpoint)
+    if kind == 'arange':
+        _, a, b, step = desc
+        return np.arange(a, b, step)
+    raise ValueError(kind)
