@@ -1,0 +1,177 @@
+/*
+ * wfk.h -- C-ABI of the MI355X waveform-sampling engine (libwfk_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of feihoo87/waveforms:
+ *   piecewise sum-of-products expression tree  ->  dense sample array
+ * i.e. what the reference does inside
+ *   calc_parts()            waveforms/_waveform.pyx:155-169   (+ _calc :134-152, _apply :130-131)
+ *   Waveform._fill_parts()  waveforms/waveform.py:524-527
+ *   Waveform.__call__()     waveforms/waveform.py:529-563
+ *   WaveVStack.__call__()   waveforms/waveform.py:679-693
+ *   Waveform.sample()       waveforms/waveform.py:173-207    (np.arange grid)
+ *   predistort(ker=...)     waveforms/distortion.py:323-337  (FIR branch)
+ *
+ * Plain C: pointers and sizes only, no torch / HIP types.  Every function
+ * returns 0 on success or a negative WFK_E* code; wfk_last_error() returns a
+ * thread-local message.  The caller owns every host buffer and every opaque
+ * handle (explicit *_destroy); the library owns device tables inside a plan.
+ * wfk_plan_launch() and wfk_fir_apply() do no allocation and no host sync.
+ */
+#ifndef WFK_H
+#define WFK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFK_ABI_VERSION 1
+
+/* error codes */
+#define WFK_OK 0
+#define WFK_EINVAL (-1)   /* malformed program / argument                      */
+#define WFK_EUNSUP (-2)   /* primitive id without a device implementation      */
+#define WFK_EHIP   (-3)   /* HIP runtime / rocFFT failure                      */
+#define WFK_ENOMEM (-4)
+
+/* Primitive ids == the reference registry (waveforms/_waveform.pyx:374-388).
+ * args (in `pool`, at fc_arg_off) per id, evaluated at u = t - shift:
+ *   1 LINEAR            ()                      u
+ *   2 GAUSSIAN          (std_sq2)               exp(-(u/std_sq2)^2)                 pyx:294-295
+ *   3 ERF               (std_sq2)               erf(u/std_sq2)                      pyx:303-304
+ *   4 COS               (w)                     cos(w*u)                            pyx:307-308
+ *   5 SINC              (bw)                    np.sinc(bw*u)                       pyx:311-312
+ *   6 EXP               (alpha)                 exp(alpha*u)                        pyx:315-316
+ *   7 INTERP            (start, stop, p0..pm-1) np.interp(u, linspace(start,stop,m), p)   pyx:319-320
+ *   8 LINEARCHIRP       (f0, f1, T, phi0)       pyx:323-324
+ *   9 EXPONENTIALCHIRP  (f0, alpha, phi0)       pyx:327-328
+ *  10 HYPERBOLICCHIRP   (f0, k, phi0)           pyx:331-332
+ *  11 COSH (w)  12 SINH (w)                     pyx:335-340
+ *  13 DRAG              (t0, freq, width, delta, block_freq|NaN=None, phase)        pyx:343-356
+ *  14 MOLLIFIER         (r, d)                  pyx:359-371
+ *  15 D_GAUSSIAN        (std_sq2, n)            pyx:298-300
+ * Any other id -> WFK_EUNSUP (Python callables cannot run on the device).      */
+enum {
+  WFK_LINEAR = 1, WFK_GAUSSIAN = 2, WFK_ERF = 3, WFK_COS = 4, WFK_SINC = 5,
+  WFK_EXP = 6, WFK_INTERP = 7, WFK_LINEARCHIRP = 8, WFK_EXPONENTIALCHIRP = 9,
+  WFK_HYPERBOLICCHIRP = 10, WFK_COSH = 11, WFK_SINH = 12, WFK_DRAG = 13,
+  WFK_MOLLIFIER = 14, WFK_D_GAUSSIAN = 15
+};
+
+/*
+ * Flattened expression forest (struct-of-arrays, depth-first in the order of
+ * the reference's own flattener Waveform._tolist, waveforms/waveform.py:259-276):
+ *
+ *   channel  = one output row.  A `Waveform` is a channel with ONE member and
+ *              its min/max as clip; a `WaveVStack` is a channel with one member
+ *              per wlist entry, `offset`, `shift`, and clip = -inf/+inf.
+ *   member   = (bounds, seq): pieces in ascending bound order, last bound +inf.
+ *              piece i is live for bound[i-1] <= t - tshift < bound[i]
+ *              (np.searchsorted side='left', _waveform.pyx:156).
+ *   piece    = sum of terms;  term = amp * prod_j factor_j(t - tshift - shift_j)^power_j
+ */
+typedef struct wfk_program {
+  int32_t n_channels, n_members, n_pieces, n_terms, n_factors;
+  int64_t n_pool;
+  const int32_t* ch_member_off;  /* [n_channels+1]                               */
+  const double*  ch_offset;      /* [n_channels]  WaveVStack.offset (real part)  */
+  const double*  ch_tshift;      /* [n_channels]  WaveVStack.shift               */
+  const double*  ch_clip_lo;     /* [n_channels]  Waveform.min                   */
+  const double*  ch_clip_hi;     /* [n_channels]  Waveform.max                   */
+  const int32_t* mb_piece_off;   /* [n_members+1]                                */
+  const double*  pc_bound;       /* [n_pieces]    upper bound in seconds         */
+  const int32_t* pc_term_off;    /* [n_pieces+1]                                 */
+  const double*  tm_amp_re;      /* [n_terms]                                    */
+  const double*  tm_amp_im;      /* [n_terms]                                    */
+  const int32_t* tm_factor_off;  /* [n_terms+1]                                  */
+  const int32_t* fc_type;        /* [n_factors]   primitive id                   */
+  const double*  fc_power;       /* [n_factors]                                  */
+  const double*  fc_shift;       /* [n_factors]                                  */
+  const int64_t* fc_arg_off;     /* [n_factors+1] into pool                      */
+  const double*  pool;           /* [n_pool]                                     */
+} wfk_program;
+
+/* Uniform time grid, bit-identical to NumPy's:
+ *   t[i] = fl(fl(i*step) + t0)           np.linspace / np.arange element formula
+ *   t[n-1] = last  if has_last            np.linspace(endpoint=True) override
+ * (replaces the `x` argument of Waveform.__call__ and the
+ *  np.arange of Waveform.sample, waveforms/waveform.py:190,232).               */
+typedef struct wfk_grid {
+  double t0, step;
+  int64_t n;
+  int32_t has_last;
+  double last;
+} wfk_grid;
+
+enum { WFK_OUT_F64 = 0, WFK_OUT_F32 = 1, WFK_OUT_C128 = 2, WFK_OUT_C64 = 3 };
+
+/* launch flags */
+#define WFK_ACCUMULATE 1u   /* out += samples  (Waveform.__call__(accumulate=True)) */
+
+typedef struct wfk_plan wfk_plan;
+typedef struct wfk_fir_plan wfk_fir_plan;
+
+typedef struct wfk_plan_info {
+  int32_t n_channels;
+  int64_t n;             /* samples per channel                                  */
+  int32_t tile;          /* samples per workgroup tile                           */
+  int64_t n_tiles;       /* workgroups per launch                                */
+  int32_t n_pieces;      /* merged device pieces                                 */
+  int64_t param_doubles; /* device parameter stream length                      */
+  int32_t n_fast;        /* factor uses on a recurrence / table fast path        */
+  int32_t n_direct;      /* factor uses evaluated with device libm               */
+} wfk_plan_info;
+
+int         wfk_abi_version(void);
+const char* wfk_last_error(void);
+int         wfk_device_count(int* count);
+int         wfk_set_device(int ordinal);
+
+/* -- sampler plans ------------------------------------------------------- */
+/* grid mode: replaces calc_parts(bounds, seq, x=grid, ...) for every channel   */
+int wfk_plan_create_grid(const wfk_program* prog, const wfk_grid* grid,
+                         wfk_plan** out);
+/* tlist mode: x is an explicit sorted float64 array on the host (it is
+ * uploaded); replaces Waveform.__call__(x) for arbitrary x                     */
+int wfk_plan_create_tlist(const wfk_program* prog, const double* t_host,
+                          int64_t n, wfk_plan** out);
+int wfk_plan_destroy(wfk_plan* plan);
+int wfk_plan_get_info(const wfk_plan* plan, wfk_plan_info* info);
+/* np.searchsorted(x - tshift, bounds) of one member (integer parity probe);
+ * writes min(cap, #bounds) values, returns #bounds                            */
+int wfk_plan_member_index(const wfk_plan* plan, int32_t member, int64_t* idx,
+                          int32_t cap);
+/* 1 if a live piece of `channel` has a complex amplitude (dtype detection of
+ * calc_parts, _waveform.pyx:164-166)                                          */
+int wfk_plan_channel_is_complex(const wfk_plan* plan, int32_t channel);
+/* Evaluate every channel into out_dev[ch*ch_stride + i] (elements of out_kind).
+ * Asynchronous on `hip_stream` (a hipStream_t, or NULL for the null stream).   */
+int wfk_plan_launch(wfk_plan* plan, void* out_dev, int64_t ch_stride,
+                    int out_kind, uint32_t flags, void* hip_stream);
+/* launch into an internal device buffer, copy to out_host, synchronise         */
+int wfk_plan_run_host(wfk_plan* plan, void* out_host, int64_t ch_stride,
+                      int out_kind);
+
+/* -- FIR stage: out[i] = sum_k ker[k] * sig[i + K/2 - k], zero padded ------- */
+/* replaces predistort(sig, ker=ker), waveforms/distortion.py:329-337          */
+int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n,
+                        int32_t batch, int kind /* WFK_OUT_F64|F32 */,
+                        wfk_fir_plan** out);
+int wfk_fir_apply(wfk_fir_plan* plan, const void* in_dev, int64_t in_stride,
+                  void* out_dev, int64_t out_stride, void* hip_stream);
+int wfk_fir_plan_destroy(wfk_fir_plan* plan);
+
+/* -- device memory helpers for FFI callers without a HIP binding ---------- */
+int wfk_malloc(void** dev_ptr, size_t bytes);
+int wfk_free(void* dev_ptr);
+int wfk_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int wfk_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int wfk_memset(void* dst_dev, int byte, size_t bytes);
+int wfk_stream_sync(void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFK_H */

@@ -1,0 +1,126 @@
+"""NumPy restatement of the reference evaluator (TEST INFRASTRUCTURE ONLY).
+
+Same pass structure as the reference's CPU path -- one NumPy ufunc pass per
+operation, a per-piece factor cache, np.clip per piece, `out[a:b] += part` --
+so that (i) it is a second, independent checker for the HIP path on the GPU box,
+where the reference itself does not exist, and (ii) timing it gives the
+"reference-like CPU path" that BASELINE.md §3 names as the denominator of the
+speed-up target.  Follows:
+    calc_parts / _calc / _apply      waveforms/_waveform.pyx:130-169
+    built-in primitives              waveforms/_waveform.pyx:290-371
+    Waveform.__call__ / _fill_parts  waveforms/waveform.py:524-563
+    WaveVStack.__call__              waveforms/waveform.py:679-693
+    Waveform.sample                  waveforms/waveform.py:173-207
+    predistort (FIR branch)          waveforms/distortion.py:329-337
+Pinned against tests/golden (made by running the real reference) in
+tests/test_oracle_golden.py.  Never imported by waveforms_amd.
+"""
+import numpy as np
+import scipy.special as special
+from scipy.signal import fftconvolve
+
+_ZERO = ((), ())
+
+
+def _drag(t, t0, freq, width, delta, block_freq, phase):
+    o = np.pi / width
+    ox = np.sin(o * (t - t0))**2
+    wt = 2 * np.pi * (freq + delta) * t - (2 * np.pi * delta * t0 + phase)
+    if block_freq is None or block_freq - delta == 0:
+        return ox * np.cos(wt)
+    b = 1 / np.pi / 2 / (block_freq - delta)
+    oy = -b * o * np.sin(2 * o * (t - t0))
+    return ox * np.cos(wt) + oy * np.sin(wt)
+
+
+def _mollifier(t, r, d):
+    x = t / r
+    q = np.abs(x)**2 - 1
+    if d == 0:
+        return np.where(q >= 0, 0, np.exp(1 / q + 1))
+    p = np.poly1d([-2, 0])
+    for n in range(1, d):
+        p = (np.poly1d([1, 0, -2, 0, 1]) * p.deriv() +
+             np.poly1d([-4 * n, 0, 4 * n - 2, 0]) * p)
+    return np.where(q >= 0, 0, np.exp(1 / q + 1) / (-q)**(2 * d)) * p(x) / r**d
+
+
+PRIMITIVES = {
+    1: lambda t: t,
+    2: lambda t, s: np.exp(-(t / s)**2),
+    3: lambda t, s: special.erf(t / s),
+    4: lambda t, w: np.cos(w * t),
+    5: lambda t, bw: np.sinc(bw * t),
+    6: lambda t, a: np.exp(a * t),
+    7: lambda t, a, b, pts: np.interp(t, np.linspace(a, b, len(pts)), pts),
+    8: lambda t, f0, f1, T, p: np.sin(p + 2 * np.pi * ((f1 - f0) / (2 * T) * t**2 + f0 * t)),
+    9: lambda t, f0, al, p: np.sin(p + 2 * np.pi * f0 * (np.exp(al * t) - 1) / al),
+    10: lambda t, f0, k, p: np.sin(p + 2 * np.pi * f0 / k * np.log(1 + k * t)),
+    11: lambda t, w: np.cosh(w * t),
+    12: lambda t, w: np.sinh(w * t),
+    13: _drag,
+    14: _mollifier,
+    15: lambda t, s, n: ((-1)**n / s**n * special.hermite(n)(t / s) *
+                         np.exp(-(t / s)**2)),
+}
+
+
+def eval_expr(expr, x):
+    cache = {}
+    total = 0
+    for (factors, powers), amp in zip(*expr):
+        prod = 1
+        for f, n in zip(factors, powers):
+            if f not in cache:
+                type_id, *args, shift = f
+                cache[f] = PRIMITIVES[type_id](x - shift, *args)
+            prod = prod * (cache[f] if n == 1 else cache[f]**n)
+        total = total + amp * prod
+    return total
+
+
+def pieces(bounds, seq, x, lo=-np.inf, hi=np.inf):
+    edges = np.searchsorted(x, bounds)
+    parts, dtype, a = [], float, 0
+    for i, b in enumerate(edges):
+        if a < b and seq[i] != _ZERO:
+            part = np.clip(eval_expr(seq[i], x[a:b]), lo, hi)
+            if isinstance(part, complex) or (isinstance(part, np.ndarray) and
+                                             isinstance(part[0], complex)):
+                dtype = complex
+            parts.append((a, b, part))
+        a = b
+    return parts, dtype
+
+
+def call_waveform(w, x):
+    parts, dtype = pieces(w.bounds, w.seq, x, w.min, w.max)
+    out = np.zeros_like(x, dtype=dtype)
+    for a, b, part in parts:
+        out[a:b] += part
+    return out
+
+
+def call_vstack(w, x):
+    out = np.full_like(x, w.offset, dtype=np.complex128)
+    if w.shift != 0:
+        x = x - w.shift
+    for bounds, seq in w.wlist:
+        for a, b, part in pieces(bounds, seq, x)[0]:
+            out[a:b] += part
+    return out.real
+
+
+def call(w, x):
+    return call_vstack(w, x) if hasattr(w, 'wlist') else call_waveform(w, x)
+
+
+def sample(w):
+    return call(w, np.arange(w.start, w.stop, 1 / w.sample_rate))
+
+
+def predistort_fir(sig, ker):
+    n = len(sig)
+    padded = np.hstack((np.zeros_like(sig), sig, np.zeros_like(sig)))
+    a = n + len(ker) // 2
+    return fftconvolve(padded, ker, mode='full')[a:a + n]

@@ -1,0 +1,99 @@
+"""Pin both oracles (oracle/np_oracle.py, oracle/wfk_oracle.c) against golden
+vectors produced by running the real reference (oracle/make_golden.py).
+
+This also covers the host-side flattener: the C oracle consumes the
+`wfk_program` it emits.  Tolerances: the C oracle uses glibc libm where NumPy
+uses its own SIMD ufunc loops (<= few ulp apart), so values are compared at
+1e-12 relative to the case's peak; integer piece indices must be identical."""
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+import waveforms_amd as wf
+from oracle import c_oracle, np_oracle
+from waveforms_amd import _flatten, workloads as wl
+
+SAMPLES = golden_io.npz('samples.npz')
+API = golden_io.npz('sample_api.npz')
+FIR = golden_io.npz('fir.npz')
+
+
+def close(got, want, rel=1e-12):
+    scale = max(1.0, float(np.max(np.abs(want)))) if want.size else 1.0
+    assert got.shape == want.shape
+    assert got.dtype == want.dtype
+    err = np.max(np.abs(got - want)) if want.size else 0.0
+    assert err <= rel * scale, (err, scale)
+
+
+@pytest.mark.parametrize('name', sorted(cases.CASES))
+def test_np_oracle_matches_reference(name):
+    build, grid = cases.CASES[name]
+    w = build(wf)
+    t = wl.make_grid(grid)
+    close(np_oracle.call(w, t), SAMPLES[name + '.y'], rel=1e-14)
+
+
+@pytest.mark.parametrize('name', sorted(cases.CASES))
+def test_c_oracle_matches_reference(name):
+    build, grid = cases.CASES[name]
+    w = build(wf)
+    want = SAMPLES[name + '.y']
+    prog = _flatten.flatten([w])
+    g = _flatten.grid_from_desc(grid)
+    t = wl.make_grid(grid)
+    assert np.array_equal(c_oracle.grid_values(g), t)       # bit-exact grid
+    cplx = want.dtype == np.complex128
+    got = c_oracle.eval_grid(prog, g, cplx)[0]
+    close(got, want)
+    got_t = c_oracle.eval_tlist(prog, t, cplx)[0]
+    assert np.array_equal(got, got_t, equal_nan=True)
+    # integer parity: np.searchsorted indices of every member
+    m0, m1 = prog.member_range(0)
+    idx = np.concatenate([c_oracle.member_index(prog, m, grid=g)
+                          for m in range(m0, m1)]) if m1 > m0 else np.zeros(0, np.int64)
+    assert np.array_equal(idx, SAMPLES[name + '.idx'])
+
+
+@pytest.mark.parametrize('name', sorted(cases.sos_cases()))
+def test_sample_api_grid(name):
+    build, start, stop, rate = cases.sos_cases()[name]
+    w = build(wf)
+    w.start, w.stop, w.sample_rate = start, stop, rate
+    want = API[name]
+    close(np_oracle.sample(w), want, rel=1e-14)
+    g = _flatten.grid_arange(start, stop, 1 / rate)
+    assert g.n == len(want)
+    assert np.array_equal(c_oracle.grid_values(g), np.arange(start, stop, 1 / rate))
+    close(c_oracle.eval_grid(_flatten.flatten([w]), g)[0], want)
+
+
+def test_reference_known_answers():
+    # reference tests/test_waveform.py:8-35 closed forms
+    t = np.linspace(-10, 10, 1001)
+    assert np.allclose(np_oracle.call(wf.cos(1), t), np.cos(t), atol=1e-4)
+    assert np.allclose(np_oracle.call(wf.sin(1), t), np.sin(t), atol=1e-4)
+    s = 2 / (4 * np.sqrt(np.log(2)))
+    assert np.allclose(np_oracle.call(wf.gaussian(2), t), np.exp(-(t / s)**2),
+                       atol=5e-3)
+    assert np.allclose(np_oracle.call(wf.poly([1, -1 / 2, 1 / 6, -1 / 12]), t),
+                       np.poly1d([-1 / 12, 1 / 6, -1 / 2, 1])(t))
+    # SURVEY.md Appendix E (README config)
+    x, y = wl.readme_xy(wf)
+    tt = np.linspace(-1e-6, 9e-6, 10001)
+    xv, yv = np_oracle.call(x, tt), np_oracle.call(y, tt)
+    assert np.array_equal(np.searchsorted(tt, x.bounds),
+                          [990, 1010, 1990, 2010, 2990, 3010, 10001])
+    assert xv[989] == 0.0 and xv[1010] == 0.0
+    assert abs(xv[1000] - 0.5) < 1e-8 and abs(yv[2000] - 1.0) < 1e-8
+    assert abs(xv.sum() - 224873786.26300055) < 1e-3
+
+
+@pytest.mark.parametrize('i', range(10))
+def test_fir_oracles(i):
+    sig, ker, want = FIR[f'{i}.sig'], FIR[f'{i}.ker'], FIR[f'{i}.out']
+    scale = max(1.0, np.abs(want).max())
+    assert np.max(np.abs(np_oracle.predistort_fir(sig, ker) - want)) <= 1e-13 * scale
+    if len(sig) * len(ker) <= 5e7:
+        assert np.max(np.abs(c_oracle.fir(sig, ker) - want)) <= 1e-12 * scale
