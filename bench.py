@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the sampling hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" = one pass of the sampler over one batch of synthetic channels with the
+output left resident in HBM (that is where the API leaves it: BatchSampler.launch).
+Workloads (SURVEY.md §8(d) / BASELINE.json configs):
+  sampler256 (default)  256 channels x 1e7 points, 100 gaussian+DRAG pulses per
+                        channel (the C4/C5 channel spec), fp64, grid mode
+  c2                    1 channel x 100 pulses x 1e7 points, fp64
+  c3                    256 WaveVStack channels x 20 pulses x 1e6 points, fp32
+  c4                    sampler256 followed by the 1024-tap FIR stage
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); channels are
+independent, so each rank samples its own block of 256 channels with no data-path
+collective (weak scaling); time = max over ranks between two barriers.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def build_workload(name, rank, channels, points):
+    import waveforms_amd as wf
+    from waveforms_amd import workloads as wl
+    base = rank * channels
+    if name in ('sampler256', 'c4'):
+        chans = [wl.sum_channel(wf, 100, 1000 + base + c) for c in range(channels)]
+        return chans, wl.c2_grid(points), np.float64, (
+            f'{channels} ch x {points:.0e} pts, 100 gaussian+DRAG pulses/ch '
+            f'(SURVEY 8(d) C4/C5 channel spec), grid mode')
+    if name == 'c2':
+        return [wl.c2_channel(wf)], wl.c2_grid(points), np.float64, (
+            f'C2: 1 ch x 100 gaussian+DRAG pulses x {points:.0e} pts')
+    if name == 'c3':
+        chans = [wl.vstack_channel(wf, 20, 100 + base + c) for c in range(channels)]
+        return chans, wl.c3_grid(points), np.float32, (
+            f'C3: {channels} WaveVStack ch x 20 pulses x {points:.0e} pts')
+    raise SystemExit(f'unknown workload {name}')
+
+
+def cpu_baseline(chans, grid_desc, budget_s=12.0):
+    """Reference-like NumPy path (oracle/np_oracle.py: same pass structure as the
+    reference's calc_parts/_calc/_fill_parts) timed single-threaded on this box's
+    host, on as many channels of the same workload as fit the time budget."""
+    from oracle import np_oracle
+    from waveforms_amd import workloads as wl
+    t = wl.make_grid(grid_desc)
+    done, t0, outs = 0, time.perf_counter(), []
+    for w in chans:
+        y = np_oracle.call(w, t)
+        if done < 2:
+            outs.append(y)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {'value': done * len(t) / dt / 1e6, 'unit': 'Msamples/s', 'cores': 1,
+            'kind': 'port',
+            'sample': f'{done} channel(s) x {len(t)} pts of the same workload, '
+                      f'NumPy restatement of the reference pass structure, '
+                      f'{dt:.1f} s, host has {os.cpu_count()} cores'}, outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='sampler256')
+    ap.add_argument('--channels', type=int, default=None)
+    ap.add_argument('--points', type=float, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the sampler has no CPU path)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from waveforms_amd import _engine
+    from waveforms_amd._sampling import BatchSampler
+    _engine.set_device(local_rank)
+
+    name = args.workload
+    channels = args.channels or (1 if name == 'c2' else 256)
+    points = int(args.points or (10**6 if name == 'c3' else 10**7))
+    chans, grid, dtype, desc = build_workload(name, rank, channels, points)
+    bs = BatchSampler(chans, grid)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    out = torch.empty((bs.n_channels, bs.n), dtype=tdt, device='cuda')
+    fir = None
+    if name == 'c4':
+        from waveforms_amd.distortion import FirStage
+        from waveforms_amd import workloads as wl
+        fir = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
+        out2 = torch.empty_like(out)
+
+    def step():
+        bs.launch_torch(out)
+        if fir is not None:
+            fir.apply_torch(out, out2)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()          # events on torch's current stream == the launch stream
+        bs.launch_torch(out)
+        b.record()
+        if fir is not None:
+            fir.apply_torch(out, out2)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    samples_per_step = bs.n_channels * bs.n * world
+    elem = np.dtype(dtype).itemsize
+    algo_bytes = bs.n_channels * bs.n * elem            # per launch, per GPU
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(name)
+
+    line = {
+        'metric': 'Msamples/s (all channels)',
+        'value': samples_per_step * args.steps / elapsed / 1e6,
+        'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64' if dtype == np.float64 else 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{name}: {desc}', 'channels_per_gpu': bs.n_channels,
+                   'points_per_channel': bs.n, 'output': 'device (HBM) buffer',
+                   'parallelism': f'channel-block-per-rank x{world}, no collective'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': traffic, 'kernel': 'wfk_sample',
+                     'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': algo_bytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, outs = cpu_baseline(chans, grid)
+        line['cpu_baseline'] = base
+        line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
+        got = out[:len(outs)].cpu().numpy().astype(np.float64)
+        line['max_abs_err_vs_numpy_ref'] = float(
+            max(np.max(np.abs(got[i] - outs[i])) for i in range(len(outs))))
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

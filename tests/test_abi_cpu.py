@@ -1,0 +1,95 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/wfk.h declares, compiles plans without a GPU (host-only plans) and gets
+the INTEGER part of the contract bit-exact: np.searchsorted piece indices."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+import waveforms_amd as wf
+from waveforms_amd import _engine, _flatten, workloads as wl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAMPLES = golden_io.npz('samples.npz')
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'wfk.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(wfk_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _engine.lib()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.wfk_abi_version() == 1
+
+
+def _indices(plan, prog):
+    m0, m1 = prog.member_range(0)
+    if m1 == m0:
+        return np.zeros(0, np.int64)
+    return np.concatenate([plan.member_index(m) for m in range(m0, m1)])
+
+
+@pytest.mark.parametrize('name', sorted(cases.CASES))
+def test_piece_indices_bit_exact(name):
+    build, grid = cases.CASES[name]
+    prog = _flatten.flatten([build(wf)])
+    want = SAMPLES[name + '.idx']
+    plan = _engine.Plan(prog, grid=_flatten.grid_from_desc(grid))
+    assert np.array_equal(_indices(plan, prog), want)
+    plan2 = _engine.Plan(prog, t=wl.make_grid(grid))
+    assert np.array_equal(_indices(plan2, prog), want)
+    assert plan.n == plan2.n == len(SAMPLES[name + '.y'])
+
+
+def test_big_grid_indices():
+    big = golden_io.npz('big.npz')
+    prog = _flatten.flatten([wl.c2_channel(wf)])
+    plan = _engine.Plan(prog, grid=_flatten.grid_from_desc(wl.c2_grid()))
+    assert np.array_equal(plan.member_index(0), big['c2.idx'])
+    assert plan.info.n_direct == 0 and plan.info.n_fast > 0
+
+
+def test_unsupported_primitive_raises():
+    w = wf.function(lambda t: t * 0 + 1.0)
+    with pytest.raises(NotImplementedError):
+        _flatten.flatten([w])
+    with pytest.raises(NotImplementedError):
+        wf.cos(1)(np.linspace(0, 1, 5), function_lib={1: lambda t: t})
+
+
+def test_sample_needs_init():
+    with pytest.raises(ValueError):
+        wf.cos(1).sample()
+
+
+def test_vstack_frag_asserts():
+    with pytest.raises(AssertionError):
+        wf.WaveVStack([wf.cos(1)])(np.linspace(0, 1, 5), frag=True)
+
+
+@pytest.mark.skipif(_engine.device_count() > 0, reason='GPU present')
+def test_launch_without_gpu_fails_loudly():
+    with pytest.raises(_engine.EngineError):
+        wf.cos(1)(np.linspace(0, 1, 5))
+
+
+def test_arange_grid_formula():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        start = rng.uniform(-1e-5, 1e-5)
+        rate = 10**rng.uniform(6, 10)
+        stop = start + rng.uniform(1, 5000) / rate
+        g = _flatten.grid_arange(start, stop, 1 / rate)
+        ref = np.arange(start, stop, 1 / rate)
+        assert g.n == len(ref)
+        i = np.arange(g.n, dtype=np.float64)
+        assert np.array_equal(i * g.step + g.t0, ref)

@@ -1,0 +1,201 @@
+"""ctypes binding of libwfk_hip.so (include/wfk.h).
+
+This is the only door from Python to the sampler.  There is no fallback: if the
+shared library is missing it cannot be imported, and if no GPU is visible every
+launch raises.  ctypes releases the GIL during calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._flatten import Program, wfk_grid, wfk_program
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libwfk_hip.so')
+
+OUT_F64, OUT_F32, OUT_C128, OUT_C64 = 0, 1, 2, 3
+ACCUMULATE = 1
+_KIND_OF = {np.dtype(np.float64): OUT_F64, np.dtype(np.float32): OUT_F32,
+            np.dtype(np.complex128): OUT_C128, np.dtype(np.complex64): OUT_C64}
+_DTYPE_OF = {v: k for k, v in _KIND_OF.items()}
+
+E_UNSUP = -2
+
+
+class wfk_plan_info(C.Structure):
+    _fields_ = [('n_channels', C.c_int32), ('n', C.c_int64), ('tile', C.c_int32),
+                ('n_tiles', C.c_int64), ('n_pieces', C.c_int32),
+                ('param_doubles', C.c_int64), ('n_fast', C.c_int32),
+                ('n_direct', C.c_int32)]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libwfk_hip.so (built by waveforms_amd/csrc/Makefile or
+    __graft_entry__.build()).  Fails loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f'{LIB_PATH} not found: build it with `make -C waveforms_amd/csrc` '
+                f'(hipcc --offload-arch=gfx950). waveforms_amd has no CPU sampling path.')
+        l = C.CDLL(LIB_PATH)
+        l.wfk_last_error.restype = C.c_char_p
+        P, I64, I32, VP = C.POINTER, C.c_int64, C.c_int32, C.c_void_p
+        l.wfk_plan_create_grid.argtypes = [P(wfk_program), P(wfk_grid), P(VP)]
+        l.wfk_plan_create_tlist.argtypes = [P(wfk_program), VP, I64, P(VP)]
+        l.wfk_plan_destroy.argtypes = [VP]
+        l.wfk_plan_get_info.argtypes = [VP, P(wfk_plan_info)]
+        l.wfk_plan_member_index.argtypes = [VP, I32, VP, I32]
+        l.wfk_plan_channel_is_complex.argtypes = [VP, I32]
+        l.wfk_plan_launch.argtypes = [VP, VP, I64, C.c_int, C.c_uint32, VP]
+        l.wfk_plan_run_host.argtypes = [VP, VP, I64, C.c_int]
+        l.wfk_fir_plan_create.argtypes = [VP, I32, I64, I32, C.c_int, P(VP)]
+        l.wfk_fir_apply.argtypes = [VP, VP, I64, VP, I64, VP]
+        l.wfk_fir_plan_destroy.argtypes = [VP]
+        l.wfk_malloc.argtypes = [P(VP), C.c_size_t]
+        l.wfk_free.argtypes = [VP]
+        l.wfk_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
+        l.wfk_memcpy_d2h.argtypes = [VP, VP, C.c_size_t]
+        l.wfk_memset.argtypes = [VP, C.c_int, C.c_size_t]
+        l.wfk_stream_sync.argtypes = [VP]
+        l.wfk_device_count.argtypes = [P(C.c_int)]
+        l.wfk_set_device.argtypes = [C.c_int]
+        if l.wfk_abi_version() != 1:
+            raise EngineError('libwfk_hip.so ABI version mismatch')
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        msg = lib().wfk_last_error().decode('utf-8', 'replace')
+        if rc == E_UNSUP:
+            raise NotImplementedError(msg)
+        raise EngineError(f'wfk error {rc}: {msg}')
+    return rc
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().wfk_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def set_device(ordinal: int):
+    check(lib().wfk_set_device(ordinal))
+
+
+class Plan:
+    """A compiled program bound to a time axis (grid or explicit t)."""
+
+    def __init__(self, prog: Program, grid: wfk_grid | None = None, t=None):
+        self.prog = prog
+        self._h = C.c_void_p()
+        if grid is not None:
+            self.grid = grid
+            check(lib().wfk_plan_create_grid(C.byref(prog.struct), C.byref(grid),
+                                             C.byref(self._h)))
+        else:
+            t = np.ascontiguousarray(t, dtype=np.float64)
+            check(lib().wfk_plan_create_tlist(C.byref(prog.struct), t.ctypes.data,
+                                              len(t), C.byref(self._h)))
+        info = wfk_plan_info()
+        check(lib().wfk_plan_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.n = int(info.n)
+        self.n_channels = int(info.n_channels)
+
+    def close(self):
+        if self._h:
+            lib().wfk_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def member_index(self, member: int) -> np.ndarray:
+        """np.searchsorted(x - shift, bounds) of one member, computed by the library."""
+        nb = len(self.prog.member_bounds(member))
+        idx = np.empty(nb, dtype=np.int64)
+        check(lib().wfk_plan_member_index(self._h, member, idx.ctypes.data, nb))
+        return idx
+
+    def launch(self, out_ptr: int, ch_stride: int, kind: int, accumulate=False,
+               stream: int = 0):
+        """Asynchronous launch into device memory at `out_ptr`."""
+        check(lib().wfk_plan_launch(self._h, out_ptr, ch_stride, kind,
+                                    ACCUMULATE if accumulate else 0, stream))
+
+    def run_host(self, dtype=np.float64) -> np.ndarray:
+        """Launch, copy back, synchronise -> (n_channels, n) NumPy array."""
+        dtype = np.dtype(dtype)
+        out = np.empty((self.n_channels, self.n), dtype=dtype)
+        if out.size:
+            check(lib().wfk_plan_run_host(self._h, out.ctypes.data, self.n,
+                                          _KIND_OF[dtype]))
+        return out
+
+
+class FirPlan:
+    """out[i] = sum_k ker[k] * sig[i + K//2 - k] (zero padded) for `batch` rows."""
+
+    def __init__(self, ker, n: int, batch: int = 1, dtype=np.float64):
+        ker = np.ascontiguousarray(ker, dtype=np.float64)
+        self.n, self.batch, self.dtype = int(n), int(batch), np.dtype(dtype)
+        self._h = C.c_void_p()
+        check(lib().wfk_fir_plan_create(ker.ctypes.data, len(ker), self.n, self.batch,
+                                        _KIND_OF[self.dtype], C.byref(self._h)))
+
+    def apply(self, in_ptr: int, in_stride: int, out_ptr: int, out_stride: int,
+              stream: int = 0):
+        check(lib().wfk_fir_apply(self._h, in_ptr, in_stride, out_ptr, out_stride,
+                                  stream))
+
+    def close(self):
+        if self._h:
+            lib().wfk_fir_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class DeviceBuffer:
+    """Raw device allocation through the C-ABI (for callers without torch)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().wfk_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        check(lib().wfk_memcpy_h2d(self.ptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(lib().wfk_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def zero(self):
+        check(lib().wfk_memset(self.ptr, 0, self.nbytes))
+
+    def close(self):
+        if getattr(self, 'ptr', None):
+            lib().wfk_free(self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+
+def sync(stream: int = 0):
+    check(lib().wfk_stream_sync(stream))

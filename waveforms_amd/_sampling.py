@@ -1,0 +1,213 @@
+"""Sampling entry points: the Python side of the drop-in boundary.
+
+`call_waveform` / `call_vstack` / `sample_waveform` keep the reference semantics of
+`Waveform.__call__` (waveforms/waveform.py:529-563), `WaveVStack.__call__`
+(:679-693) and `Waveform.sample` / `_sample_iter` (:173-257) -- argument meaning,
+output dtype rule, `out`/`accumulate`/`frag` behaviour, exception types -- while all
+evaluation happens in the HIP library.  `sample_batch` is the additive multi-channel
+API (no reference counterpart): many channels, one launch, output left in HBM.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _engine, _flatten
+from ._ir import ZERO
+
+
+def _check_function_lib(function_lib):
+    if function_lib is not None:
+        raise NotImplementedError(
+            'function_lib overrides are Python callables and cannot run on the '
+            'device; only the built-in primitive ids 1..15 are implemented')
+
+
+def _as_time_array(x):
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError('x must be a scalar or a 1-D sorted array')
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def _live_pieces(plan, member, seq):
+    """[(start, stop, expr)] of the evaluated pieces of one member: start < stop
+    and expr != ZERO, exactly the reference's condition (_waveform.pyx:160-161)."""
+    out, start = [], 0
+    for stop, expr in zip(plan.member_index(member), seq):
+        stop = int(stop)
+        if start < stop and expr != ZERO:
+            out.append((start, stop, expr))
+        start = stop
+    return out
+
+
+def _has_complex_amp(expr):
+    return any(isinstance(a, complex) for a in expr[1])
+
+
+def _result_dtype(live):
+    # dtype detection of calc_parts (_waveform.pyx:164-166)
+    return np.complex128 if any(_has_complex_amp(e) for _, _, e in live) else np.float64
+
+
+def _finish(w, plan, frag, out, accumulate):
+    live = _live_pieces(plan, 0, w.seq)
+    dtype = _result_dtype(live)
+    res = plan.run_host(dtype)[0]
+    if not frag:
+        if out is None:
+            return res
+        if not accumulate:
+            out *= 0
+        out[:len(res)] += res
+        return out
+    parts = []
+    for a, b, expr in live:
+        if all(len(f) == 0 for f, _ in expr[0]):
+            part = res[a]            # constant piece: the reference yields a scalar
+        else:
+            part = res[a:b].copy()
+        parts.append((a, b, part))
+    if out is None:
+        return parts
+    if accumulate:
+        raise NotImplementedError  # as the reference (_merge_parts, waveform.py:516-522)
+    out.clear()
+    out.extend(parts)
+    return out
+
+
+def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=None):
+    _check_function_lib(function_lib)
+    if isinstance(x, (int, float, complex)):
+        return call_waveform(w, np.array([x]))[0]
+    t = _as_time_array(x)
+    plan = _engine.Plan(_flatten.flatten([w]), t=t)
+    try:
+        return _finish(w, plan, frag, out, accumulate)
+    finally:
+        plan.close()
+
+
+def call_vstack(w, x, function_lib=None):
+    if function_lib is None and w.function_lib is not None:
+        function_lib = w.function_lib
+    _check_function_lib(function_lib)
+    if isinstance(x, (int, float, complex)):
+        return call_vstack(w, np.array([x]))[0]
+    plan = _engine.Plan(_flatten.flatten([w]), t=_as_time_array(x))
+    try:
+        return plan.run_host(np.float64)[0]
+    finally:
+        plan.close()
+
+
+def _sample_on_grid(w, grid, out, function_lib):
+    from .waveform import WaveVStack
+    _check_function_lib(function_lib)
+    plan = _engine.Plan(_flatten.flatten([w]), grid=grid)
+    try:
+        if isinstance(w, WaveVStack):
+            return plan.run_host(np.float64)[0]
+        return _finish(w, plan, False, out, False)
+    finally:
+        plan.close()
+
+
+def sample_waveform(w, sample_rate=None, out=None, chunk_size=None, function_lib=None,
+                    filters=None):
+    if sample_rate is None:
+        sample_rate = w.sample_rate
+    if w.start is None or w.stop is None or sample_rate is None:
+        raise ValueError(
+            f'Waveform is not initialized. {w.start=}, {w.stop=}, {sample_rate=}')
+    if filters is None:
+        filters = w.filters
+    if filters is not None:
+        raise NotImplementedError(
+            'SOS IIR filters in sample() are not implemented on the device yet '
+            '(SURVEY.md §8(f) N1); sample without filters')
+    if chunk_size is None:
+        grid = _flatten.grid_arange(w.start, w.stop, 1 / sample_rate)
+        return _sample_on_grid(w, grid, out, function_lib)
+    return _sample_iter(w, sample_rate, chunk_size, out, function_lib)
+
+
+def _sample_iter(w, sample_rate, chunk_size, out, function_lib):
+    # chunk grid: np.linspace(start, stop, size, endpoint=False) per chunk
+    # (reference: waveforms/waveform.py:223-232, 256-257)
+    start, start_n = float(w.start), 0
+    length = chunk_size / sample_rate
+    while start < w.stop:
+        if start + length > w.stop:
+            length = w.stop - start
+            stop = float(w.stop)
+            size = round((stop - start) * sample_rate)
+        else:
+            stop = start + length
+            size = chunk_size
+        grid = _flatten.grid_linspace(start, stop, size, endpoint=False)
+        yield _sample_on_grid(w, grid, None if out is None else out[start_n:],
+                              function_lib)
+        start = stop
+        start_n += chunk_size
+
+
+# ---------------------------------------------------------------------------
+# batched multi-channel API (additive)
+# ---------------------------------------------------------------------------
+class BatchSampler:
+    """Many channels (Waveform / WaveVStack objects) sampled on ONE uniform grid
+    by a single kernel launch.  Build once, launch many times.
+
+        bs = BatchSampler(channels, ('linspace', 0.0, 3e-6, 10**7, False))
+        bs.launch(out_ptr, ch_stride, dtype)        # async, output stays in HBM
+        arr = bs.to_host(np.float32)                # or: run + copy back
+    """
+
+    def __init__(self, channels, grid):
+        if not isinstance(grid, _flatten.wfk_grid):
+            grid = _flatten.grid_from_desc(grid)
+        self.grid = grid
+        self.prog = _flatten.flatten(list(channels))
+        self.plan = _engine.Plan(self.prog, grid=grid)
+        self.n = self.plan.n
+        self.n_channels = self.plan.n_channels
+
+    def launch(self, out_ptr: int, ch_stride: int | None = None, dtype=np.float64,
+               accumulate=False, stream: int = 0):
+        kind = _engine._KIND_OF[np.dtype(dtype)]
+        self.plan.launch(out_ptr, self.n if ch_stride is None else ch_stride, kind,
+                         accumulate, stream)
+
+    def launch_torch(self, out, accumulate=False):
+        """Launch into a CUDA/HIP torch tensor of shape (n_channels, >= n) on the
+        current torch stream; returns `out`."""
+        import torch
+        if not out.is_cuda or out.dim() != 2 or out.shape[0] != self.n_channels \
+                or out.shape[1] < self.n or out.stride(1) != 1:
+            raise ValueError('out must be a (n_channels, >=n) row-contiguous device tensor')
+        dtype = {torch.float64: np.float64, torch.float32: np.float32,
+                 torch.complex128: np.complex128, torch.complex64: np.complex64}[out.dtype]
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        self.launch(out.data_ptr(), out.stride(0), dtype, accumulate, stream)
+        return out
+
+    def to_host(self, dtype=np.float64):
+        return self.plan.run_host(dtype)
+
+    def close(self):
+        self.plan.close()
+
+
+def sample_batch(channels, grid, dtype=np.float64, out=None):
+    """Sample `channels` on `grid`.  With a device tensor `out` the result stays in
+    HBM (returned as `out`); otherwise a (n_channels, n) NumPy array is returned."""
+    bs = BatchSampler(channels, grid)
+    try:
+        if out is not None:
+            return bs.launch_torch(out)
+        return bs.to_host(dtype)
+    finally:
+        if out is None:
+            bs.close()

@@ -1,0 +1,344 @@
+// wfk_compile.cpp -- host compiler: flattened expression forest (include/wfk.h)
+// + time axis -> device tables (wfk_internal.h).  Pure host C++, no HIP calls.
+//
+// What it decides, all of it O(#pieces), never per sample:
+//  * integer piece membership: np.searchsorted(x - tshift, bounds, 'left') per
+//    member (reference: waveforms/_waveform.pyx:156), evaluated on the EXACT grid
+//    formula t[i] = fl(fl(i*step)+t0) so indices are bit-identical to NumPy's
+//  * WaveVStack members (waveforms/waveform.py:690-692) merged into disjoint
+//    pieces per channel, so each output sample is written exactly once
+//  * per factor: uniform-grid fast path (phasor table / recurrences) or direct
+//    device-libm evaluation
+//  * parameter blocks sized for the LDS staging buffer
+//
+// Compiled with -ffp-contract=off: the grid formula must round twice.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "wfk.h"
+#include "wfk_internal.h"
+
+namespace {
+
+struct TimeAxis {
+  const wfk_grid* g;
+  const double* t;
+  int64_t n;
+  double at(int64_t i) const {
+    if (t) return t[i];
+    if (g->has_last && i == g->n - 1) return g->last;
+    volatile double m = (double)i * g->step;
+    return m + g->t0;
+  }
+  // first i with fl(x[i] - tshift) >= b
+  int64_t search_left(double tshift, double b) const {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      int64_t mid = lo + (hi - lo) / 2;
+      double x = at(mid);
+      if (tshift != 0.0) x = x - tshift;
+      if (x < b) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  }
+};
+
+int argc_of(int type) {
+  switch (type) {
+    case WFK_LINEAR: return 0;
+    case WFK_GAUSSIAN: case WFK_ERF: case WFK_COS: case WFK_SINC: case WFK_EXP:
+    case WFK_COSH: case WFK_SINH: return 1;
+    case WFK_MOLLIFIER: case WFK_D_GAUSSIAN: return 2;
+    case WFK_EXPONENTIALCHIRP: case WFK_HYPERBOLICCHIRP: return 3;
+    case WFK_LINEARCHIRP: return 4;
+    case WFK_DRAG: return 6;
+    case WFK_INTERP: return -1;
+    default: return -2;
+  }
+}
+
+// MOLLIFIER d>0 polynomial, highest degree first (reference: pyx:365-368)
+std::vector<double> mollifier_poly(int d) {
+  std::vector<double> p = {0.0, -2.0};  // p[k] = coeff of x^k
+  for (int n = 1; n < d; ++n) {
+    std::vector<double> nx(p.size() + 3, 0.0);
+    for (size_t k = 1; k < p.size(); ++k) {
+      double c = (double)k * p[k];
+      nx[k - 1 + 4] += c;
+      nx[k - 1 + 2] += -2.0 * c;
+      nx[k - 1] += c;
+    }
+    for (size_t k = 0; k < p.size(); ++k) {
+      nx[k + 3] += -4.0 * n * p[k];
+      nx[k + 1] += (4.0 * n - 2.0) * p[k];
+    }
+    p.swap(nx);
+  }
+  std::reverse(p.begin(), p.end());
+  return p;
+}
+
+struct BlockBuilder {
+  std::vector<double> body;     // after the 2-double header
+  std::vector<double> tables;   // appended behind the records
+  std::vector<std::pair<size_t, int>> table_refs;  // (index of aux slot in body, table id)
+  std::map<double, int> table_of_w;               // dedupe COS tables by dphase
+  int n_terms = 0;
+  size_t size() const { return WFK_BLK_HDR + body.size() + tables.size() + 1; }
+};
+
+}  // namespace
+
+int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
+                int64_t n_tlist, HostPlan& H, std::string& err) {
+  if (!P || (!grid && !tlist && n_tlist != 0)) { err = "null program or time axis"; return WFK_EINVAL; }
+  if (P->n_channels < 0 || P->n_members < 0) { err = "negative counts"; return WFK_EINVAL; }
+  TimeAxis ax{grid, tlist, grid ? grid->n : n_tlist};
+  if (ax.n < 0) { err = "negative sample count"; return WFK_EINVAL; }
+  H = HostPlan();
+  H.tlist = grid == nullptr;
+  H.n_channels = P->n_channels;
+  H.n = ax.n;
+  if (grid) {
+    H.t0 = grid->t0; H.step = grid->step; H.last = grid->last; H.has_last = grid->has_last;
+    if (ax.n > 1 && !(grid->step > 0)) { err = "grid step must be positive"; return WFK_EINVAL; }
+  }
+  H.ns = H.tlist ? WFK_NS_TLIST : WFK_NS_GRID;
+  H.tile = WFK_WG * H.ns;
+  const int NS = H.ns;
+  const double dstride = grid ? 64.0 * grid->step : 0.0;  // lane-to-lane sample stride in time
+  // validation / A-B switch: evaluate every factor with device libm even on a grid
+  const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
+  const bool nofast = nofast_env && nofast_env[0] == '1';
+
+  // ---- validate structure ----------------------------------------------------
+  for (int32_t c = 0; c < P->n_channels; ++c) {
+    if (P->ch_member_off[c] > P->ch_member_off[c + 1]) { err = "ch_member_off not monotone"; return WFK_EINVAL; }
+    if (std::isnan(P->ch_clip_lo[c]) || std::isnan(P->ch_clip_hi[c])) { err = "NaN clip"; return WFK_EINVAL; }
+  }
+  for (int32_t m = 0; m < P->n_members; ++m) {
+    int32_t a = P->mb_piece_off[m], b = P->mb_piece_off[m + 1];
+    if (b <= a) { err = "member without pieces"; return WFK_EINVAL; }
+    if (!(P->pc_bound[b - 1] == INFINITY)) { err = "last bound of a member must be +inf"; return WFK_EINVAL; }
+    for (int32_t p = a + 1; p < b; ++p)
+      if (!(P->pc_bound[p - 1] <= P->pc_bound[p])) { err = "bounds not ascending"; return WFK_EINVAL; }
+  }
+  for (int32_t f = 0; f < P->n_factors; ++f) {
+    int want = argc_of(P->fc_type[f]);
+    int64_t have = P->fc_arg_off[f + 1] - P->fc_arg_off[f];
+    if (want == -2) {
+      err = "primitive id " + std::to_string(P->fc_type[f]) + " has no device implementation";
+      return WFK_EUNSUP;
+    }
+    if ((want >= 0 && have != want) || (want == -1 && have < 3)) {
+      err = "wrong argument count for primitive id " + std::to_string(P->fc_type[f]);
+      return WFK_EINVAL;
+    }
+    const double* a = P->pool + P->fc_arg_off[f];
+    if ((P->fc_type[f] == WFK_MOLLIFIER && (a[1] < 0 || a[1] > 12 || a[1] != std::floor(a[1]))) ||
+        (P->fc_type[f] == WFK_D_GAUSSIAN && (a[1] < 0 || a[1] > 64 || a[1] != std::floor(a[1])))) {
+      err = "derivative order out of range"; return WFK_EINVAL;
+    }
+  }
+
+  // ---- searchsorted per member ----------------------------------------------
+  H.member_idx.resize(P->n_members);
+  for (int32_t c = 0; c < P->n_channels; ++c)
+    for (int32_t m = P->ch_member_off[c]; m < P->ch_member_off[c + 1]; ++m) {
+      auto& idx = H.member_idx[m];
+      for (int32_t p = P->mb_piece_off[m]; p < P->mb_piece_off[m + 1]; ++p)
+        idx.push_back(ax.search_left(P->ch_tshift[c], P->pc_bound[p]));
+    }
+
+  // ---- factor record emission -------------------------------------------------
+  auto emit_factor = [&](BlockBuilder& B, int32_t f, double tshift, int64_t s0, int64_t s1) {
+    const int type = P->fc_type[f];
+    const double pw = P->fc_power[f], shift = P->fc_shift[f];
+    const double* a = P->pool + P->fc_arg_off[f];
+    const int64_t na = P->fc_arg_off[f + 1] - P->fc_arg_off[f];
+    double rec[WFK_FREC] = {(double)type, pw, shift, 0, 0, 0, 0, 0, 0, 0};
+    int table = -1;
+    bool fast = false;
+    if (!H.tlist && !nofast && pw == 1.0 && s1 > s0) {
+      // time range of the piece on this channel's shifted axis
+      double ua = (ax.at(s0) - tshift) - shift, ub = (ax.at(s1 - 1) - tshift) - shift;
+      double umax = std::max(std::fabs(ua), std::fabs(ub));
+      if (type == WFK_LINEAR) {
+        rec[0] = WFK_M_LIN_REC; rec[3] = dstride; fast = true;
+      } else if (type == WFK_COS && std::isfinite(a[0])) {
+        rec[0] = WFK_M_COS_TAB; rec[3] = a[0]; fast = true;
+        double dphase = a[0] * dstride;
+        auto it = B.table_of_w.find(dphase);
+        if (it == B.table_of_w.end()) {
+          table = (int)(B.tables.size() / (2 * NS));
+          B.table_of_w[dphase] = table;
+          for (int k = 0; k < NS; ++k) {
+            long double th = (long double)dphase * k;
+            B.tables.push_back((double)cosl(th));
+            B.tables.push_back((double)sinl(th));
+          }
+        } else {
+          table = it->second;
+        }
+      } else if (type == WFK_GAUSSIAN && std::isfinite(a[0]) && a[0] != 0.0) {
+        double Hs = dstride / std::fabs(a[0]);
+        if (Hs <= 2.0 && umax / std::fabs(a[0]) <= 24.0) {
+          // exp(-((u+k D)/s)^2): with v=u/s, H=D/s (signed through s)
+          double Hh = dstride / a[0];
+          rec[0] = WFK_M_GAUSS_REC; rec[3] = a[0]; rec[4] = Hh; rec[5] = std::exp(-2.0 * Hh * Hh);
+          fast = true;
+        }
+      } else if (type == WFK_EXP && std::isfinite(a[0])) {
+        if (std::fabs(a[0]) * (umax + dstride * NS) <= 600.0) {
+          rec[0] = WFK_M_EXP_REC; rec[3] = a[0]; rec[4] = std::exp(a[0] * dstride);
+          fast = true;
+        }
+      }
+    }
+    if (!fast) {
+      switch (type) {
+        case WFK_INTERP:
+          rec[3] = a[0]; rec[4] = a[1]; rec[5] = (double)(na - 2); rec[6] = (double)H.pool.size();
+          H.pool.insert(H.pool.end(), a + 2, a + na);
+          break;
+        case WFK_MOLLIFIER: {
+          int d = (int)a[1];
+          rec[3] = a[0]; rec[4] = d;
+          if (d > 0) {
+            std::vector<double> poly = mollifier_poly(d);
+            rec[5] = (double)(poly.size() - 1); rec[6] = (double)H.pool.size();
+            rec[7] = std::pow(a[0], (double)d);
+            H.pool.insert(H.pool.end(), poly.begin(), poly.end());
+          }
+          break;
+        }
+        case WFK_D_GAUSSIAN:
+          rec[3] = a[0]; rec[4] = a[1];
+          rec[5] = std::pow(-1.0, a[1]) / std::pow(a[0], a[1]);
+          break;
+        default:
+          for (int64_t k = 0; k < na && k < 6; ++k) rec[3 + k] = a[k];
+      }
+      ++H.n_direct;
+    } else {
+      ++H.n_fast;
+    }
+    size_t at = B.body.size();
+    B.body.insert(B.body.end(), rec, rec + WFK_FREC);
+    if (table >= 0) B.table_refs.emplace_back(at + WFK_FREC - 1, table);
+  };
+
+  auto flush_block = [&](BlockBuilder& B) -> int32_t {
+    // [len, n_terms, body..., pad?, tables...]
+    size_t tab_off = WFK_BLK_HDR + B.body.size();
+    if (tab_off & 1) ++tab_off;  // 16-byte aligned tables
+    for (auto& r : B.table_refs) B.body[r.first] = (double)(tab_off + (size_t)r.second * 2 * NS);
+    size_t len = tab_off + B.tables.size();
+    H.params.push_back((double)len);
+    H.params.push_back((double)B.n_terms);
+    H.params.insert(H.params.end(), B.body.begin(), B.body.end());
+    if ((WFK_BLK_HDR + B.body.size()) & 1) H.params.push_back(0.0);
+    H.params.insert(H.params.end(), B.tables.begin(), B.tables.end());
+    if (H.params.size() & 1) { H.params.push_back(0.0); }  // keep every block start even
+    B = BlockBuilder();
+    return (int32_t)len;
+  };
+
+  // ---- merge members into disjoint device pieces -----------------------------
+  H.channels.resize(P->n_channels);
+  H.channel_complex.assign(P->n_channels, 0);
+  for (int32_t c = 0; c < P->n_channels; ++c) {
+    DevChannel& C = H.channels[c];
+    C.offset = P->ch_offset[c]; C.tshift = P->ch_tshift[c];
+    C.clip_lo = P->ch_clip_lo[c]; C.clip_hi = P->ch_clip_hi[c];
+    C.do_clip = (C.clip_lo != -INFINITY || C.clip_hi != INFINITY) ? 1 : 0;
+    C.pad = 0;
+    C.piece_begin = (int32_t)H.pieces.size();
+    const int32_t m0 = P->ch_member_off[c], m1 = P->ch_member_off[c + 1];
+    std::vector<int64_t> cuts = {0, ax.n};
+    for (int32_t m = m0; m < m1; ++m)
+      cuts.insert(cuts.end(), H.member_idx[m].begin(), H.member_idx[m].end());
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    std::vector<int32_t> cur(m1 - m0, 0);  // per member: current piece (relative)
+    for (size_t ci = 0; ci + 1 < cuts.size(); ++ci) {
+      const int64_t s0 = cuts[ci], s1 = cuts[ci + 1];
+      if (s0 < 0 || s1 > ax.n || s0 >= s1) continue;
+      // collect live member pieces
+      std::vector<int32_t> live;
+      for (int32_t m = m0; m < m1; ++m) {
+        const auto& idx = H.member_idx[m];
+        int32_t& k = cur[m - m0];
+        while (k < (int32_t)idx.size() - 1 && idx[k] <= s0) ++k;
+        if (idx[k] <= s0) continue;  // past the last bound cannot happen (idx.back()==n)
+        int32_t p = P->mb_piece_off[m] + k;
+        if (P->pc_term_off[p + 1] > P->pc_term_off[p]) live.push_back(p);
+      }
+      DevPiece D{};
+      D.start = s0; D.stop = s1; D.n_blk = 0; D.flags = 0; D.first_len = 0; D.pad = 0;
+      if (H.params.size() & 1) H.params.push_back(0.0);
+      D.par_off = (int64_t)H.params.size();
+      if (!live.empty()) {
+        D.flags |= WFK_PF_HAS_TERMS;
+        BlockBuilder B;
+        for (int32_t p : live)
+          for (int32_t k = P->pc_term_off[p]; k < P->pc_term_off[p + 1]; ++k) {
+            if (P->tm_amp_im[k] != 0.0) H.channel_complex[c] = 1;
+            const int32_t f0 = P->tm_factor_off[k], f1 = P->tm_factor_off[k + 1];
+            // conservative size of this term: header + records + one table per COS
+            size_t need = WFK_TERM_HDR + (size_t)(f1 - f0) * (WFK_FREC + 2 * NS);
+            if (WFK_BLK_HDR + need + 2 > WFK_LDS_DOUBLES) {
+              err = "a single term with " + std::to_string(f1 - f0) + " factors exceeds the LDS parameter buffer";
+              return WFK_EINVAL;
+            }
+            if (B.n_terms > 0 && B.size() + need > WFK_LDS_DOUBLES) {
+              int32_t len = flush_block(B);
+              if (D.n_blk == 0) D.first_len = len;
+              ++D.n_blk;
+            }
+            B.body.push_back(P->tm_amp_re[k]);
+            B.body.push_back(P->tm_amp_im[k]);
+            B.body.push_back((double)(f1 - f0));
+            for (int32_t f = f0; f < f1; ++f) emit_factor(B, f, C.tshift, s0, s1);
+            ++B.n_terms;
+          }
+        int32_t len = flush_block(B);
+        if (D.n_blk == 0) D.first_len = len;
+        ++D.n_blk;
+      }
+      // fuse adjacent zero pieces
+      if (D.n_blk == 0 && (int32_t)H.pieces.size() > C.piece_begin &&
+          H.pieces.back().n_blk == 0 && H.pieces.back().stop == s0) {
+        H.pieces.back().stop = s1;
+      } else {
+        H.pieces.push_back(D);
+      }
+    }
+    C.piece_end = (int32_t)H.pieces.size();
+  }
+
+  // ---- workgroup chunking ------------------------------------------------------
+  int64_t tiles_per_ch = (ax.n + H.tile - 1) / H.tile;
+  int64_t total_tiles = tiles_per_ch * P->n_channels;
+  int64_t tpc = total_tiles / 8192;  // aim for >= ~8k workgroups (256 CUs x 32)
+  H.tiles_per_chunk = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, tpc));
+  H.chunks_per_ch = (tiles_per_ch + H.tiles_per_chunk - 1) / H.tiles_per_chunk;
+  H.chunk_first.assign((size_t)(H.chunks_per_ch * P->n_channels), 0);
+  const int64_t chunk_samples = (int64_t)H.tiles_per_chunk * H.tile;
+  for (int32_t c = 0; c < P->n_channels; ++c) {
+    int32_t p = H.channels[c].piece_begin;
+    for (int64_t k = 0; k < H.chunks_per_ch; ++k) {
+      int64_t g0 = k * chunk_samples;
+      while (p < H.channels[c].piece_end - 1 && H.pieces[p].stop <= g0) ++p;
+      H.chunk_first[(size_t)(c * H.chunks_per_ch + k)] = p;
+    }
+  }
+  if (H.pool.empty()) H.pool.push_back(0.0);
+  if (H.params.empty()) H.params.push_back(0.0);
+  return WFK_OK;
+}

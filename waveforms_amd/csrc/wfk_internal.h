@@ -1,0 +1,102 @@
+// wfk_internal.h -- device-side program layout shared by the host compiler
+// (wfk_compile.cpp) and the gfx950 kernels (wfk_kernels.hip).
+//
+// Data layout in HBM (all tables are tiny next to the output stream):
+//   DevChannel[n_channels]    offset / tshift / clip + piece range
+//   DevPiece[n_pieces]        DISJOINT sample ranges covering [0, n) per channel,
+//                             merged over WaveVStack members on the host
+//   double params[]           per-piece "parameter blocks" (see below); staged
+//                             into LDS by the workgroup that evaluates the piece
+//   double pool[]             variable-length args (INTERP points, MOLLIFIER
+//                             polynomial), read per lane
+//   int32 chunk_first[]       first piece overlapping each workgroup chunk
+//
+// Parameter block (doubles; integers stored exactly as doubles):
+//   [0] block length (doubles, this header included)   [1] n_terms
+//   per term:   amp_re, amp_im, n_factors
+//   per factor: WFK_FREC doubles  { mode, power, shift, a0..a5, aux }
+//   then tables referenced by `aux` (offset inside the block, even => 16-B aligned)
+#pragma once
+#include <stdint.h>
+
+#define WFK_WG 256            // threads per workgroup (4 wave64)
+#define WFK_NS_GRID 16        // samples per lane per wave tile, grid mode
+#define WFK_NS_TLIST 8        // samples per lane per wave tile, tlist mode
+#define WFK_LDS_DOUBLES 2048  // LDS parameter buffer (16 KiB)
+#define WFK_FREC 10           // doubles per factor record
+#define WFK_BLK_HDR 2
+#define WFK_TERM_HDR 3
+
+// factor evaluation modes (record slot 0).  1..15 = direct evaluation of that
+// primitive with device libm; >=100 = uniform-grid fast paths (power == 1).
+#define WFK_M_LIN_REC 101     // u_n = u_0 + n*D                       a0 = D = 64*step
+#define WFK_M_GAUSS_REC 102   // g_{n+1}=g_n r_n, r_{n+1}=r_n q        a0 = sigma, a1 = H, a2 = q
+#define WFK_M_COS_TAB 104     // cos(th0 + n*dth) = c0*C[n] - s0*S[n]  a0 = w, aux = table
+#define WFK_M_EXP_REC 106     // e_{n+1} = e_n * rho                   a0 = alpha, a1 = rho
+
+#define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)
+
+struct DevPiece {
+  int64_t start, stop;        // sample range [start, stop)
+  int64_t par_off;            // first parameter block (doubles into params[])
+  int32_t n_blk;              // consecutive blocks (0: zero piece)
+  int32_t flags;
+  int32_t first_len;          // length of the first block
+  int32_t pad;
+};
+
+struct DevChannel {
+  double offset, tshift, clip_lo, clip_hi;
+  int32_t piece_begin, piece_end;
+  int32_t do_clip, pad;
+};
+
+struct KArgs {
+  const DevChannel* channels;
+  const DevPiece* pieces;
+  const double* params;
+  const double* pool;
+  const int32_t* chunk_first;  // [n_channels * chunks_per_ch]
+  const double* tlist;         // tlist mode only
+  void* out;
+  int64_t ch_stride;           // elements
+  int64_t n;                   // samples per channel
+  int64_t chunks_per_ch;
+  int32_t tiles_per_chunk;     // workgroup tiles per workgroup
+  int32_t accumulate;
+  double t0, step, last;
+  int32_t has_last, pad;
+};
+
+#ifdef __cplusplus
+#include <string>
+#include <vector>
+struct wfk_program;
+struct wfk_grid;
+
+struct HostPlan {
+  bool tlist = false;
+  int32_t n_channels = 0;
+  int64_t n = 0;
+  double t0 = 0, step = 0, last = 0;
+  int32_t has_last = 0;
+  int32_t ns = 0, tile = 0, tiles_per_chunk = 1;
+  int64_t chunks_per_ch = 0;
+  std::vector<DevChannel> channels;
+  std::vector<DevPiece> pieces;
+  std::vector<double> params, pool;
+  std::vector<int32_t> chunk_first;
+  std::vector<std::vector<int64_t>> member_idx;
+  std::vector<uint8_t> channel_complex;
+  int32_t n_fast = 0, n_direct = 0;
+};
+
+// host compiler: flattened program + time axis -> device tables.  Returns 0 or a
+// negative WFK_E* code with a message in err.
+int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tlist,
+                int64_t n, HostPlan& out, std::string& err);
+
+// kernels (wfk_kernels.hip)
+int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist,
+                       bool direct, void* stream, std::string& err);
+#endif

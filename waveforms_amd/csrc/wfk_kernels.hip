@@ -1,0 +1,405 @@
+// wfk_kernels.hip -- gfx950 (MI355X / CDNA4) sampler kernels.
+//
+// One kernel family evaluates
+//     out[ch, j] = offset + clip( sum_k amp_k * prod_f f(t_j - shift_f)^n_f )
+// for every channel and sample: the device replacement for the reference's
+// calc_parts/_calc/_apply/_fill_parts passes (waveforms/_waveform.pyx:130-169,
+// waveforms/waveform.py:524-527).  It is elementwise/transcendental work bounded by
+// HBM *write* bandwidth (8 B/sample fp64): no contraction, hence no MFMA.
+//
+// Mapping (wave64, 256-thread workgroups):
+//   workgroup -> `tiles_per_chunk` consecutive tiles of 256*NS samples of one channel
+//   wave      -> 64*NS consecutive samples; lane l owns samples j0+l+64*k, k<NS, so every
+//                store instruction of a wave writes 64 consecutive elements (coalesced)
+//   piece     -> its parameter block is staged in LDS once per workgroup and reused for
+//                every tile that stays inside the piece; all control flow on the program
+//                (term / factor / mode) is wave-uniform (scalar branches)
+// Uniform-grid fast paths keep the per-sample cost at a few FMAs instead of a libm call:
+//   COS   : one exact sincos per lane per tile, then cos(th0+k*dth) = c0*C[k] - s0*S[k]
+//           with the (C,S) table (k<NS) read from LDS as wave-wide broadcasts
+//   GAUSS : g_{k+1} = g_k r_k, r_{k+1} = r_k q   (two exact exps per lane per tile)
+//   EXP   : e_{k+1} = e_k rho          LINEAR: u_k = u_0 + k D
+// Everything else (and tlist mode) evaluates the primitive with the device libm.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "wfk.h"
+#include "wfk_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// t[j] = fl(fl(j*step) + t0): NumPy's linspace/arange element formula, two roundings.
+__device__ __forceinline__ double grid_time(const KArgs& a, int64_t j) {
+#pragma clang fp contract(off)
+  double m = (double)j * a.step;
+  double t = m + a.t0;
+  if (a.has_last && j == a.n - 1) t = a.last;
+  return t;
+}
+
+// sin/cos of a large phase without the Payne-Hanek register cost of libm's sincos:
+// theta/pi as an exact two-term product (1/pi split hi+lo), reduced with rint, then
+// sincospi on |r| <= 1/2.  Phase error ~1 ulp of r, i.e. as accurate as libm.
+__device__ __attribute__((noinline)) double2 sincos_phase(double theta) {
+  const double IPI_HI = 0.31830988618379069, IPI_LO = -1.9678676675182486e-17;
+  const double xh = theta * IPI_HI;
+  const double xl = fma(theta, IPI_HI, -xh) + theta * IPI_LO;
+  const double n = rint(xh);
+  const double r = (xh - n) + xl;
+  double ss, cc;
+  sincospi(r, &ss, &cc);
+  const bool odd = ((long long)n) & 1;
+  return make_double2(odd ? -cc : cc, odd ? -ss : ss);  // (cos, sin)
+}
+
+// Out-of-line so that libm's polynomial constants are not hoisted into VGPRs that
+// stay live across the whole sampling loop.
+__device__ __attribute__((noinline)) double exp_seed(double x) { return exp(x); }
+
+template <bool TLIST>
+__device__ __forceinline__ double time_at(const KArgs& a, int64_t j) {
+  if (TLIST) {
+    int64_t jj = j < a.n ? j : a.n - 1;
+    return a.tlist[jj];
+  }
+  return grid_time(a, j);
+}
+
+// ---- direct primitives (device libm), evaluated at u = t - shift ----------------
+// Formulas: reference waveforms/_waveform.pyx:290-371.
+__device__ double np_linspace_at(double start, double stop, int64_t m, int64_t k) {
+#pragma clang fp contract(off)
+  if (m == 1) return start;
+  if (k == m - 1) return stop;
+  double step = (stop - start) / (double)(m - 1);
+  double a = (double)k * step;
+  return a + start;
+}
+
+__device__ double prim_interp(double x, double start, double stop, const double* fp, int64_t m) {
+#pragma clang fp contract(off)
+  if (isnan(x)) return x;
+  double x0 = np_linspace_at(start, stop, m, 0), xl = np_linspace_at(start, stop, m, m - 1);
+  if (x > xl) return fp[m - 1];
+  if (x < x0) return fp[0];
+  int64_t lo = 0, hi = m;
+  while (hi - lo > 1) {
+    int64_t mid = lo + (hi - lo) / 2;
+    if (x >= np_linspace_at(start, stop, m, mid)) lo = mid; else hi = mid;
+  }
+  int64_t j = lo;
+  if (j == m - 1) return fp[j];
+  double xj = np_linspace_at(start, stop, m, j), xj1 = np_linspace_at(start, stop, m, j + 1);
+  if (xj == x) return fp[j];
+  double slope = (fp[j + 1] - fp[j]) / (xj1 - xj);
+  double r = slope * (x - xj) + fp[j];
+  if (isnan(r)) {
+    r = slope * (x - xj1) + fp[j + 1];
+    if (isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
+  }
+  return r;
+}
+
+__device__ double prim_drag(double t, const double* r) {
+  const double t0 = r[3], freq = r[4], width = r[5], delta = r[6], bf = r[7], phase = r[8];
+  const double PI = 3.141592653589793;
+  double o = PI / width;
+  double sx = sin(o * (t - t0));
+  double Ox = sx * sx;
+  double wt = 2 * PI * (freq + delta) * t - (2 * PI * delta * t0 + phase);
+  if (isnan(bf) || bf - delta == 0) return Ox * cos(wt);
+  double b = 1 / PI / 2 / (bf - delta);
+  double Oy = -b * o * sin(2 * o * (t - t0));
+  double s, c;
+  sincos(wt, &s, &c);
+  return Ox * c + Oy * s;
+}
+
+__device__ double prim_mollifier(double u, const double* r, const double* pool) {
+  double x = u / r[3];
+  double q = fabs(x) * fabs(x) - 1.0;
+  int d = (int)r[4];
+  if (d == 0) return q >= 0 ? 0.0 : exp(1.0 / q + 1.0);
+  int deg = (int)r[5];
+  const double* p = pool + (int64_t)r[6];
+  double px = 0.0;
+  for (int k = 0; k <= deg; ++k) px = px * x + p[k];
+  double env = q >= 0 ? 0.0 : exp(1.0 / q + 1.0) / pow(-q, 2.0 * d);
+  return env * px / r[7];
+}
+
+__device__ double prim_dgauss(double u, const double* r) {
+  double x = u / r[3];
+  int n = (int)r[4];
+  double h0 = 1.0, h1 = 2.0 * x, h = n == 0 ? h0 : h1;
+  for (int k = 1; k < n; ++k) {
+    h = 2.0 * x * h1 - 2.0 * k * h0;
+    h0 = h1;
+    h1 = h;
+  }
+  return r[5] * h * exp(-(x * x));
+}
+
+__device__ double prim_direct(int type, double u, const double* r, const double* pool) {
+  const double PI = 3.141592653589793;
+  switch (type) {
+    case WFK_LINEAR: return u;
+    case WFK_GAUSSIAN: { double x = u / r[3]; return exp(-(x * x)); }
+    case WFK_ERF: return erf(u / r[3]);
+    case WFK_COS: return cos(r[3] * u);
+    case WFK_SINC: { double x = r[3] * u; double y = PI * (x == 0 ? 1.0e-20 : x); return sin(y) / y; }
+    case WFK_EXP: return exp(r[3] * u);
+    case WFK_INTERP: return prim_interp(u, r[3], r[4], pool + (int64_t)r[6], (int64_t)r[5]);
+    case WFK_LINEARCHIRP:
+      return sin(r[6] + 2 * PI * ((r[4] - r[3]) / (2 * r[5]) * (u * u) + r[3] * u));
+    case WFK_EXPONENTIALCHIRP: return sin(r[5] + 2 * PI * r[3] * (exp(r[4] * u) - 1) / r[4]);
+    case WFK_HYPERBOLICCHIRP: return sin(r[5] + 2 * PI * r[3] / r[4] * log(1 + r[4] * u));
+    case WFK_COSH: return cosh(r[3] * u);
+    case WFK_SINH: return sinh(r[3] * u);
+    case WFK_DRAG: return prim_drag(u, r);
+    case WFK_MOLLIFIER: return prim_mollifier(u, r, pool);
+    case WFK_D_GAUSSIAN: return prim_dgauss(u, r);
+    default: return __builtin_nan("");
+  }
+}
+
+__device__ double np_power(double v, double n) {
+  if (n == 2.0) return v * v;
+  if (n == -1.0) return 1.0 / v;
+  if (n == 0.5) return sqrt(v);
+  if (n == 0.0) return 1.0;
+  return pow(v, n);
+}
+
+// ---- one factor over the wave tile: prod[k] *= f(t_k - shift)^power -------------
+// blk: LDS parameter block, r: this factor's record inside it, j0: lane's first sample.
+template <typename T, bool TLIST, bool DIRECT, int NS>
+__device__ __forceinline__ void apply_factor(const double* blk, const double* r, const KArgs& a,
+                                             double tshift, int64_t j0, T (&prod)[NS]) {
+  const int mode = uni((int)r[0]);
+  const double shift = r[2];
+  if (!TLIST && mode >= 100) {
+    // seed at the lane's first sample, evaluated exactly as the reference does
+    double x = grid_time(a, j0);
+    if (tshift != 0.0) x = x - tshift;
+    const double u0 = x - shift;
+    if (mode == WFK_M_COS_TAB) {
+      const double2 cs0 = sincos_phase(r[3] * u0);
+      const T c0 = (T)cs0.x, s0 = (T)cs0.y;
+      const double2* tab = reinterpret_cast<const double2*>(blk + uni((int)r[9]));
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const double2 cs = tab[k];  // wave-wide LDS broadcast
+        prod[k] *= c0 * (T)cs.x - s0 * (T)cs.y;
+      }
+    } else if (mode == WFK_M_GAUSS_REC) {
+      const double v = u0 / r[3], Hh = r[4];
+      T g = (T)exp_seed(-(v * v));
+      T rr = (T)exp_seed(-Hh * (2.0 * v + Hh));
+      const T q = (T)r[5];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        prod[k] *= g;
+        g *= rr;
+        rr *= q;
+      }
+    } else if (mode == WFK_M_EXP_REC) {
+      T e = (T)exp_seed(r[3] * u0);
+      const T rho = (T)r[4];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        prod[k] *= e;
+        e *= rho;
+      }
+    } else {  // WFK_M_LIN_REC
+      const double D = r[3];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) prod[k] *= (T)(u0 + (double)k * D);
+    }
+    return;
+  }
+  if (!DIRECT) return;  // fast-only build: the plan holds no direct factor
+  // direct evaluation: a rolled loop (small code) that rotates the register array so
+  // that every access keeps a compile-time index
+  const double pw = r[1];
+  const bool has_pw = pw != 1.0;
+#pragma unroll 1
+  for (int k = 0; k < NS; ++k) {
+    double x = time_at<TLIST>(a, j0 + 64 * (int64_t)k);
+    if (tshift != 0.0) x = x - tshift;
+    double v = prim_direct(mode, x - shift, r, a.pool);
+    if (has_pw) v = np_power(v, pw);
+    const T head = prod[0] * (T)v;
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) prod[i] = prod[i + 1];
+    prod[NS - 1] = head;
+  }
+}
+
+template <typename T> struct OutOps;
+template <> struct OutOps<double> {
+  using Real = double;
+  using Cplx = double2;
+};
+template <> struct OutOps<float> {
+  using Real = float;
+  using Cplx = float2;
+};
+
+template <typename T>
+__device__ __forceinline__ T clip_np(T v, T lo, T hi) {
+  // np.clip: NaN propagates, otherwise min(max(v, lo), hi)
+  v = v < lo ? lo : v;
+  v = v > hi ? hi : v;
+  return v;
+}
+
+template <typename T, bool CPLX, bool TLIST, bool DIRECT, int NS>
+__global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
+  __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
+  constexpr int WT = 64 * NS;
+  constexpr int TILE = WFK_WG * NS;
+  using OutR = typename OutOps<T>::Real;
+  using OutC = typename OutOps<T>::Cplx;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int64_t chunk = blockIdx.x;
+  const int ch = (int)(chunk / a.chunks_per_ch);
+  const int64_t cc = chunk - (int64_t)ch * a.chunks_per_ch;
+  const DevChannel C = a.channels[ch];
+  int p = a.chunk_first[chunk];
+  int64_t staged = -1;
+
+  OutR* outr = reinterpret_cast<OutR*>(a.out) + (int64_t)ch * a.ch_stride;
+  OutC* outc = reinterpret_cast<OutC*>(a.out) + (int64_t)ch * a.ch_stride;
+
+  for (int tt = 0; tt < a.tiles_per_chunk; ++tt) {
+    const int64_t g0 = (cc * a.tiles_per_chunk + tt) * TILE;
+    if (g0 >= a.n) break;
+    const int64_t g1 = g0 + TILE < a.n ? g0 + TILE : a.n;
+    const int64_t w0 = g0 + (int64_t)wave * WT;
+    const int64_t j0 = w0 + lane;
+    while (p < C.piece_end - 1 && a.pieces[p].stop <= g0) ++p;
+
+    for (int q = p; q < C.piece_end; ++q) {
+      const DevPiece P = a.pieces[q];
+      if (P.start >= g1) break;
+      const bool active = w0 < a.n && P.start < w0 + WT && P.stop > w0;  // wave-uniform
+
+      T acc[NS], acci[CPLX ? NS : 1];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) acc[k] = (T)0;
+      if (CPLX) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acci[k] = (T)0;
+      }
+
+      int64_t off = P.par_off;
+      int len = P.first_len;
+      for (int b = 0; b < P.n_blk; ++b) {
+        if (off != staged) {
+          __syncthreads();  // every wave is done with the previous block
+          for (int i = threadIdx.x; i < len; i += WFK_WG) s_par[i] = a.params[off + i];
+          __syncthreads();
+          staged = off;
+        }
+        if (active) {
+          const int nt = uni((int)s_par[1]);
+          int pos = WFK_BLK_HDR;
+          for (int k = 0; k < nt; ++k) {
+            const T ar = (T)s_par[pos], ai = (T)s_par[pos + 1];
+            const int nf = uni((int)s_par[pos + 2]);
+            pos += WFK_TERM_HDR;
+            T prod[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) prod[i] = (T)1;
+            for (int f = 0; f < nf; ++f) {
+              apply_factor<T, TLIST, DIRECT, NS>(s_par, s_par + pos, a, C.tshift, j0, prod);
+              pos += WFK_FREC;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) acc[i] += ar * prod[i];
+            if (CPLX) {
+#pragma unroll
+              for (int i = 0; i < NS; ++i) acci[i] += ai * prod[i];
+            }
+          }
+        }
+        off += len;
+        if (b + 1 < P.n_blk) len = (int)a.params[off];
+      }
+
+      if (active) {
+        const bool full = P.start <= w0 && P.stop >= w0 + WT;
+        const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
+        const T lo = (T)C.clip_lo, hi = (T)C.clip_hi, base = (T)C.offset;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          const int64_t j = j0 + 64 * k;
+          if (full || (j >= P.start && j < P.stop)) {
+            T v = acc[k];
+            if (clip) v = clip_np(v, lo, hi);
+            v += base;
+            if (CPLX) {
+              OutC o;
+              o.x = v;
+              o.y = acci[k];
+              if (a.accumulate) {
+                const OutC old = outc[j];
+                o.x += old.x;
+                o.y += old.y;
+              }
+              outc[j] = o;
+            } else {
+              if (a.accumulate) v += outr[j];
+              outr[j] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, bool CPLX, bool TLIST, int NS>
+int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool direct) {
+  if (!TLIST && !direct)
+    hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, false, NS>), dim3((unsigned)blocks), dim3(WFK_WG), 0, s, a);
+  else
+  hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, true, NS>), dim3((unsigned)blocks), dim3(WFK_WG), 0, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, bool direct,
+                       void* stream, std::string& err) {
+  const int64_t blocks = (int64_t)n_channels * a.chunks_per_ch;
+  if (blocks == 0) return WFK_OK;
+  if (blocks > 0x7fffffffLL) { err = "grid too large"; return WFK_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (!tlist) {
+    switch (out_kind) {
+      case WFK_OUT_F64: rc = launch<double, false, false, WFK_NS_GRID>(a, blocks, s, direct); break;
+      case WFK_OUT_F32: rc = launch<float, false, false, WFK_NS_GRID>(a, blocks, s, direct); break;
+      case WFK_OUT_C128: rc = launch<double, true, false, WFK_NS_GRID>(a, blocks, s, direct); break;
+      case WFK_OUT_C64: rc = launch<float, true, false, WFK_NS_GRID>(a, blocks, s, direct); break;
+      default: err = "bad out_kind"; return WFK_EINVAL;
+    }
+  } else {
+    switch (out_kind) {
+      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
+      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
+      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
+      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
+      default: err = "bad out_kind"; return WFK_EINVAL;
+    }
+  }
+  if (rc) { err = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()); return WFK_EHIP; }
+  return WFK_OK;
+}
