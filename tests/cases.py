@@ -155,6 +155,14 @@ CASES = {
     'single_point': (lambda ns: ns.gaussian(2) * ns.cos(3),
                      ('linspace', 0.25, 0.25, 1, True)),
     'all_outside': (lambda ns: ns.gaussian(2) >> 100, LIN),
+    # coarse grids: the Gaussian recurrence runs with a large per-step ratio and a
+    # seed far outside the piece (H ~ 1), or must fall back to libm (H ~ 1.9)
+    'coarse_gauss_rec': (lambda ns: (ns.gaussian(3.3302184446307908) * ns.cos(2.0)) >> 7.3,
+                         ('linspace', -50.0, 50.0, 6400, True)),
+    'coarse_gauss_direct': (lambda ns: (ns.gaussian(3.3302184446307908) * ns.cos(2.0)) >> 7.3,
+                            ('linspace', -50.0, 50.0, 3400, True)),
+    'coarse_exp': (lambda ns: ns.exp(-0.9) * ns.square(60) * ns.cos(0.3),
+                   ('linspace', -50.0, 50.0, 2500, True)),
     'tiny_pieces': (lambda ns: wl.sum_channel(ns, 40, 9, 2e-9),
                     ('linspace', 0.0, 100e-9, 777, True)),
 }

@@ -186,16 +186,22 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           table = it->second;
         }
       } else if (type == WFK_GAUSSIAN && std::isfinite(a[0]) && a[0] != 0.0) {
+        // exp(-((u+k D)/s)^2): v=u/s, H=D/s.  A lane's seed may sit up to NS strides
+        // outside the piece, so the range check includes that overhang.
         double Hs = dstride / std::fabs(a[0]);
-        if (Hs <= 2.0 && umax / std::fabs(a[0]) <= 24.0) {
-          // exp(-((u+k D)/s)^2): with v=u/s, H=D/s (signed through s)
+        double vext = umax / std::fabs(a[0]) + NS * Hs;
+        if (Hs <= 2.0 && vext <= 26.0) {           // exp(-676) ~ 1e-294: normal fp64
           double Hh = dstride / a[0];
           rec[0] = WFK_M_GAUSS_REC; rec[3] = a[0]; rec[4] = Hh; rec[5] = std::exp(-2.0 * Hh * Hh);
+          // fp32 state is safe only while g and r stay inside float's exponent range
+          rec[9] = (vext <= 8.0 && 2.0 * vext * Hs + Hs * Hs <= 80.0) ? 1.0 : 0.0;
           fast = true;
         }
       } else if (type == WFK_EXP && std::isfinite(a[0])) {
-        if (std::fabs(a[0]) * (umax + dstride * NS) <= 600.0) {
+        double ext = std::fabs(a[0]) * (umax + dstride * NS);
+        if (ext <= 600.0) {
           rec[0] = WFK_M_EXP_REC; rec[3] = a[0]; rec[4] = std::exp(a[0] * dstride);
+          rec[9] = ext <= 80.0 ? 1.0 : 0.0;
           fast = true;
         }
       }

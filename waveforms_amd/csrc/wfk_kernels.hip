@@ -197,22 +197,45 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
       }
     } else if (mode == WFK_M_GAUSS_REC) {
       const double v = u0 / r[3], Hh = r[4];
-      T g = (T)exp_seed(-(v * v));
-      T rr = (T)exp_seed(-Hh * (2.0 * v + Hh));
-      const T q = (T)r[5];
+      const double gd = exp_seed(-(v * v)), rd = exp_seed(-Hh * (2.0 * v + Hh));
+      if (sizeof(T) == 4 && uni((int)r[9]) == 0) {
+        // float output but the state would leave float's exponent range: keep it in double
+        double g = gd, rr = rd;
+        const double q = r[5];
 #pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        prod[k] *= g;
-        g *= rr;
-        rr *= q;
+        for (int k = 0; k < NS; ++k) {
+          prod[k] *= (T)g;
+          g *= rr;
+          rr *= q;
+        }
+      } else {
+        T g = (T)gd, rr = (T)rd;
+        const T q = (T)r[5];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          prod[k] *= g;
+          g *= rr;
+          rr *= q;
+        }
       }
     } else if (mode == WFK_M_EXP_REC) {
-      T e = (T)exp_seed(r[3] * u0);
-      const T rho = (T)r[4];
+      const double ed = exp_seed(r[3] * u0);
+      if (sizeof(T) == 4 && uni((int)r[9]) == 0) {
+        double e = ed;
+        const double rho = r[4];
 #pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        prod[k] *= e;
-        e *= rho;
+        for (int k = 0; k < NS; ++k) {
+          prod[k] *= (T)e;
+          e *= rho;
+        }
+      } else {
+        T e = (T)ed;
+        const T rho = (T)r[4];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          prod[k] *= e;
+          e *= rho;
+        }
       }
     } else {  // WFK_M_LIN_REC
       const double D = r[3];
