@@ -96,10 +96,15 @@ def test_sample_api(name):
     assert err(got, want) <= FP64_TOL * peak(want)
     # chunked generator: same samples, np.linspace(endpoint=False) grid per chunk
     chunks = list(w.sample(chunk_size=257))
-    cat = np.concatenate(chunks)
-    assert abs(len(cat) - len(want)) <= 1
-    m = min(len(cat), len(want))
-    assert err(cat[:m], want[:m]) <= 1e-6 * peak(want)
+    assert abs(sum(map(len, chunks)) - len(want)) <= 1
+    # every full chunk lands on the arange grid (the last, partial chunk re-spaces
+    # its points: step = (stop - start) / round(...), reference waveform.py:225-232)
+    cat = np.concatenate(chunks[:-1])
+    assert err(cat, want[:len(cat)]) <= 1e-9 * peak(want)
+    out = np.zeros(len(chunks) * 257)
+    for _ in w.sample(chunk_size=257, out=out):
+        pass
+    assert err(out[:len(cat)], cat) == 0.0
 
 
 def test_reference_test_waveform():
