@@ -122,6 +122,8 @@ typedef struct wfk_plan_info {
   int64_t param_doubles; /* device parameter stream length                      */
   int32_t n_fast;        /* factor uses on a recurrence / table fast path        */
   int32_t n_direct;      /* factor uses evaluated with device libm               */
+  int32_t n_fused;       /* terms absorbed into fused carrier-envelope ops       */
+  int32_t n_generic;     /* terms evaluated factor by factor                     */
 } wfk_plan_info;
 
 int         wfk_abi_version(void);

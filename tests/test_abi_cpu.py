@@ -55,7 +55,8 @@ def test_big_grid_indices():
     prog = _flatten.flatten([wl.c2_channel(wf)])
     plan = _engine.Plan(prog, grid=_flatten.grid_from_desc(wl.c2_grid()))
     assert np.array_equal(plan.member_index(0), big['c2.idx'])
-    assert plan.info.n_direct == 0 and plan.info.n_fast > 0
+    # the whole DRAG workload is absorbed by the host fusion pass
+    assert plan.info.n_direct == 0 and plan.info.n_generic == 0 and plan.info.n_fused > 0
 
 
 def test_unsupported_primitive_raises():

@@ -29,7 +29,8 @@ class wfk_plan_info(C.Structure):
     _fields_ = [('n_channels', C.c_int32), ('n', C.c_int64), ('tile', C.c_int32),
                 ('n_tiles', C.c_int64), ('n_pieces', C.c_int32),
                 ('param_doubles', C.c_int64), ('n_fast', C.c_int32),
-                ('n_direct', C.c_int32)]
+                ('n_direct', C.c_int32), ('n_fused', C.c_int32),
+                ('n_generic', C.c_int32)]
 
 
 class EngineError(RuntimeError):

@@ -83,12 +83,22 @@ std::vector<double> mollifier_poly(int d) {
   return p;
 }
 
+// one fused carrier-envelope group (see WFK_FCE_* in wfk_internal.h)
+struct FceGroup {
+  double W = 0, sref = 0;
+  long double psi_ref = 0;
+  bool has_env = false, env32 = false, has_lin = false;
+  double sigma = 0, sg = 0, slin = 0;
+  long double A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
+  int deg = 0, nterms = 0;
+};
+
 struct BlockBuilder {
   std::vector<double> body;     // after the 2-double header
   std::vector<double> tables;   // appended behind the records
   std::vector<std::pair<size_t, int>> table_refs;  // (index of aux slot in body, table id)
   std::map<double, int> table_of_w;               // dedupe COS tables by dphase
-  int n_terms = 0;
+  int n_terms = 0;                                // ops in this block
   size_t size() const { return WFK_BLK_HDR + body.size() + tables.size() + 1; }
 };
 
@@ -155,6 +165,31 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         idx.push_back(ax.search_left(P->ch_tshift[c], P->pc_bound[p]));
     }
 
+  // phasor table (C[k], S[k]) = (cos, sin)(k * dphase), k < NS, shared per block
+  auto table_for = [&](BlockBuilder& B, double dphase) -> int {
+    auto it = B.table_of_w.find(dphase);
+    if (it != B.table_of_w.end()) return it->second;
+    int table = (int)(B.tables.size() / (2 * NS));
+    B.table_of_w[dphase] = table;
+    for (int k = 0; k < NS; ++k) {
+      long double th = (long double)dphase * k;
+      B.tables.push_back((double)cosl(th));
+      B.tables.push_back((double)sinl(th));
+    }
+    return table;
+  };
+
+  // Gaussian recurrence validity over the samples [s0, s1) (+ NS strides of overhang)
+  auto gauss_range = [&](double sigma, double shift, double tshift, int64_t s0, int64_t s1,
+                         bool& f64_ok, bool& f32_ok) {
+    double ua = (ax.at(s0) - tshift) - shift, ub = (ax.at(s1 - 1) - tshift) - shift;
+    double umax = std::max(std::fabs(ua), std::fabs(ub));
+    double Hs = dstride / std::fabs(sigma);
+    double vext = umax / std::fabs(sigma) + NS * Hs;
+    f64_ok = std::isfinite(sigma) && sigma != 0.0 && Hs <= 2.0 && vext <= 26.0;
+    f32_ok = f64_ok && vext <= 8.0 && 2.0 * vext * Hs + Hs * Hs <= 80.0;
+  };
+
   // ---- factor record emission -------------------------------------------------
   auto emit_factor = [&](BlockBuilder& B, int32_t f, double tshift, int64_t s0, int64_t s1) {
     const int type = P->fc_type[f];
@@ -172,29 +207,17 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         rec[0] = WFK_M_LIN_REC; rec[3] = dstride; fast = true;
       } else if (type == WFK_COS && std::isfinite(a[0])) {
         rec[0] = WFK_M_COS_TAB; rec[3] = a[0]; fast = true;
-        double dphase = a[0] * dstride;
-        auto it = B.table_of_w.find(dphase);
-        if (it == B.table_of_w.end()) {
-          table = (int)(B.tables.size() / (2 * NS));
-          B.table_of_w[dphase] = table;
-          for (int k = 0; k < NS; ++k) {
-            long double th = (long double)dphase * k;
-            B.tables.push_back((double)cosl(th));
-            B.tables.push_back((double)sinl(th));
-          }
-        } else {
-          table = it->second;
-        }
-      } else if (type == WFK_GAUSSIAN && std::isfinite(a[0]) && a[0] != 0.0) {
+        table = table_for(B, a[0] * dstride);
+      } else if (type == WFK_GAUSSIAN) {
         // exp(-((u+k D)/s)^2): v=u/s, H=D/s.  A lane's seed may sit up to NS strides
         // outside the piece, so the range check includes that overhang.
-        double Hs = dstride / std::fabs(a[0]);
-        double vext = umax / std::fabs(a[0]) + NS * Hs;
-        if (Hs <= 2.0 && vext <= 26.0) {           // exp(-676) ~ 1e-294: normal fp64
+        bool ok64, ok32;
+        gauss_range(a[0], shift, tshift, s0, s1, ok64, ok32);
+        if (ok64) {                                // exp(-676) ~ 1e-294: normal fp64
           double Hh = dstride / a[0];
           rec[0] = WFK_M_GAUSS_REC; rec[3] = a[0]; rec[4] = Hh; rec[5] = std::exp(-2.0 * Hh * Hh);
           // fp32 state is safe only while g and r stay inside float's exponent range
-          rec[9] = (vext <= 8.0 && 2.0 * vext * Hs + Hs * Hs <= 80.0) ? 1.0 : 0.0;
+          rec[9] = ok32 ? 1.0 : 0.0;
           fast = true;
         }
       } else if (type == WFK_EXP && std::isfinite(a[0])) {
@@ -255,6 +278,140 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     return (int32_t)len;
   };
 
+  // ---- fusion: terms -> carrier-envelope groups ---------------------------------
+  const char* nofuse_env = std::getenv("WFK_DISABLE_FUSE");
+  const bool can_fuse = !H.tlist && !nofast && !(nofuse_env && nofuse_env[0] == '1');
+
+  auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
+                       int64_t s1) -> bool {
+    if (P->tm_amp_im[k] != 0.0) return false;
+    const int32_t f0 = P->tm_factor_off[k], f1 = P->tm_factor_off[k + 1];
+    int p = 0, ncos = 0;
+    bool has_lin = false, has_env = false, env32 = false;
+    double slin = 0, sigma = 0, sg = 0;
+    double cw[3], cs[3];
+    for (int32_t f = f0; f < f1; ++f) {
+      const double pw = P->fc_power[f], sh = P->fc_shift[f];
+      const double* a = P->pool + P->fc_arg_off[f];
+      switch (P->fc_type[f]) {
+        case WFK_LINEAR:
+          if (!(pw == 1.0 || pw == 2.0 || pw == 3.0)) return false;
+          if (has_lin && sh != slin) return false;
+          has_lin = true; slin = sh; p += (int)pw;
+          break;
+        case WFK_GAUSSIAN: {
+          if (pw != 1.0 || has_env) return false;
+          bool ok64;
+          gauss_range(a[0], sh, tshift, s0, s1, ok64, env32);
+          if (!ok64) return false;
+          has_env = true; sigma = a[0]; sg = sh;
+          break;
+        }
+        case WFK_COS:
+          if (pw != 1.0 || ncos == 3 || !std::isfinite(a[0]) || !std::isfinite(sh)) return false;
+          cw[ncos] = a[0]; cs[ncos] = sh; ++ncos;
+          break;
+        default:
+          return false;
+      }
+    }
+    if (p > 3 || !std::isfinite(P->tm_amp_re[k])) return false;
+    // product of cosines -> sum of single carriers:  cos a cos b = (cos(a+b) + cos(a-b)) / 2
+    struct Car { long double c, W, Psi; };   // c * cos(W t' - Psi)
+    std::vector<Car> cars;
+    if (ncos == 0) {
+      cars.push_back({(long double)P->tm_amp_re[k], 0.0L, 0.0L});
+    } else {
+      cars.push_back({(long double)P->tm_amp_re[k], (long double)cw[0],
+                      (long double)cw[0] * cs[0]});
+      for (int i = 1; i < ncos; ++i) {
+        std::vector<Car> nx;
+        const long double w = cw[i], ps = (long double)cw[i] * cs[i];
+        for (const Car& q : cars) {
+          nx.push_back({q.c / 2, q.W + w, q.Psi + ps});
+          nx.push_back({q.c / 2, q.W - w, q.Psi - ps});
+        }
+        cars.swap(nx);
+      }
+    }
+    // stage the contributions; commit only if every carrier finds/creates a group
+    std::vector<FceGroup> staged = groups;
+    for (Car q : cars) {
+      if (q.W < 0) { q.W = -q.W; q.Psi = -q.Psi; }
+      const double W = (double)q.W;
+      if ((long double)W != q.W && ncos > 1) {
+        // sum/difference frequency not exactly representable: keep its rounded value
+        // (relative error <= 2^-53, i.e. the same class as the reference's own w*t rounding)
+      }
+      FceGroup* G = nullptr;
+      for (FceGroup& g : staged)
+        if (g.W == W && g.has_env == has_env && (!has_env || (g.sigma == sigma && g.sg == sg))) { G = &g; break; }
+      if (!G) {
+        staged.emplace_back();
+        G = &staged.back();
+        G->W = W; G->has_env = has_env; G->sigma = sigma; G->sg = sg; G->env32 = env32;
+        G->sref = W == 0.0 ? 0.0 : (ncos == 1 ? cs[0] : (double)(q.Psi / q.W));
+        G->psi_ref = (long double)W * G->sref;
+      }
+      if (has_env && !env32) G->env32 = false;
+      long double ca, cb;
+      if (W == 0.0) { ca = q.c * cosl(q.Psi); cb = 0.0L; }
+      else {
+        const long double delta = G->psi_ref - q.Psi;   // cos(th_ref + delta)
+        ca = q.c * cosl(delta);
+        cb = -q.c * sinl(delta);
+      }
+      // multiply by u_term^p with u_term = u_group + d
+      long double d = 0.0L;
+      if (p > 0) {
+        if (!G->has_lin) { G->has_lin = true; G->slin = slin; }
+        d = (long double)G->slin - slin;
+      }
+      static const int binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+      for (int i = 0; i <= p; ++i) {
+        long double f = binom[p][i] * powl(d, p - i);
+        G->A[i] += ca * f;
+        G->B[i] += cb * f;
+      }
+      if (p > G->deg) G->deg = p;
+      ++G->nterms;
+    }
+    groups.swap(staged);
+    return true;
+  };
+
+  auto emit_group = [&](BlockBuilder& B, FceGroup& G) {
+    double rec[WFK_FCE_REC] = {0};
+    long double A0 = G.A[0], B0 = G.B[0];
+    double sref = G.sref;
+    if (G.deg == 0 && G.W != 0.0) {
+      // A cos(th) + B sin(th) = R cos(th - phi): fold B into the reference shift
+      long double R = hypotl(A0, B0), phi = atan2l(B0, A0);
+      sref = (double)((long double)G.sref + phi / (long double)G.W);
+      A0 = R; B0 = 0.0L;
+    }
+    rec[0] = WFK_OP_FCE;
+    rec[WFK_FCE_W] = G.W;
+    rec[WFK_FCE_SREF] = sref;
+    rec[WFK_FCE_SLIN] = G.has_lin ? G.slin : 0.0;
+    rec[WFK_FCE_DEG] = G.deg;
+    rec[WFK_FCE_A] = (double)A0;
+    rec[WFK_FCE_B] = (double)B0;
+    for (int i = 1; i < 4; ++i) { rec[WFK_FCE_A + i] = (double)G.A[i]; rec[WFK_FCE_B + i] = (double)G.B[i]; }
+    rec[WFK_FCE_ENV] = G.has_env ? 1.0 : 0.0;
+    if (G.has_env) {
+      double Hh = dstride / G.sigma;
+      rec[WFK_FCE_SIGMA] = G.sigma; rec[WFK_FCE_SG] = G.sg;
+      rec[WFK_FCE_H] = Hh; rec[WFK_FCE_Q] = std::exp(-2.0 * Hh * Hh);
+      rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
+    }
+    rec[WFK_FCE_D] = dstride;
+    rec[WFK_FCE_CARRIER] = G.W != 0.0 ? 1.0 : 0.0;
+    size_t at = B.body.size();
+    B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
+    if (G.W != 0.0) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
+  };
+
   // ---- merge members into disjoint device pieces -----------------------------
   H.channels.resize(P->n_channels);
   H.channel_complex.assign(P->n_channels, 0);
@@ -292,27 +449,46 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       if (!live.empty()) {
         D.flags |= WFK_PF_HAS_TERMS;
         BlockBuilder B;
+        auto room_for = [&](size_t need) -> int {
+          if (WFK_BLK_HDR + need + 2 > WFK_LDS_DOUBLES) return -1;
+          if (B.n_terms > 0 && B.size() + need > WFK_LDS_DOUBLES) {
+            int32_t len = flush_block(B);
+            if (D.n_blk == 0) D.first_len = len;
+            ++D.n_blk;
+          }
+          return 0;
+        };
+        // pass 1: fuse eligible terms into carrier-envelope groups
+        std::vector<FceGroup> groups;
+        std::vector<int32_t> generic;
         for (int32_t p : live)
           for (int32_t k = P->pc_term_off[p]; k < P->pc_term_off[p + 1]; ++k) {
             if (P->tm_amp_im[k] != 0.0) H.channel_complex[c] = 1;
-            const int32_t f0 = P->tm_factor_off[k], f1 = P->tm_factor_off[k + 1];
-            // conservative size of this term: header + records + one table per COS
-            size_t need = WFK_TERM_HDR + (size_t)(f1 - f0) * (WFK_FREC + 2 * NS);
-            if (WFK_BLK_HDR + need + 2 > WFK_LDS_DOUBLES) {
-              err = "a single term with " + std::to_string(f1 - f0) + " factors exceeds the LDS parameter buffer";
-              return WFK_EINVAL;
-            }
-            if (B.n_terms > 0 && B.size() + need > WFK_LDS_DOUBLES) {
-              int32_t len = flush_block(B);
-              if (D.n_blk == 0) D.first_len = len;
-              ++D.n_blk;
-            }
-            B.body.push_back(P->tm_amp_re[k]);
-            B.body.push_back(P->tm_amp_im[k]);
-            B.body.push_back((double)(f1 - f0));
-            for (int32_t f = f0; f < f1; ++f) emit_factor(B, f, C.tshift, s0, s1);
-            ++B.n_terms;
+            if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
+            else generic.push_back(k);
           }
+        for (FceGroup& G : groups) {
+          if (room_for(WFK_FCE_REC + 2 * NS) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
+          emit_group(B, G);
+          ++B.n_terms;
+        }
+        // pass 2: whatever is left, factor by factor
+        for (int32_t k : generic) {
+          const int32_t f0 = P->tm_factor_off[k], f1 = P->tm_factor_off[k + 1];
+          // conservative size of this term: header + records + one table per COS
+          size_t need = WFK_TERM_HDR + (size_t)(f1 - f0) * (WFK_FREC + 2 * NS);
+          if (room_for(need) < 0) {
+            err = "a single term with " + std::to_string(f1 - f0) + " factors exceeds the LDS parameter buffer";
+            return WFK_EINVAL;
+          }
+          B.body.push_back((double)WFK_OP_TERM);
+          B.body.push_back(P->tm_amp_re[k]);
+          B.body.push_back(P->tm_amp_im[k]);
+          B.body.push_back((double)(f1 - f0));
+          for (int32_t f = f0; f < f1; ++f) emit_factor(B, f, C.tshift, s0, s1);
+          ++B.n_terms;
+          ++H.n_generic;
+        }
         int32_t len = flush_block(B);
         if (D.n_blk == 0) D.first_len = len;
         ++D.n_blk;

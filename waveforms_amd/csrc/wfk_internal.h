@@ -12,10 +12,12 @@
 //   int32 chunk_first[]       first piece overlapping each workgroup chunk
 //
 // Parameter block (doubles; integers stored exactly as doubles):
-//   [0] block length (doubles, this header included)   [1] n_terms
-//   per term:   amp_re, amp_im, n_factors
-//   per factor: WFK_FREC doubles  { mode, power, shift, a0..a5, aux }
-//   then tables referenced by `aux` (offset inside the block, even => 16-B aligned)
+//   [0] block length (doubles, this header included)   [1] n_ops
+//   per op:  kind, then
+//     kind 1 (generic term): amp_re, amp_im, n_factors, then per factor WFK_FREC
+//                            doubles { mode, power, shift, a0..a5, aux }
+//     kind 2 (fused carrier-envelope group, WFK_FCE_REC doubles): see WFK_FCE_*
+//   then phasor tables referenced by offset inside the block (even => 16-B aligned)
 #pragma once
 #include <stdint.h>
 
@@ -25,7 +27,33 @@
 #define WFK_LDS_DOUBLES 2048  // LDS parameter buffer (16 KiB)
 #define WFK_FREC 10           // doubles per factor record
 #define WFK_BLK_HDR 2
-#define WFK_TERM_HDR 3
+#define WFK_TERM_HDR 4        // kind, amp_re, amp_im, n_factors
+#define WFK_OP_TERM 1
+#define WFK_OP_FCE 2
+
+// Fused carrier-envelope op: the host rewrites every term of the shape
+//   amp * LINEAR^p * [GAUSSIAN] * COS*COS*...      (real amp, p <= 3)
+// by product-to-sum into single carriers and merges all terms of a piece that share
+// (envelope, carrier frequency W) into   E(t) * ( A(u) cos(th) + B(u) sin(th) ),
+//   th = W (t - s_ref),  u = t - s_lin,  A/B polynomials of degree <= 3,
+//   E = 1 or exp(-((t - s_g)/sigma)^2).
+// Device cost: ONE phasor seed + (optionally) one Gaussian seed per lane per tile.
+#define WFK_FCE_REC 22
+#define WFK_FCE_W 1
+#define WFK_FCE_SREF 2
+#define WFK_FCE_SLIN 3
+#define WFK_FCE_DEG 4
+#define WFK_FCE_A 5           // A0..A3
+#define WFK_FCE_B 9           // B0..B3
+#define WFK_FCE_ENV 13        // 0 none, 1 gaussian
+#define WFK_FCE_SIGMA 14
+#define WFK_FCE_SG 15
+#define WFK_FCE_H 16
+#define WFK_FCE_Q 17
+#define WFK_FCE_F32OK 18
+#define WFK_FCE_TAB 19
+#define WFK_FCE_D 20
+#define WFK_FCE_CARRIER 21    // 0: W == 0 (no phasor needed)
 
 // factor evaluation modes (record slot 0).  1..15 = direct evaluation of that
 // primitive with device libm; >=100 = uniform-grid fast paths (power == 1).
@@ -88,7 +116,7 @@ struct HostPlan {
   std::vector<int32_t> chunk_first;
   std::vector<std::vector<int64_t>> member_idx;
   std::vector<uint8_t> channel_complex;
-  int32_t n_fast = 0, n_direct = 0;
+  int32_t n_fast = 0, n_direct = 0, n_fused = 0, n_generic = 0;
 };
 
 // host compiler: flattened program + time axis -> device tables.  Returns 0 or a
@@ -98,5 +126,5 @@ int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tli
 
 // kernels (wfk_kernels.hip)
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist,
-                       bool direct, void* stream, std::string& err);
+                       bool generic, bool direct, void* stream, std::string& err);
 #endif

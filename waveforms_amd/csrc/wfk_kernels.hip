@@ -262,6 +262,95 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
   }
 }
 
+// ---- fused carrier-envelope op over the wave tile (see WFK_FCE_* ) --------------
+//   acc[k] += E_k * ( A(u_k) * cos(th_k) + B(u_k) * sin(th_k) )
+// One phasor seed (exact sincos) and at most one Gaussian seed (two exps) per lane per
+// tile; per sample 2..13 FMAs.  The phasor at sample k is seed * table[k] (no recurrence,
+// no error growth); the (C,S) table entries are wave-wide LDS broadcasts.
+template <typename T, int NS>
+__device__ __forceinline__ void apply_fce(const double* blk, const double* r, const KArgs& a,
+                                          double tshift, int64_t j0, T (&acc)[NS]) {
+  double x = grid_time(a, j0);
+  if (tshift != 0.0) x = x - tshift;
+  const int deg = uni((int)r[WFK_FCE_DEG]);
+  const bool carrier = uni((int)r[WFK_FCE_CARRIER]) != 0;
+  const bool env = uni((int)r[WFK_FCE_ENV]) != 0;
+  T c0 = (T)1, s0 = (T)0;
+  if (carrier) {
+    const double2 cs0 = sincos_phase(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]));
+    c0 = (T)cs0.x;
+    s0 = (T)cs0.y;
+  }
+  const double2* tab = reinterpret_cast<const double2*>(blk + uni((int)r[WFK_FCE_TAB]));
+  T val[NS];
+  if (deg == 0) {
+    // A0 * cos(th) only (B was folded into the reference shift on the host)
+    const T ac = (T)r[WFK_FCE_A] * c0, as = (T)r[WFK_FCE_A] * s0;
+    if (carrier) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const double2 cs = tab[k];
+        val[k] = ac * (T)cs.x - as * (T)cs.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) val[k] = ac;
+    }
+  } else {
+    const double u0 = x - r[WFK_FCE_SLIN], D = r[WFK_FCE_D];
+    const T A0 = (T)r[WFK_FCE_A], A1 = (T)r[WFK_FCE_A + 1], A2 = (T)r[WFK_FCE_A + 2],
+            A3 = (T)r[WFK_FCE_A + 3];
+    const T B0 = (T)r[WFK_FCE_B], B1 = (T)r[WFK_FCE_B + 1], B2 = (T)r[WFK_FCE_B + 2],
+            B3 = (T)r[WFK_FCE_B + 3];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const T u = (T)(u0 + (double)k * D);
+      T pa, pb;
+      if (deg == 1) {
+        pa = A1 * u + A0;
+        pb = B1 * u + B0;
+      } else {
+        pa = ((A3 * u + A2) * u + A1) * u + A0;
+        pb = ((B3 * u + B2) * u + B1) * u + B0;
+      }
+      if (carrier) {
+        const double2 cs = tab[k];
+        const T ck = c0 * (T)cs.x - s0 * (T)cs.y;
+        const T sk = s0 * (T)cs.x + c0 * (T)cs.y;
+        val[k] = pa * ck + pb * sk;
+      } else {
+        val[k] = pa;
+      }
+    }
+  }
+  if (env) {
+    const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
+    const double gd = exp_seed(-(v * v)), rd = exp_seed(-Hh * (2.0 * v + Hh));
+    if (sizeof(T) == 4 && uni((int)r[WFK_FCE_F32OK]) == 0) {
+      double g = gd, rr = rd;
+      const double q = r[WFK_FCE_Q];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        acc[k] += val[k] * (T)g;
+        g *= rr;
+        rr *= q;
+      }
+    } else {
+      T g = (T)gd, rr = (T)rd;
+      const T q = (T)r[WFK_FCE_Q];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        acc[k] += val[k] * g;
+        g *= rr;
+        rr *= q;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] += val[k];
+  }
+}
+
 template <typename T> struct OutOps;
 template <> struct OutOps<double> {
   using Real = double;
@@ -280,7 +369,7 @@ __device__ __forceinline__ T clip_np(T v, T lo, T hi) {
   return v;
 }
 
-template <typename T, bool CPLX, bool TLIST, bool DIRECT, int NS>
+template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
 __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
   constexpr int WT = 64 * NS;
@@ -331,11 +420,18 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
           staged = off;
         }
         if (active) {
-          const int nt = uni((int)s_par[1]);
+          const int nops = uni((int)s_par[1]);
           int pos = WFK_BLK_HDR;
-          for (int k = 0; k < nt; ++k) {
-            const T ar = (T)s_par[pos], ai = (T)s_par[pos + 1];
-            const int nf = uni((int)s_par[pos + 2]);
+          for (int k = 0; k < nops; ++k) {
+            const int kind = uni((int)s_par[pos]);
+            if (!TLIST && kind == WFK_OP_FCE) {
+              apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acc);
+              pos += WFK_FCE_REC;
+              continue;
+            }
+            if (!GENERIC) continue;  // fused-only build: the plan holds no generic term
+            const T ar = (T)s_par[pos + 1], ai = (T)s_par[pos + 2];
+            const int nf = uni((int)s_par[pos + 3]);
             pos += WFK_TERM_HDR;
             T prod[NS];
 #pragma unroll
@@ -389,18 +485,21 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
 }
 
 template <typename T, bool CPLX, bool TLIST, int NS>
-int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool direct) {
-  if (!TLIST && !direct)
-    hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, false, NS>), dim3((unsigned)blocks), dim3(WFK_WG), 0, s, a);
+int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool generic, bool direct) {
+  const dim3 g((unsigned)blocks), b(WFK_WG);
+  if (TLIST || direct)
+    hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, true, true, NS>), g, b, 0, s, a);
+  else if (generic)
+    hipLaunchKernelGGL((wfk_sample<T, CPLX, false, true, false, NS>), g, b, 0, s, a);
   else
-  hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, true, NS>), dim3((unsigned)blocks), dim3(WFK_WG), 0, s, a);
+    hipLaunchKernelGGL((wfk_sample<T, CPLX, false, false, false, NS>), g, b, 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 }  // namespace
 
-int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, bool direct,
-                       void* stream, std::string& err) {
+int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, bool generic,
+                       bool direct, void* stream, std::string& err) {
   const int64_t blocks = (int64_t)n_channels * a.chunks_per_ch;
   if (blocks == 0) return WFK_OK;
   if (blocks > 0x7fffffffLL) { err = "grid too large"; return WFK_EINVAL; }
@@ -408,18 +507,18 @@ int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tl
   int rc;
   if (!tlist) {
     switch (out_kind) {
-      case WFK_OUT_F64: rc = launch<double, false, false, WFK_NS_GRID>(a, blocks, s, direct); break;
-      case WFK_OUT_F32: rc = launch<float, false, false, WFK_NS_GRID>(a, blocks, s, direct); break;
-      case WFK_OUT_C128: rc = launch<double, true, false, WFK_NS_GRID>(a, blocks, s, direct); break;
-      case WFK_OUT_C64: rc = launch<float, true, false, WFK_NS_GRID>(a, blocks, s, direct); break;
+      case WFK_OUT_F64: rc = launch<double, false, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
+      case WFK_OUT_F32: rc = launch<float, false, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
+      case WFK_OUT_C128: rc = launch<double, true, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
+      case WFK_OUT_C64: rc = launch<float, true, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
       default: err = "bad out_kind"; return WFK_EINVAL;
     }
   } else {
     switch (out_kind) {
-      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
-      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
-      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
-      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST>(a, blocks, s, direct); break;
+      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
+      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
+      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
+      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
       default: err = "bad out_kind"; return WFK_EINVAL;
     }
   }
