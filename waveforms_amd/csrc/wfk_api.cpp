@@ -188,7 +188,8 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   a.last = p->h.last;
   a.has_last = p->h.has_last;
   std::string err;
-  int rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.n_generic > 0,
+  int rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.lean,
+                              p->h.n_generic > 0,
                               p->h.n_direct > 0,
                               hip_stream, err);
   return rc ? fail(rc, err) : WFK_OK;

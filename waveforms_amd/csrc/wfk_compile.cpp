@@ -169,9 +169,9 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   auto table_for = [&](BlockBuilder& B, double dphase) -> int {
     auto it = B.table_of_w.find(dphase);
     if (it != B.table_of_w.end()) return it->second;
-    int table = (int)(B.tables.size() / (2 * NS));
+    int table = (int)(B.tables.size() / (2 * (NS + 1)));
     B.table_of_w[dphase] = table;
-    for (int k = 0; k < NS; ++k) {
+    for (int k = 0; k <= NS; ++k) {   // entry NS advances a carried phasor by one tile
       long double th = (long double)dphase * k;
       B.tables.push_back((double)cosl(th));
       B.tables.push_back((double)sinl(th));
@@ -266,7 +266,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     // [len, n_terms, body..., pad?, tables...]
     size_t tab_off = WFK_BLK_HDR + B.body.size();
     if (tab_off & 1) ++tab_off;  // 16-byte aligned tables
-    for (auto& r : B.table_refs) B.body[r.first] = (double)(tab_off + (size_t)r.second * 2 * NS);
+    for (auto& r : B.table_refs) B.body[r.first] = (double)(tab_off + (size_t)r.second * 2 * (NS + 1));
     size_t len = tab_off + B.tables.size();
     H.params.push_back((double)len);
     H.params.push_back((double)B.n_terms);
@@ -279,6 +279,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   };
 
   // ---- fusion: terms -> carrier-envelope groups ---------------------------------
+  const char* nolean_env = std::getenv("WFK_DISABLE_LEAN");
+  const bool nolean = nolean_env && nolean_env[0] == '1';
   const char* nofuse_env = std::getenv("WFK_DISABLE_FUSE");
   const bool can_fuse = !H.tlist && !nofast && !(nofuse_env && nofuse_env[0] == '1');
 
@@ -413,6 +415,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   };
 
   // ---- merge members into disjoint device pieces -----------------------------
+  bool lean_ok = can_fuse;
   H.channels.resize(P->n_channels);
   H.channel_complex.assign(P->n_channels, 0);
   for (int32_t c = 0; c < P->n_channels; ++c) {
@@ -467,8 +470,9 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
             if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
             else generic.push_back(k);
           }
+        if (!generic.empty() || groups.size() > WFK_LEAN_OPS) lean_ok = false;
         for (FceGroup& G : groups) {
-          if (room_for(WFK_FCE_REC + 2 * NS) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
+          if (room_for(WFK_FCE_REC + 2 * (NS + 1)) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
           emit_group(B, G);
           ++B.n_terms;
         }
@@ -476,7 +480,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         for (int32_t k : generic) {
           const int32_t f0 = P->tm_factor_off[k], f1 = P->tm_factor_off[k + 1];
           // conservative size of this term: header + records + one table per COS
-          size_t need = WFK_TERM_HDR + (size_t)(f1 - f0) * (WFK_FREC + 2 * NS);
+          size_t need = WFK_TERM_HDR + (size_t)(f1 - f0) * (WFK_FREC + 2 * (NS + 1));
           if (room_for(need) < 0) {
             err = "a single term with " + std::to_string(f1 - f0) + " factors exceeds the LDS parameter buffer";
             return WFK_EINVAL;
@@ -492,6 +496,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         int32_t len = flush_block(B);
         if (D.n_blk == 0) D.first_len = len;
         ++D.n_blk;
+        if (D.n_blk != 1 || len > WFK_LEAN_PAR) lean_ok = false;
       }
       // fuse adjacent zero pieces
       if (D.n_blk == 0 && (int32_t)H.pieces.size() > C.piece_begin &&
@@ -505,9 +510,13 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   }
 
   // ---- workgroup chunking ------------------------------------------------------
+  // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
+  // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
+  H.lean = lean_ok && !nolean && H.n_fused > 0;
+  if (H.lean) H.tile = 64 * H.ns;
   int64_t tiles_per_ch = (ax.n + H.tile - 1) / H.tile;
   int64_t total_tiles = tiles_per_ch * P->n_channels;
-  int64_t tpc = total_tiles / 8192;  // aim for >= ~8k workgroups (256 CUs x 32)
+  int64_t tpc = total_tiles / (H.lean ? 16384 : 8192);  // keep >= ~8-16k workgroups in flight
   H.tiles_per_chunk = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, tpc));
   H.chunks_per_ch = (tiles_per_ch + H.tiles_per_chunk - 1) / H.tiles_per_chunk;
   H.chunk_first.assign((size_t)(H.chunks_per_ch * P->n_channels), 0);

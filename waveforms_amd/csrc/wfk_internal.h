@@ -62,6 +62,12 @@
 #define WFK_M_COS_TAB 104     // cos(th0 + n*dth) = c0*C[n] - s0*S[n]  a0 = w, aux = table
 #define WFK_M_EXP_REC 106     // e_{n+1} = e_n * rho                   a0 = alpha, a1 = rho
 
+// "lean" plans: every piece is one block of <= WFK_LEAN_OPS fused ops and nothing else.
+// They run on the wave-per-workgroup kernel that carries per-lane op state across tiles.
+#define WFK_LEAN_OPS 4
+#define WFK_LEAN_PAR 512      // doubles of LDS parameter buffer per wave
+#define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles
+
 #define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)
 
 struct DevPiece {
@@ -117,6 +123,7 @@ struct HostPlan {
   std::vector<std::vector<int64_t>> member_idx;
   std::vector<uint8_t> channel_complex;
   int32_t n_fast = 0, n_direct = 0, n_fused = 0, n_generic = 0;
+  bool lean = false;           // wave-per-workgroup fused kernel (see WFK_LEAN_*)
 };
 
 // host compiler: flattened program + time axis -> device tables.  Returns 0 or a
@@ -126,5 +133,5 @@ int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tli
 
 // kernels (wfk_kernels.hip)
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist,
-                       bool generic, bool direct, void* stream, std::string& err);
+                       bool lean, bool generic, bool direct, void* stream, std::string& err);
 #endif

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <type_traits>
 
 #include "wfk.h"
 #include "wfk_internal.h"
@@ -267,88 +268,153 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
 // One phasor seed (exact sincos) and at most one Gaussian seed (two exps) per lane per
 // tile; per sample 2..13 FMAs.  The phasor at sample k is seed * table[k] (no recurrence,
 // no error growth); the (C,S) table entries are wave-wide LDS broadcasts.
+struct FceSeeds { double c, s, g, r; };
+
+// All libm work of one fused op in ONE out-of-line routine: the three polynomial chains
+// (sincospi, exp, exp) are independent, so the scheduler interleaves them, and their
+// constants are not live across the sampling loops.
+__device__ __attribute__((noinline)) FceSeeds fce_seeds(double theta, double ea, double eb,
+                                                        int carrier, int env) {
+  FceSeeds o;
+  o.c = 1.0; o.s = 0.0; o.g = 1.0; o.r = 1.0;
+  if (carrier) {
+    const double IPI_HI = 0.31830988618379069, IPI_LO = -1.9678676675182486e-17;
+    const double xh = theta * IPI_HI;
+    const double xl = fma(theta, IPI_HI, -xh) + theta * IPI_LO;
+    const double n = rint(xh);
+    double ss, cc;
+    sincospi((xh - n) + xl, &ss, &cc);
+    const bool odd = ((long long)n) & 1;
+    o.s = odd ? -ss : ss;
+    o.c = odd ? -cc : cc;
+  }
+  if (env) {
+    o.g = exp(ea);
+    o.r = exp(eb);
+  }
+  return o;
+}
+
+// ENV: 0 none, 1 Gaussian with state in T, 2 Gaussian with state in double (float
+// output whose state would leave float's exponent range).  DEG: 0, 1, or 3 (= 2..3).
+template <typename T, int NS, int DEG, bool CARRIER, int ENV>
+__device__ __forceinline__ void fce_loop(const double2* tab, const double* r, FceSeeds& sd,
+                                         double u0, T (&acc)[NS]) {  // u0 by value: made opaque below
+  using S = typename std::conditional<ENV == 2, double, T>::type;
+  constexpr int SB = 4;  // sub-batch: bounds the live LDS-table / temporary registers
+  // The specialised loops share sub-expressions (u_k, the table loads); without this
+  // opaque barrier GVN hoists all of them above the variant dispatch and every variant
+  // pays ~100 live VGPRs for it.
+  asm volatile("" : "+v"(u0) : : "memory");
+  const T c0 = (T)sd.c, s0 = (T)sd.s;
+  const T A0 = (T)r[WFK_FCE_A], A1 = (T)r[WFK_FCE_A + 1], B0 = (T)r[WFK_FCE_B],
+          B1 = (T)r[WFK_FCE_B + 1];
+  const T A2 = DEG > 1 ? (T)r[WFK_FCE_A + 2] : (T)0, A3 = DEG > 1 ? (T)r[WFK_FCE_A + 3] : (T)0;
+  const T B2 = DEG > 1 ? (T)r[WFK_FCE_B + 2] : (T)0, B3 = DEG > 1 ? (T)r[WFK_FCE_B + 3] : (T)0;
+  const T ac = A0 * c0, as = A0 * s0;  // DEG == 0
+  const double D = r[WFK_FCE_D];
+  S g = (S)sd.g, rr = (S)sd.r;
+  const S q = (S)r[WFK_FCE_Q];
+#pragma unroll
+  for (int k0 = 0; k0 < NS; k0 += SB) {
+#pragma unroll
+    for (int kk = 0; kk < SB; ++kk) {
+      const int k = k0 + kk;
+      T val;
+      if (DEG == 0) {
+        if (CARRIER) {
+          const double2 cs = tab[k];
+          val = ac * (T)cs.x - as * (T)cs.y;
+        } else {
+          val = A0;
+        }
+      } else {
+        const T u = (T)(u0 + (double)k * D);
+        T pa, pb;
+        if (DEG == 1) {
+          pa = A1 * u + A0;
+          pb = B1 * u + B0;
+        } else {
+          pa = ((A3 * u + A2) * u + A1) * u + A0;
+          pb = ((B3 * u + B2) * u + B1) * u + B0;
+        }
+        if (CARRIER) {
+          const double2 cs = tab[k];
+          const T ck = c0 * (T)cs.x - s0 * (T)cs.y;
+          const T sk = s0 * (T)cs.x + c0 * (T)cs.y;
+          val = pa * ck + pb * sk;
+        } else {
+          val = pa;
+        }
+      }
+      if (ENV) {
+        acc[k] += val * (T)g;
+        g *= rr;
+        rr *= q;
+      } else {
+        acc[k] += val;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // advance the per-lane state by one wave tile (used by the lean kernel, which carries
+  // it to the next tile; dead code elsewhere): NS recurrence steps already happened for
+  // the envelope, the phasor turns by table entry NS.
+  if (ENV) {
+    sd.g = (double)g;
+    sd.r = (double)rr;
+  }
+  if (CARRIER) {
+    const double2 e = tab[NS];
+    const double c = sd.c, sn = sd.s;
+    sd.c = c * e.x - sn * e.y;
+    sd.s = sn * e.x + c * e.y;
+  }
+}
+
+template <typename T, int NS, int DEG, bool CARRIER>
+__device__ __forceinline__ void fce_env(const double2* tab, const double* r, FceSeeds& sd,
+                                        double u0, int env, T (&acc)[NS]) {
+  if (env == 0) fce_loop<T, NS, DEG, CARRIER, 0>(tab, r, sd, u0, acc);
+  else if (sizeof(T) == 8 || env == 1) fce_loop<T, NS, DEG, CARRIER, 1>(tab, r, sd, u0, acc);
+  else fce_loop<T, NS, DEG, CARRIER, 2>(tab, r, sd, u0, acc);
+}
+
+// exact per-lane seeds of one fused op at sample time x (already minus tshift)
+__device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x) {
+  const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
+  return fce_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), -(v * v), -Hh * (2.0 * v + Hh),
+                   uni((int)r[WFK_FCE_CARRIER]), uni((int)r[WFK_FCE_ENV]));
+}
+
+// run one fused op over the wave tile from the given state; `wide_env`: keep the
+// Gaussian state in double even for float output
+template <typename T, int NS>
+__device__ __forceinline__ void fce_eval(const double* blk, const double* r, FceSeeds& sd,
+                                         double x, bool wide_env, T (&acc)[NS]) {
+  const int deg = uni((int)r[WFK_FCE_DEG]);
+  const int carrier = uni((int)r[WFK_FCE_CARRIER]);
+  int env = uni((int)r[WFK_FCE_ENV]);
+  if (env && sizeof(T) == 4 && (wide_env || uni((int)r[WFK_FCE_F32OK]) == 0)) env = 2;
+  const double2* tab = reinterpret_cast<const double2*>(blk + uni((int)r[WFK_FCE_TAB]));
+  const double u0 = x - r[WFK_FCE_SLIN];
+  if (carrier) {
+    if (deg == 0) fce_env<T, NS, 0, true>(tab, r, sd, u0, env, acc);
+    else if (deg == 1) fce_env<T, NS, 1, true>(tab, r, sd, u0, env, acc);
+    else fce_env<T, NS, 3, true>(tab, r, sd, u0, env, acc);
+  } else {
+    if (deg == 0) fce_env<T, NS, 0, false>(tab, r, sd, u0, env, acc);
+    else fce_env<T, NS, 3, false>(tab, r, sd, u0, env, acc);
+  }
+}
+
 template <typename T, int NS>
 __device__ __forceinline__ void apply_fce(const double* blk, const double* r, const KArgs& a,
                                           double tshift, int64_t j0, T (&acc)[NS]) {
   double x = grid_time(a, j0);
   if (tshift != 0.0) x = x - tshift;
-  const int deg = uni((int)r[WFK_FCE_DEG]);
-  const bool carrier = uni((int)r[WFK_FCE_CARRIER]) != 0;
-  const bool env = uni((int)r[WFK_FCE_ENV]) != 0;
-  T c0 = (T)1, s0 = (T)0;
-  if (carrier) {
-    const double2 cs0 = sincos_phase(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]));
-    c0 = (T)cs0.x;
-    s0 = (T)cs0.y;
-  }
-  const double2* tab = reinterpret_cast<const double2*>(blk + uni((int)r[WFK_FCE_TAB]));
-  T val[NS];
-  if (deg == 0) {
-    // A0 * cos(th) only (B was folded into the reference shift on the host)
-    const T ac = (T)r[WFK_FCE_A] * c0, as = (T)r[WFK_FCE_A] * s0;
-    if (carrier) {
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        const double2 cs = tab[k];
-        val[k] = ac * (T)cs.x - as * (T)cs.y;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NS; ++k) val[k] = ac;
-    }
-  } else {
-    const double u0 = x - r[WFK_FCE_SLIN], D = r[WFK_FCE_D];
-    const T A0 = (T)r[WFK_FCE_A], A1 = (T)r[WFK_FCE_A + 1], A2 = (T)r[WFK_FCE_A + 2],
-            A3 = (T)r[WFK_FCE_A + 3];
-    const T B0 = (T)r[WFK_FCE_B], B1 = (T)r[WFK_FCE_B + 1], B2 = (T)r[WFK_FCE_B + 2],
-            B3 = (T)r[WFK_FCE_B + 3];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const T u = (T)(u0 + (double)k * D);
-      T pa, pb;
-      if (deg == 1) {
-        pa = A1 * u + A0;
-        pb = B1 * u + B0;
-      } else {
-        pa = ((A3 * u + A2) * u + A1) * u + A0;
-        pb = ((B3 * u + B2) * u + B1) * u + B0;
-      }
-      if (carrier) {
-        const double2 cs = tab[k];
-        const T ck = c0 * (T)cs.x - s0 * (T)cs.y;
-        const T sk = s0 * (T)cs.x + c0 * (T)cs.y;
-        val[k] = pa * ck + pb * sk;
-      } else {
-        val[k] = pa;
-      }
-    }
-  }
-  if (env) {
-    const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
-    const double gd = exp_seed(-(v * v)), rd = exp_seed(-Hh * (2.0 * v + Hh));
-    if (sizeof(T) == 4 && uni((int)r[WFK_FCE_F32OK]) == 0) {
-      double g = gd, rr = rd;
-      const double q = r[WFK_FCE_Q];
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        acc[k] += val[k] * (T)g;
-        g *= rr;
-        rr *= q;
-      }
-    } else {
-      T g = (T)gd, rr = (T)rd;
-      const T q = (T)r[WFK_FCE_Q];
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        acc[k] += val[k] * g;
-        g *= rr;
-        rr *= q;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) acc[k] += val[k];
-  }
+  FceSeeds sd = fce_make_seeds(r, x);
+  fce_eval<T, NS>(blk, r, sd, x, false, acc);
 }
 
 template <typename T> struct OutOps;
@@ -367,6 +433,133 @@ __device__ __forceinline__ T clip_np(T v, T lo, T hi) {
   v = v < lo ? lo : v;
   v = v > hi ? hi : v;
   return v;
+}
+
+// write one wave tile of one piece: clip (evaluated pieces only), + offset, optional
+// accumulate into `out`; lanes outside [P.start, P.stop) keep their hands off.
+template <typename T, bool CPLX, int NS>
+__device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, const DevPiece& P,
+                                           typename OutOps<T>::Real* outr,
+                                           typename OutOps<T>::Cplx* outc, int64_t w0, int64_t j0,
+                                           const T (&acc)[NS], const T (&acci)[CPLX ? NS : 1]) {
+  using OutC = typename OutOps<T>::Cplx;
+  constexpr int WT = 64 * NS;
+  const bool full = P.start <= w0 && P.stop >= w0 + WT;
+  const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
+  const T lo = (T)C.clip_lo, hi = (T)C.clip_hi, base = (T)C.offset;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int64_t j = j0 + 64 * k;
+    if (full || (j >= P.start && j < P.stop)) {
+      T v = acc[k];
+      if (clip) v = clip_np(v, lo, hi);
+      v += base;
+      if (CPLX) {
+        OutC o;
+        o.x = v;
+        o.y = acci[k];
+        if (a.accumulate) {
+          const OutC old = outc[j];
+          o.x += old.x;
+          o.y += old.y;
+        }
+        outc[j] = o;
+      } else {
+        if (a.accumulate) v += outr[j];
+        outr[j] = v;
+      }
+    }
+  }
+}
+
+// ---- lean kernel: fully fused plans ----------------------------------------------------
+// One wave per workgroup owns `tiles_per_chunk` CONSECUTIVE wave tiles of one channel.
+// Per piece (<= WFK_LEAN_OPS fused ops, one parameter block) the per-lane op state
+// (phasor c,s and Gaussian g,r) lives in LDS and is carried from tile to tile: advancing it
+// costs 4 FMAs per op per tile; exact libm seeds are taken when a piece is entered and
+// every WFK_LEAN_RESEED tiles, in a phase where no accumulator is live (so the libm call
+// does not inflate the kernel's register allocation).  No barriers between waves at all.
+template <typename T, bool CPLX, int NS>
+__global__ void __launch_bounds__(64) wfk_sample_lean(const KArgs a) {
+  __shared__ __attribute__((aligned(16))) double s_par[WFK_LEAN_PAR];
+  __shared__ double s_c[WFK_LEAN_OPS][64], s_s[WFK_LEAN_OPS][64], s_g[WFK_LEAN_OPS][64],
+      s_r[WFK_LEAN_OPS][64];
+  constexpr int WT = 64 * NS;
+  using OutR = typename OutOps<T>::Real;
+  using OutC = typename OutOps<T>::Cplx;
+
+  const int lane = threadIdx.x;
+  const int64_t chunk = blockIdx.x;
+  const int ch = (int)(chunk / a.chunks_per_ch);
+  const int64_t cc = chunk - (int64_t)ch * a.chunks_per_ch;
+  const DevChannel C = a.channels[ch];
+  int p = a.chunk_first[chunk];
+  int64_t staged = -1;
+  int state_piece = -1;       // piece whose op state sits in LDS ...
+  int64_t state_w0 = -1;      // ... valid for the tile that starts here
+  int since_seed = 0;
+
+  OutR* outr = reinterpret_cast<OutR*>(a.out) + (int64_t)ch * a.ch_stride;
+  OutC* outc = reinterpret_cast<OutC*>(a.out) + (int64_t)ch * a.ch_stride;
+
+  for (int tt = 0; tt < a.tiles_per_chunk; ++tt) {
+    const int64_t w0 = (cc * a.tiles_per_chunk + tt) * WT;
+    if (w0 >= a.n) break;
+    const int64_t w1 = w0 + WT < a.n ? w0 + WT : a.n;
+    const int64_t j0 = w0 + lane;
+    while (p < C.piece_end - 1 && a.pieces[p].stop <= w0) ++p;
+
+    for (int q = p; q < C.piece_end; ++q) {
+      const DevPiece P = a.pieces[q];
+      if (P.start >= w1) break;
+      T acc[NS], acci[CPLX ? NS : 1];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) acc[k] = (T)0;
+      if (CPLX) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acci[k] = (T)0;
+      }
+      if (P.n_blk != 0) {
+        if (P.par_off != staged) {
+          __syncthreads();
+          for (int i = lane; i < P.first_len; i += 64) s_par[i] = a.params[P.par_off + i];
+          __syncthreads();
+          staged = P.par_off;
+        }
+        const int nops = uni((int)s_par[1]);
+        double x = grid_time(a, j0);
+        if (C.tshift != 0.0) x = x - C.tshift;
+        const bool carried = state_piece == q && state_w0 == w0 && since_seed < WFK_LEAN_RESEED;
+        if (!carried) {
+          // seed phase: libm, nothing else live
+          for (int op = 0; op < nops; ++op) {
+            const FceSeeds sd = fce_make_seeds(s_par + WFK_BLK_HDR + op * WFK_FCE_REC, x);
+            s_c[op][lane] = sd.c;
+            s_s[op][lane] = sd.s;
+            s_g[op][lane] = sd.g;
+            s_r[op][lane] = sd.r;
+          }
+          since_seed = 0;
+        }
+        for (int op = 0; op < nops; ++op) {
+          FceSeeds sd;
+          sd.c = s_c[op][lane];
+          sd.s = s_s[op][lane];
+          sd.g = s_g[op][lane];
+          sd.r = s_r[op][lane];
+          fce_eval<T, NS>(s_par, s_par + WFK_BLK_HDR + op * WFK_FCE_REC, sd, x, true, acc);
+          s_c[op][lane] = sd.c;
+          s_s[op][lane] = sd.s;
+          s_g[op][lane] = sd.g;
+          s_r[op][lane] = sd.r;
+        }
+        state_piece = q;
+        state_w0 = w0 + WT;
+        ++since_seed;
+      }
+      store_tile<T, CPLX, NS>(a, C, P, outr, outc, w0, j0, acc, acci);
+    }
+  }
 }
 
 template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
@@ -452,42 +645,17 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
         if (b + 1 < P.n_blk) len = (int)a.params[off];
       }
 
-      if (active) {
-        const bool full = P.start <= w0 && P.stop >= w0 + WT;
-        const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
-        const T lo = (T)C.clip_lo, hi = (T)C.clip_hi, base = (T)C.offset;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-          const int64_t j = j0 + 64 * k;
-          if (full || (j >= P.start && j < P.stop)) {
-            T v = acc[k];
-            if (clip) v = clip_np(v, lo, hi);
-            v += base;
-            if (CPLX) {
-              OutC o;
-              o.x = v;
-              o.y = acci[k];
-              if (a.accumulate) {
-                const OutC old = outc[j];
-                o.x += old.x;
-                o.y += old.y;
-              }
-              outc[j] = o;
-            } else {
-              if (a.accumulate) v += outr[j];
-              outr[j] = v;
-            }
-          }
-        }
-      }
+      if (active) store_tile<T, CPLX, NS>(a, C, P, outr, outc, w0, j0, acc, acci);
     }
   }
 }
 
 template <typename T, bool CPLX, bool TLIST, int NS>
-int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool generic, bool direct) {
+int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generic, bool direct) {
   const dim3 g((unsigned)blocks), b(WFK_WG);
-  if (TLIST || direct)
+  if (!TLIST && lean)
+    hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS>), g, dim3(64), 0, s, a);
+  else if (TLIST || direct)
     hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, true, true, NS>), g, b, 0, s, a);
   else if (generic)
     hipLaunchKernelGGL((wfk_sample<T, CPLX, false, true, false, NS>), g, b, 0, s, a);
@@ -498,8 +666,8 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool generic, bool dir
 
 }  // namespace
 
-int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, bool generic,
-                       bool direct, void* stream, std::string& err) {
+int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, bool lean,
+                       bool generic, bool direct, void* stream, std::string& err) {
   const int64_t blocks = (int64_t)n_channels * a.chunks_per_ch;
   if (blocks == 0) return WFK_OK;
   if (blocks > 0x7fffffffLL) { err = "grid too large"; return WFK_EINVAL; }
@@ -507,18 +675,18 @@ int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tl
   int rc;
   if (!tlist) {
     switch (out_kind) {
-      case WFK_OUT_F64: rc = launch<double, false, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
-      case WFK_OUT_F32: rc = launch<float, false, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
-      case WFK_OUT_C128: rc = launch<double, true, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
-      case WFK_OUT_C64: rc = launch<float, true, false, WFK_NS_GRID>(a, blocks, s, generic, direct); break;
+      case WFK_OUT_F64: rc = launch<double, false, false, WFK_NS_GRID>(a, blocks, s, lean, generic, direct); break;
+      case WFK_OUT_F32: rc = launch<float, false, false, WFK_NS_GRID>(a, blocks, s, lean, generic, direct); break;
+      case WFK_OUT_C128: rc = launch<double, true, false, WFK_NS_GRID>(a, blocks, s, lean, generic, direct); break;
+      case WFK_OUT_C64: rc = launch<float, true, false, WFK_NS_GRID>(a, blocks, s, lean, generic, direct); break;
       default: err = "bad out_kind"; return WFK_EINVAL;
     }
   } else {
     switch (out_kind) {
-      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
-      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
-      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
-      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST>(a, blocks, s, true, true); break;
+      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
       default: err = "bad out_kind"; return WFK_EINVAL;
     }
   }
