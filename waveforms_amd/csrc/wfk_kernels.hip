@@ -24,6 +24,7 @@
 
 #include <string>
 #include <type_traits>
+#include <utility>
 
 #include "wfk.h"
 #include "wfk_internal.h"
@@ -31,6 +32,21 @@
 namespace {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Compile-time unrolled loop.  Register arrays are only ever indexed with constants, so
+// SROA splits them into independent scalars up front (a `#pragma unroll` loop indexes them
+// dynamically until late, and the array then becomes ONE 32-register tuple that is copied
+// wholesale at every control-flow merge).
+template <int... K, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, K...>, F&& f) {
+  (f(std::integral_constant<int, K>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+#define WFK_EACH(N, k) static_for<N>([&](auto k##_) __attribute__((always_inline)) { constexpr int k = decltype(k##_)::value;
+#define WFK_END });
 
 // t[j] = fl(fl(j*step) + t0): NumPy's linspace/arange element formula, two roundings.
 __device__ __forceinline__ double grid_time(const KArgs& a, int64_t j) {
@@ -315,11 +331,11 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
   const double D = r[WFK_FCE_D];
   S g = (S)sd.g, rr = (S)sd.r;
   const S q = (S)r[WFK_FCE_Q];
-#pragma unroll
-  for (int k0 = 0; k0 < NS; k0 += SB) {
-#pragma unroll
-    for (int kk = 0; kk < SB; ++kk) {
-      const int k = k0 + kk;
+  T u = (T)u0;
+  const T Dt = (T)D;
+  WFK_EACH(NS / SB, kb)
+    WFK_EACH(SB, kk)
+      constexpr int k = kb * SB + kk;
       T val;
       if (DEG == 0) {
         if (CARRIER) {
@@ -329,7 +345,6 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
           val = A0;
         }
       } else {
-        const T u = (T)(u0 + (double)k * D);
         T pa, pb;
         if (DEG == 1) {
           pa = A1 * u + A0;
@@ -338,6 +353,7 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
           pa = ((A3 * u + A2) * u + A1) * u + A0;
           pb = ((B3 * u + B2) * u + B1) * u + B0;
         }
+        u += Dt;
         if (CARRIER) {
           const double2 cs = tab[k];
           const T ck = c0 * (T)cs.x - s0 * (T)cs.y;
@@ -354,9 +370,9 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
       } else {
         acc[k] += val;
       }
-    }
+    WFK_END
     __builtin_amdgcn_sched_barrier(0);
-  }
+  WFK_END
   // advance the per-lane state by one wave tile (used by the lean kernel, which carries
   // it to the next tile; dead code elsewhere): NS recurrence steps already happened for
   // the envelope, the phasor turns by table entry NS.
@@ -437,39 +453,42 @@ __device__ __forceinline__ T clip_np(T v, T lo, T hi) {
 
 // write one wave tile of one piece: clip (evaluated pieces only), + offset, optional
 // accumulate into `out`; lanes outside [P.start, P.stop) keep their hands off.
+// `tr`/`tc` point at the tile's first sample (wave-uniform => scalar base + lane offset).
 template <typename T, bool CPLX, int NS>
 __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, const DevPiece& P,
-                                           typename OutOps<T>::Real* outr,
-                                           typename OutOps<T>::Cplx* outc, int64_t w0, int64_t j0,
+                                           typename OutOps<T>::Real* tr,
+                                           typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
                                            const T (&acc)[NS], const T (&acci)[CPLX ? NS : 1]) {
   using OutC = typename OutOps<T>::Cplx;
   constexpr int WT = 64 * NS;
   const bool full = P.start <= w0 && P.stop >= w0 + WT;
   const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
+  const bool accum = a.accumulate != 0;
   const T lo = (T)C.clip_lo, hi = (T)C.clip_hi, base = (T)C.offset;
-#pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    const int64_t j = j0 + 64 * k;
-    if (full || (j >= P.start && j < P.stop)) {
+  const int lo_l = (int)(P.start - w0 > 0 ? P.start - w0 : 0);         // tile-relative range
+  const int hi_l = (int)(P.stop - w0 < WT ? P.stop - w0 : WT);
+  WFK_EACH(NS, k)
+    const int o = lane + 64 * k;
+    if (full || (o >= lo_l && o < hi_l)) {
       T v = acc[k];
       if (clip) v = clip_np(v, lo, hi);
       v += base;
-      if (CPLX) {
-        OutC o;
-        o.x = v;
-        o.y = acci[k];
-        if (a.accumulate) {
-          const OutC old = outc[j];
-          o.x += old.x;
-          o.y += old.y;
+      if constexpr (CPLX) {
+        OutC w;
+        w.x = v;
+        w.y = acci[k];
+        if (accum) {
+          const OutC old = tc[o];
+          w.x += old.x;
+          w.y += old.y;
         }
-        outc[j] = o;
+        tc[o] = w;
       } else {
-        if (a.accumulate) v += outr[j];
-        outr[j] = v;
+        if (accum) v += tr[o];
+        tr[o] = v;
       }
     }
-  }
+  WFK_END
 }
 
 // ---- lean kernel: fully fused plans ----------------------------------------------------
@@ -480,7 +499,10 @@ __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, 
 // every WFK_LEAN_RESEED tiles, in a phase where no accumulator is live (so the libm call
 // does not inflate the kernel's register allocation).  No barriers between waves at all.
 template <typename T, bool CPLX, int NS>
-__global__ void __launch_bounds__(64) wfk_sample_lean(const KArgs a) {
+#ifndef WFK_LEAN_WAVES
+#define WFK_LEAN_WAVES 3   // occupancy target (waves per SIMD) for the register allocator
+#endif
+__global__ void __launch_bounds__(64, WFK_LEAN_WAVES) wfk_sample_lean(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LEAN_PAR];
   __shared__ double s_c[WFK_LEAN_OPS][64], s_s[WFK_LEAN_OPS][64], s_g[WFK_LEAN_OPS][64],
       s_r[WFK_LEAN_OPS][64];
@@ -513,12 +535,8 @@ __global__ void __launch_bounds__(64) wfk_sample_lean(const KArgs a) {
       const DevPiece P = a.pieces[q];
       if (P.start >= w1) break;
       T acc[NS], acci[CPLX ? NS : 1];
-#pragma unroll
-      for (int k = 0; k < NS; ++k) acc[k] = (T)0;
-      if (CPLX) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acci[k] = (T)0;
-      }
+      WFK_EACH(NS, k) acc[k] = (T)0; WFK_END
+      WFK_EACH(CPLX ? NS : 1, k) acci[k] = (T)0; WFK_END
       if (P.n_blk != 0) {
         if (P.par_off != staged) {
           __syncthreads();
@@ -557,7 +575,7 @@ __global__ void __launch_bounds__(64) wfk_sample_lean(const KArgs a) {
         state_w0 = w0 + WT;
         ++since_seed;
       }
-      store_tile<T, CPLX, NS>(a, C, P, outr, outc, w0, j0, acc, acci);
+      store_tile<T, CPLX, NS>(a, C, P, outr + w0, outc + w0, w0, lane, acc, acci);
     }
   }
 }
@@ -645,7 +663,7 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
         if (b + 1 < P.n_blk) len = (int)a.params[off];
       }
 
-      if (active) store_tile<T, CPLX, NS>(a, C, P, outr, outc, w0, j0, acc, acci);
+      if (active) store_tile<T, CPLX, NS>(a, C, P, outr + w0, outc + w0, w0, lane, acc, acci);
     }
   }
 }
