@@ -454,22 +454,24 @@ __device__ __forceinline__ T clip_np(T v, T lo, T hi) {
 // write one wave tile of one piece: clip (evaluated pieces only), + offset, optional
 // accumulate into `out`; lanes outside [P.start, P.stop) keep their hands off.
 // `tr`/`tc` point at the tile's first sample (wave-uniform => scalar base + lane offset).
-template <typename T, bool CPLX, int NS>
-__device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, const DevPiece& P,
-                                           typename OutOps<T>::Real* tr,
-                                           typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
-                                           const T (&acc)[NS], const T (&acci)[CPLX ? NS : 1]) {
+// PLAIN = the tile lies inside the piece, no clip, no accumulate: add + store per sample.
+template <typename T, bool CPLX, int NS, bool PLAIN>
+__device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel& C,
+                                                const DevPiece& P, typename OutOps<T>::Real* tr,
+                                                typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
+                                                const T (&acc)[NS],
+                                                const T (&acci)[CPLX ? NS : 1]) {
   using OutC = typename OutOps<T>::Cplx;
   constexpr int WT = 64 * NS;
-  const bool full = P.start <= w0 && P.stop >= w0 + WT;
-  const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
-  const bool accum = a.accumulate != 0;
-  const T lo = (T)C.clip_lo, hi = (T)C.clip_hi, base = (T)C.offset;
+  const T base = (T)C.offset;
+  const bool clip = !PLAIN && C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
+  const bool accum = !PLAIN && a.accumulate != 0;
+  const T lo = (T)C.clip_lo, hi = (T)C.clip_hi;
   const int lo_l = (int)(P.start - w0 > 0 ? P.start - w0 : 0);         // tile-relative range
   const int hi_l = (int)(P.stop - w0 < WT ? P.stop - w0 : WT);
   WFK_EACH(NS, k)
     const int o = lane + 64 * k;
-    if (full || (o >= lo_l && o < hi_l)) {
+    if (PLAIN || (o >= lo_l && o < hi_l)) {
       T v = acc[k];
       if (clip) v = clip_np(v, lo, hi);
       v += base;
@@ -489,6 +491,19 @@ __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, 
       }
     }
   WFK_END
+}
+
+template <typename T, bool CPLX, int NS>
+__device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, const DevPiece& P,
+                                           typename OutOps<T>::Real* tr,
+                                           typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
+                                           const T (&acc)[NS], const T (&acci)[CPLX ? NS : 1]) {
+  const bool full = P.start <= w0 && P.stop >= w0 + 64 * NS;
+  const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
+  if (full && !clip && !a.accumulate)
+    store_tile_impl<T, CPLX, NS, true>(a, C, P, tr, tc, w0, lane, acc, acci);
+  else
+    store_tile_impl<T, CPLX, NS, false>(a, C, P, tr, tc, w0, lane, acc, acci);
 }
 
 // ---- lean kernel: fully fused plans ----------------------------------------------------
