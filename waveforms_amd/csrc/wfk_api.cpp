@@ -66,6 +66,9 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
 
 extern "C" {
 
+// shared with wfk_fir.hip (not part of the public header)
+void wfk_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
+
 int wfk_abi_version(void) { return WFK_ABI_VERSION; }
 
 const char* wfk_last_error(void) { return g_err.c_str(); }
