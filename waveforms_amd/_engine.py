@@ -7,6 +7,7 @@ launch raises.  ctypes releases the GIL during calls.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -49,6 +50,12 @@ def lib():
             raise EngineError(
                 f'{LIB_PATH} not found: build it with `make -C waveforms_amd/csrc` '
                 f'(hipcc --offload-arch=gfx950). waveforms_amd has no CPU sampling path.')
+        # PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 / librocfft under
+        # the same SONAMEs as /opt/rocm.  Whichever is loaded first serves the whole
+        # process, and a system runtime loaded before torch leaves torch without a GPU.
+        # So when torch is installed, let it load its runtime first.
+        if importlib.util.find_spec('torch') is not None:
+            import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         l.wfk_last_error.restype = C.c_char_p
         P, I64, I32, VP = C.POINTER, C.c_int64, C.c_int32, C.c_void_p
