@@ -31,22 +31,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 
 
-def build_workload(name, rank, channels, points):
+def workload(name, channels, points):
+    """-> (make_channel(c), grid, dtype, description); channel c is global (all ranks)."""
     import waveforms_amd as wf
     from waveforms_amd import workloads as wl
-    base = rank * channels
     if name in ('sampler256', 'c4'):
-        chans = [wl.sum_channel(wf, 100, 1000 + base + c) for c in range(channels)]
-        return chans, wl.c2_grid(points), np.float64, (
-            f'{channels} ch x {points:.0e} pts, 100 gaussian+DRAG pulses/ch '
+        return (lambda c: wl.sum_channel(wf, 100, 1000 + c)), wl.c2_grid(points), np.float64, (
+            f'{channels} ch/GPU x {points:.0e} pts, 100 gaussian+DRAG pulses/ch '
             f'(SURVEY 8(d) C4/C5 channel spec), grid mode')
     if name == 'c2':
-        return [wl.c2_channel(wf)], wl.c2_grid(points), np.float64, (
+        return (lambda c: wl.c2_channel(wf)), wl.c2_grid(points), np.float64, (
             f'C2: 1 ch x 100 gaussian+DRAG pulses x {points:.0e} pts')
     if name == 'c3':
-        chans = [wl.vstack_channel(wf, 20, 100 + base + c) for c in range(channels)]
-        return chans, wl.c3_grid(points), np.float32, (
-            f'C3: {channels} WaveVStack ch x 20 pulses x {points:.0e} pts')
+        return (lambda c: wl.vstack_channel(wf, 20, 100 + c)), wl.c3_grid(points), np.float32, (
+            f'C3: {channels} WaveVStack ch/GPU x 20 pulses x {points:.0e} pts')
     raise SystemExit(f'unknown workload {name}')
 
 
@@ -97,14 +95,17 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from waveforms_amd import _engine
-    from waveforms_amd._sampling import BatchSampler
+    from waveforms_amd._dist import ShardedSampler
     _engine.set_device(local_rank)
 
     name = args.workload
     channels = args.channels or (1 if name == 'c2' else 256)
     points = int(args.points or (10**6 if name == 'c3' else 10**7))
-    chans, grid, dtype, desc = build_workload(name, rank, channels, points)
-    bs = BatchSampler(chans, grid)
+    make_channel, grid, dtype, desc = workload(name, channels, points)
+    # weak scaling: every rank owns a block of `channels` channels of the global job
+    sh = ShardedSampler(channels * world, make_channel, grid, rank, world)
+    bs = sh.local
+    chans = [make_channel(c) for c in range(min(channels, 32))] if rank == 0 else []
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     out = torch.empty((bs.n_channels, bs.n), dtype=tdt, device='cuda')
     fir = None

@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: world_size 2, gloo.  Covers what the multi-GPU bench relies on
+apart from the kernels: channel-block partitioning, rank-local flatten/compile (host-
+only plans: bit-exact piece indices vs the unsharded program), result placement by
+all_gather, and the max-over-ranks timing reduction."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_channel_block_partition():
+    from waveforms_amd._dist import channel_block
+    for n in (0, 1, 5, 256, 257, 4096):
+        for world in (1, 2, 3, 8):
+            blocks = [channel_block(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        channel_block(4, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import waveforms_amd as wf
+        from waveforms_amd import _engine, _flatten, workloads as wl
+        from waveforms_amd._dist import channel_block, gather_rows, max_over_ranks
+        nch, grid = 7, ('linspace', 0.0, 6 * wl.SPAN, 40000, False)
+        make = lambda c: wl.sum_channel(wf, 6, 1000 + c)
+        a, b = channel_block(nch, rank, world)
+        local = _flatten.flatten([make(c) for c in range(a, b)])
+        plan = _engine.Plan(local, grid=_flatten.grid_from_desc(grid))      # host-only
+        whole = _flatten.flatten([make(c) for c in range(nch)])
+        ref = _engine.Plan(whole, grid=_flatten.grid_from_desc(grid))
+        for i, c in enumerate(range(a, b)):
+            assert np.array_equal(plan.member_index(i), ref.member_index(c))
+        # result placement: rank r contributes rows filled with its channel numbers
+        rows = torch.arange(a, b, dtype=torch.float64)[:, None].repeat(1, 5)
+        full = gather_rows(rows, nch)
+        assert full.shape == (nch, 5)
+        assert torch.equal(full[:, 0], torch.arange(nch, dtype=torch.float64))
+        assert max_over_ranks(1.0 + rank) == float(world)
+        q.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
