@@ -15,8 +15,17 @@ FIR = golden_io.npz('fir.npz')
 BIG = golden_io.npz('big.npz')
 
 
+@pytest.fixture(params=['fused', 'rocfft'])
+def fir_path(request, monkeypatch):
+    """Both FIR implementations behind wfk_fir_*: the fused LDS-FFT kernel (short
+    kernels) and the rocFFT overlap-save pipeline (any length)."""
+    if request.param == 'rocfft':
+        monkeypatch.setenv('WFK_FIR_ROCFFT', '1')
+    return request.param
+
+
 @pytest.mark.parametrize('i', range(10))
-def test_fir_matches_reference_vectors(i):
+def test_fir_matches_reference_vectors(i, fir_path):
     sig, ker, want = FIR[f'{i}.sig'], FIR[f'{i}.ker'], FIR[f'{i}.out']
     got = distortion.predistort(sig, ker=ker)
     assert got.shape == want.shape and got.dtype == np.float64
@@ -24,10 +33,10 @@ def test_fir_matches_reference_vectors(i):
     assert np.max(np.abs(got - want)) <= 1e-12 * scale
 
 
-def test_fir_edge_semantics():
+def test_fir_edge_semantics(fir_path):
     rng = np.random.default_rng(3)
     for n, k in [(1, 1), (2, 5), (17, 2), (7168, 1024), (7169, 1024), (7170, 1024),
-                 (20000, 1), (50, 1024)]:
+                 (20000, 1), (50, 1024), (9000, 1537), (9000, 1538), (5000, 3000)]:
         sig, ker = rng.normal(size=n), rng.normal(size=k)
         want = np_oracle.predistort_fir(sig, ker)
         got = distortion.predistort(sig, ker=ker)
@@ -42,7 +51,7 @@ def test_fir_edge_semantics():
         distortion.predistort(s, filters=[([1.0], [1.0, -0.5])])
 
 
-def test_fir_batch_fp32_and_properties():
+def test_fir_batch_fp32_and_properties(fir_path):
     import torch
     rng = np.random.default_rng(5)
     n, batch, K = 300_000, 5, 1024

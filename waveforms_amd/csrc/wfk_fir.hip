@@ -71,7 +71,16 @@ std::once_flag g_rocfft_once;
 
 }  // namespace
 
+// fused single-kernel path for short kernels (wfk_fir_fused.hip)
+extern "C" int wfk_internal_fir_fused_launch(int kind, const void* in, int64_t in_stride, void* out,
+                                             int64_t out_stride, const void* hspec, const void* tw,
+                                             int64_t n, int M, int K, int lead, int64_t nblk,
+                                             int32_t batch, void* stream);
+extern "C" int wfk_internal_fir_fused_len(void);
+
 struct wfk_fir_plan {
+  bool fused = false;
+  void* tw = nullptr;          // fused: exp(-2 pi i j / L), j < 256
   int32_t K = 0, batch = 0, kind = 0, L = 0, M = 0, lead = 0, chunk = 0;
   int64_t n = 0, nblk = 0;
   rocfft_plan fwd = nullptr, inv = nullptr, fwd_tail = nullptr, inv_tail = nullptr;
@@ -174,6 +183,7 @@ int wfk_fir_plan_destroy(wfk_fir_plan* p) {
   (void)hipFree(p->win);
   (void)hipFree(p->spec);
   (void)hipFree(p->kspec);
+  (void)hipFree(p->tw);
   delete p;
   return WFK_OK;
 }
@@ -192,14 +202,19 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
   std::call_once(g_rocfft_once, [] { rocfft_setup(); });
   wfk_fir_plan* p = new wfk_fir_plan();
   p->K = K; p->n = n; p->batch = batch; p->kind = kind;
+  const int FL = wfk_internal_fir_fused_len();
+  const char* force = getenv("WFK_FIR_ROCFFT");
+  p->fused = K <= FL - 2559 && batch <= 65535 && !(force && force[0] == '1');
   int L = 1024;
   while (L < 8 * K) L *= 2;               // hop M = L - K + 1 >= 7/8 L
   if (const char* e = getenv("WFK_FIR_L")) { int v = atoi(e); if (v >= 2 * K && (v & (v - 1)) == 0) L = v; }
+  if (p->fused) L = FL;
   p->L = L; p->M = L - K + 1; p->lead = (K - 1) - K / 2;
   p->nblk = n > 0 ? (n + p->M - 1) / p->M : 0;
   if (n == 0) { *out = p; return WFK_OK; }
   const size_t es = kind == WFK_OUT_F32 ? 4 : 8;
-  const size_t nf = (size_t)L / 2 + 1;
+  const size_t nf = p->fused ? (size_t)L : (size_t)L / 2 + 1;   // fused: full complex spectrum
+  if (!p->fused) {
   const double per_ch = (double)p->nblk * ((double)L * es + (double)nf * 2 * es);
   int64_t chunk = (int64_t)(3.0e9 / per_ch);
   chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, batch));
@@ -214,12 +229,17 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
   bool ok = rocfft_execution_info_create(&p->info) == rocfft_status_success;
   ok = ok && hipMalloc(&p->win, (size_t)p->chunk * p->nblk * L * es) == hipSuccess;
   ok = ok && hipMalloc(&p->spec, (size_t)p->chunk * p->nblk * nf * 2 * es) == hipSuccess;
-  ok = ok && hipMalloc(&p->kspec, nf * 2 * es) == hipSuccess;
   if (ok && work_bytes) {
     ok = hipMalloc(&p->work, work_bytes) == hipSuccess &&
          rocfft_execution_info_set_work_buffer(p->info, p->work, work_bytes) == rocfft_status_success;
   }
   if (!ok) {
+    wfk_fir_plan_destroy(p);
+    return fir_fail(WFK_ENOMEM, "FIR buffer allocation failed");
+  }
+  }
+  if (hipMalloc(&p->kspec, nf * 2 * es) != hipSuccess ||
+      (p->fused && hipMalloc(&p->tw, 256 * 2 * es) != hipSuccess)) {
     wfk_fir_plan_destroy(p);
     return fir_fail(WFK_ENOMEM, "FIR buffer allocation failed");
   }
@@ -241,6 +261,16 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
   hipError_t e = kind == WFK_OUT_F32
                      ? hipMemcpy(p->kspec, ks32.data(), nf * 8, hipMemcpyHostToDevice)
                      : hipMemcpy(p->kspec, ks64.data(), nf * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess && p->fused) {
+    std::vector<double> t64(512);
+    std::vector<float> t32(512);
+    for (int j = 0; j < 256; ++j) {
+      t64[2 * j] = (double)tw[j].real(); t64[2 * j + 1] = (double)tw[j].imag();
+      t32[2 * j] = (float)tw[j].real(); t32[2 * j + 1] = (float)tw[j].imag();
+    }
+    e = kind == WFK_OUT_F32 ? hipMemcpy(p->tw, t32.data(), 256 * 8, hipMemcpyHostToDevice)
+                            : hipMemcpy(p->tw, t64.data(), 256 * 16, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     wfk_fir_plan_destroy(p);
     return fir_fail(WFK_EHIP, "kernel spectrum upload failed");
@@ -255,8 +285,14 @@ int wfk_fir_apply(wfk_fir_plan* p, const void* in_dev, int64_t in_stride, void* 
   if (p->n == 0) return WFK_OK;
   if (!in_dev || !out_dev) return fir_fail(WFK_EINVAL, "null buffer");
   if (in_stride < p->n || out_stride < p->n) return fir_fail(WFK_EINVAL, "stride smaller than n");
-  if (p->nblk > 65535) return fir_fail(WFK_EINVAL, "signal too long for one FIR plan (blocks > 65535)");
   hipStream_t s = (hipStream_t)hip_stream;
+  if (p->fused) {
+    if (wfk_internal_fir_fused_launch(p->kind, in_dev, in_stride, out_dev, out_stride, p->kspec,
+                                      p->tw, p->n, p->M, p->K, p->lead, p->nblk, p->batch, s))
+      return fir_fail(WFK_EHIP, "fused FIR kernel launch failed");
+    return WFK_OK;
+  }
+  if (p->nblk > 65535) return fir_fail(WFK_EINVAL, "signal too long for one rocFFT FIR plan (blocks > 65535)");
   if (p->kind == WFK_OUT_F32) return fir_run<float, float2>(p, in_dev, in_stride, out_dev, out_stride, s);
   return fir_run<double, double2>(p, in_dev, in_stride, out_dev, out_stride, s);
 }

@@ -1,0 +1,204 @@
+// wfk_fir_fused.hip -- fused overlap-save FIR for short kernels (K <= 1537).
+//
+// One 256-thread workgroup convolves TWO consecutive overlap-save windows of one row:
+// the windows are packed as z = x1 + i*x2; because the FIR kernel is real,
+// conv(z, h) = conv(x1, h) + i*conv(x2, h), so ONE complex FFT of length L = 4096, one
+// pointwise multiply by the (full, complex) kernel spectrum, and one inverse FFT give both
+// blocks with no real-FFT split/merge pass.  The whole transform lives on chip:
+//   4096 = 16 x 16 x 16: three radix-16 passes, each thread holds 16 complex points in
+//   registers; two LDS exchanges per transform (layouts padded against bank conflicts).
+// HBM traffic per output sample: read 8*L/M + write 8 bytes (L/M = 1.33 for K = 1024)
+// instead of the ~120 B/sample of the rocFFT pipeline in wfk_fir.hip.
+//
+// Index maps (N = 4096, forward):  input  v[n1] = x[256*n1 + tid]
+//                                  output v[k3] = X[tid + 256*k3]      (natural order)
+// so the output of the forward transform is exactly the input layout of the inverse.
+#include <hip/hip_runtime.h>
+
+#include "wfk.h"
+
+namespace {
+
+constexpr int FL = 4096;        // transform length
+constexpr int RB = 273;         // padded row for the second exchange (elements)
+constexpr int LDS_ELEMS = 16 * RB;
+
+template <typename T>
+struct cx {
+  T x, y;
+};
+template <typename T>
+__device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// multiply by -i (forward) or +i (inverse)
+template <bool INV, typename T>
+__device__ __forceinline__ cx<T> rot(cx<T> a) {
+  return INV ? cx<T>{-a.y, a.x} : cx<T>{a.y, -a.x};
+}
+
+template <bool INV, typename T>
+__device__ __forceinline__ void dft4(cx<T>& a, cx<T>& b, cx<T>& c, cx<T>& d) {
+  const cx<T> s0 = a + c, s1 = a - c, s2 = b + d, s3 = rot<INV>(b - d);
+  a = s0 + s2;
+  b = s1 + s3;
+  c = s0 - s2;
+  d = s1 - s3;
+}
+
+// 16-point DFT in registers, natural order in and out: v[k] = sum_n v[n] W16^{+-nk}
+template <bool INV, typename T>
+__device__ __forceinline__ void dft16(cx<T> (&v)[16]) {
+  // n = 4*n1 + n2: DFT4 over n1 for every n2
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+  // now v[4*k1 + n2]; twiddle W16^{n2*k1}
+  const T c1 = (T)0.92387953251128673848, s1 = (T)0.38268343236508977173;  // cos/sin(pi/8)
+  const T h = (T)0.70710678118654752440;
+  const T sg = INV ? (T)1 : (T)-1;  // forward: exp(-i..)
+  const cx<T> w1{c1, sg * s1}, w2{h, sg * h}, w3{s1, sg * c1}, w6{-h, sg * h}, w9{-c1, -sg * s1};
+  v[4 * 1 + 1] = cmul(v[4 * 1 + 1], w1);
+  v[4 * 1 + 2] = cmul(v[4 * 1 + 2], w2);
+  v[4 * 1 + 3] = cmul(v[4 * 1 + 3], w3);
+  v[4 * 2 + 1] = cmul(v[4 * 2 + 1], w2);
+  v[4 * 2 + 2] = rot<INV>(v[4 * 2 + 2]);  // W16^4 = -+i
+  v[4 * 2 + 3] = cmul(v[4 * 2 + 3], w6);
+  v[4 * 3 + 1] = cmul(v[4 * 3 + 1], w3);
+  v[4 * 3 + 2] = cmul(v[4 * 3 + 2], w6);
+  v[4 * 3 + 3] = cmul(v[4 * 3 + 3], w9);
+  // DFT4 over n2 for every k1: result A[k1 + 4*k2] sits at v[4*k1 + k2]
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+  // transpose the 4x4 register tile to natural order
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      const cx<T> t = v[4 * a + b];
+      v[4 * a + b] = v[4 * b + a];
+      v[4 * b + a] = t;
+    }
+}
+
+// v[k] *= w^k, k = 1..15 (w = base twiddle); powers by a short product tree
+template <typename T>
+__device__ __forceinline__ void twiddle16(cx<T> (&v)[16], cx<T> w) {
+  const cx<T> w2 = cmul(w, w), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
+  const cx<T> w3 = cmul(w2, w), w5 = cmul(w4, w), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+  v[1] = cmul(v[1], w);
+  v[2] = cmul(v[2], w2);
+  v[3] = cmul(v[3], w3);
+  v[4] = cmul(v[4], w4);
+  v[5] = cmul(v[5], w5);
+  v[6] = cmul(v[6], w6);
+  v[7] = cmul(v[7], w7);
+  v[8] = cmul(v[8], w8);
+  v[9] = cmul(v[9], cmul(w8, w));
+  v[10] = cmul(v[10], cmul(w8, w2));
+  v[11] = cmul(v[11], cmul(w8, w3));
+  v[12] = cmul(v[12], cmul(w8, w4));
+  v[13] = cmul(v[13], cmul(w8, w5));
+  v[14] = cmul(v[14], cmul(w8, w6));
+  v[15] = cmul(v[15], cmul(w8, w7));
+}
+
+// in: v[n1] = x[256*n1 + tid]; out: v[k3] = X[tid + 256*k3].  tw[j] = exp(-2 pi i j/4096), j<256
+template <bool INV, typename T>
+__device__ __forceinline__ void fft4096(cx<T> (&v)[16], cx<T>* lds, const cx<T>* __restrict__ tw,
+                                        int tid) {
+  // pass 1: DFT16 over n1, twiddle W_4096^{tid*k1}
+  dft16<INV>(v);
+  {
+    cx<T> w = tw[tid];
+    if (INV) w.y = -w.y;
+    twiddle16(v, w);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) lds[k1 * 256 + tid] = v[k1];
+  __syncthreads();
+  // pass 2: thread (k1, n3): DFT16 over n2 of E1[k1][16*n2 + n3], twiddle W_256^{n3*k2}
+  {
+    const int k1 = tid >> 4, n3 = tid & 15;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = lds[k1 * 256 + 16 * n2 + n3];
+    __syncthreads();
+    dft16<INV>(v);
+    cx<T> w = tw[16 * n3];
+    if (INV) w.y = -w.y;
+    twiddle16(v, w);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) lds[k1 * RB + n3 * 17 + k2] = v[k2];
+  }
+  __syncthreads();
+  // pass 3: thread (k1 = tid&15, k2 = tid>>4): DFT16 over n3 -> k3
+  {
+    const int k1 = tid & 15, k2 = tid >> 4;
+#pragma unroll
+    for (int n3 = 0; n3 < 16; ++n3) v[n3] = lds[k1 * RB + n3 * 17 + k2];
+    dft16<INV>(v);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fir_fused(const T* __restrict__ in, int64_t in_stride,
+                                                 T* __restrict__ out, int64_t out_stride,
+                                                 const cx<T>* __restrict__ hspec,
+                                                 const cx<T>* __restrict__ tw, int64_t n, int M,
+                                                 int K, int lead) {
+  __shared__ __attribute__((aligned(16))) cx<T> lds[LDS_ELEMS];
+  const int tid = threadIdx.x;
+  const int64_t pair = blockIdx.x, ch = blockIdx.y;
+  const T* row = in + ch * in_stride;
+  T* orow = out + ch * out_stride;
+  const int64_t b1 = 2 * pair, b2 = b1 + 1;
+  const int64_t s1 = b1 * M - lead, s2 = b2 * M - lead;  // window starts (sample index)
+
+  cx<T> v[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int i = 256 * n1 + tid;
+    const int64_t j1 = s1 + i, j2 = s2 + i;
+    v[n1].x = (j1 >= 0 && j1 < n) ? row[j1] : (T)0;
+    v[n1].y = (j2 >= 0 && j2 < n) ? row[j2] : (T)0;
+  }
+  fft4096<false>(v, lds, tw, tid);
+#pragma unroll
+  for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
+  __syncthreads();  // pass-3 reads of the forward transform are done
+  fft4096<true>(v, lds, tw, tid);
+#pragma unroll
+  for (int q3 = 0; q3 < 16; ++q3) {
+    const int r = tid + 256 * q3 - (K - 1);
+    if (r >= 0 && r < M) {
+      const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
+      if (d1 < n) orow[d1] = v[q3].x;
+      if (d2 < n) orow[d2] = v[q3].y;
+    }
+  }
+}
+
+}  // namespace
+
+// launched from wfk_fir.hip
+extern "C" int wfk_internal_fir_fused_launch(int kind, const void* in, int64_t in_stride, void* out,
+                                             int64_t out_stride, const void* hspec, const void* tw,
+                                             int64_t n, int M, int K, int lead, int64_t nblk,
+                                             int32_t batch, void* stream) {
+  const dim3 grid((unsigned)((nblk + 1) / 2), (unsigned)batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == WFK_OUT_F32)
+    hipLaunchKernelGGL(fir_fused<float>, grid, dim3(256), 0, s, (const float*)in, in_stride,
+                       (float*)out, out_stride, (const cx<float>*)hspec, (const cx<float>*)tw, n, M,
+                       K, lead);
+  else
+    hipLaunchKernelGGL(fir_fused<double>, grid, dim3(256), 0, s, (const double*)in, in_stride,
+                       (double*)out, out_stride, (const cx<double>*)hspec, (const cx<double>*)tw, n,
+                       M, K, lead);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int wfk_internal_fir_fused_len(void) { return FL; }
