@@ -132,12 +132,16 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     t0 = time.perf_counter()
+    ev_fir = []
     for a, b in ev:
         a.record()          # events on torch's current stream == the launch stream
         bs.launch_torch(out)
         b.record()
         if fir is not None:
             fir.apply_torch(out, out2)
+            c = torch.cuda.Event(enable_timing=True)
+            c.record()
+            ev_fir.append((b, c))
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -170,6 +174,16 @@ def main():
                      'traffic': traffic, 'kernel': 'wfk_sample',
                      'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': algo_bytes},
     }
+    if fir is not None:
+        # the FIR stage dominates this workload: report ITS roofline (16 B/sample: read+write)
+        fir_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_fir]))
+        fb = 2 * algo_bytes
+        line['roofline'] = {'bound': 'hbm', 'achieved': fb / (fir_ms * 1e-3) / 1e9,
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': fb / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            'traffic': traffic, 'kernel': 'fir_fused', 'kernel_ms': fir_ms,
+                            'algorithmic_bytes_per_launch': fb,
+                            'sampler_kernel_ms': kern_ms}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, outs = cpu_baseline(chans, grid)
         line['cpu_baseline'] = base
