@@ -165,6 +165,27 @@ int wfk_fir_apply(wfk_fir_plan* plan, const void* in_dev, int64_t in_stride,
                   void* out_dev, int64_t out_stride, void* hip_stream);
 int wfk_fir_plan_destroy(wfk_fir_plan* plan);
 
+/* -- IIR stage ---------------------------------------- */
+/* y = cascade of direct-form-II-transposed sections along each row, i.e.
+ *   scipy.signal.sosfilt (n_sections sections of order 2)  -- Waveform.sample(filters=),
+ *                                                             waveforms/waveform.py:193-203,244-251
+ *   scipy.signal.lfilter (ONE section of order max(len(a),len(b))-1) -- predistort(filters=),
+ *                                                             waveforms/distortion.py:298-321
+ * orders[s] = order of section s; b and a hold the sections back to back, orders[s]+1
+ * coefficients each (a[0] of a section need not be 1).  State layout == scipy's zi:
+ * sections back to back, orders[s] values each (total wfk_iir_state_dim()).
+ * apply: out = F(in - initial) + initial; zi_dev/zf_dev: optional [batch][state_dim]
+ * device arrays (initial state in, final state out; NULL = zeros / not wanted).       */
+typedef struct wfk_iir_plan wfk_iir_plan;
+int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double* b,
+                        const double* a, int64_t n, int32_t batch,
+                        int kind /* WFK_OUT_F64|F32 */, wfk_iir_plan** out);
+int wfk_iir_state_dim(const wfk_iir_plan* plan);
+int wfk_iir_apply(wfk_iir_plan* plan, const void* in_dev, int64_t in_stride, void* out_dev,
+                  int64_t out_stride, const double* zi_dev, double* zf_dev, double initial,
+                  void* hip_stream);
+int wfk_iir_plan_destroy(wfk_iir_plan* plan);
+
 /* -- device memory helpers for FFI callers without a HIP binding ---------- */
 int wfk_malloc(void** dev_ptr, size_t bytes);
 int wfk_free(void* dev_ptr);

@@ -16,6 +16,7 @@ Outputs
   tests/golden/sample_api.npz     reference wav.sample() per sos_case
   tests/golden/big.npz            C2 / C3 / C4: strided subsets, piece indices, sums
   tests/golden/fir.npz            distortion.predistort(sig, ker=...) vectors
+  tests/golden/iir.npz            sample(filters=...) and predistort(filters=...) vectors
 """
 import json
 import os
@@ -159,6 +160,27 @@ def main():
         fir[f'{i}.ker'] = kr
         fir[f'{i}.out'] = ref.distortion.predistort(sig, ker=kr)
     np.savez_compressed(os.path.join(gold, 'fir.npz'), **fir)
+
+    # ---- IIR stages: sample(filters=) and predistort(filters=) ----
+    from scipy.signal import butter, tf2sos
+    iir = {}
+    for name, (build, start, stop, rate, order, fc, initial) in cases.iir_cases().items():
+        w = build(ref)
+        w.start, w.stop, w.sample_rate = start, stop, rate
+        b, a = butter(order, fc, 'lowpass', fs=rate)
+        w.filters = (tf2sos(b, a), initial)
+        iir[name + '.full'] = w.sample()
+        iir[name + '.chunked'] = np.concatenate(list(w.sample(chunk_size=300)))
+    dist = ref.distortion
+    for i, (n, params, initial, k) in enumerate(cases.predistort_cases()):
+        sig, ker = cases.predistort_inputs(i)      # seeded: inputs are not stored
+        filters = [dist.exp_decay_filter(A, tau, 1e9) for A, tau in params]
+        y, zf = dist.predistort(sig, filters, ker=ker, initial=initial, return_zf=True)
+        iir[f'pd{i}.out'], iir[f'pd{i}.zf'] = y, zf
+        b, a = dist.combine_filters(filters)
+        iir[f'pd{i}.ba'] = np.concatenate([b, a])
+        iir[f'pd{i}.distort'] = dist.distort(sig, np.asarray(params).reshape(-1), 1e9, initial)
+    np.savez_compressed(os.path.join(gold, 'iir.npz'), **iir)
     for f in sorted(os.listdir(gold)):
         print(f, os.path.getsize(os.path.join(gold, f)))
 

@@ -124,3 +124,48 @@ def predistort_fir(sig, ker):
     padded = np.hstack((np.zeros_like(sig), sig, np.zeros_like(sig)))
     a = n + len(ker) // 2
     return fftconvolve(padded, ker, mode='full')[a:a + n]
+
+
+# ---- IIR stages --------------------------------------------
+def sample_filtered(w, chunk_size=None):
+    """Waveform.sample with filters=(sos, initial): scipy.signal.sosfilt on the sampled
+    signal, state carried across chunks (reference: waveform.py:193-203, 209-257)."""
+    from scipy.signal import sosfilt
+    sos, initial = w.filters
+    sos = np.array(sos)
+    if chunk_size is None:
+        sig = sample(w)
+        return sosfilt(sos, sig - initial) + initial if initial else sosfilt(sos, sig)
+    out, start = [], float(w.start)
+    length = chunk_size / w.sample_rate
+    zi = np.zeros((sos.shape[0], 2))
+    while start < w.stop:
+        if start + length > w.stop:
+            length, stop = w.stop - start, float(w.stop)
+            size = round((stop - start) * w.sample_rate)
+        else:
+            stop, size = start + length, chunk_size
+        sig = call(w, np.linspace(start, stop, size, endpoint=False))
+        if initial:
+            sig = sig - initial
+        sig, zi = sosfilt(sos, sig, zi=zi)
+        out.append(sig + initial if initial else sig)
+        start = stop
+    return np.concatenate(out)
+
+
+def predistort(sig, filters=None, ker=None, initial=0.0, zi=None):
+    """predistort with both branches (reference: distortion.py:289-337) -> (out, zf)."""
+    from scipy.signal import lfilter, lfiltic
+    zf = None
+    if filters is not None:
+        b, a = np.poly1d([1.0]), np.poly1d([1.0])
+        for b_, a_ in filters:
+            b, a = b * np.poly1d(b_), a * np.poly1d(a_)
+        b, a = b.coeffs, a.coeffs
+        if zi is None:
+            zi = lfiltic(b, a, np.full(len(a) - 1, initial), np.full(len(b) - 1, initial))
+        sig, zf = lfilter(b, a, sig, zi=zi)
+    if ker is not None:
+        sig = predistort_fir(sig, ker)
+    return sig, zf

@@ -177,3 +177,37 @@ def sos_cases():
         'sample_odd': (lambda ns: ns.gaussian(3) * ns.cos(7) >> 0.1, -4.0, 4.3,
                        123.456),
     }
+
+
+def iir_cases():
+    """sample(filters=(sos, initial)) cases: name -> (builder, start, stop, rate,
+    butter order, cutoff, initial).  First two mirror the reference's test_filters
+    (tests/test_waveform.py:169-194, tests/test_wavevstack.py:113-137)."""
+    return {
+        'iir_step': (lambda ns: ns.step(0), -1, 1, 1000, 3, 4.0, 0),
+        'iir_vstack': (lambda ns: ns.WaveVStack([ns.step(0) << 0.5, -ns.step(0)]),
+                       -1, 1, 1000, 3, 4.0, 0),
+        'iir_initial': (lambda ns: 0.3 + ns.square(0.8, edge=0.1) * ns.cos(40.0),
+                        -1, 1.5, 4000, 4, 90.0, 0.3),
+        'iir_long': (lambda ns: ns.square(30.0) * ns.cos(3.0) >> 40,
+                     0, 80, 1500, 2, 7.0, 0),
+    }
+
+
+def predistort_cases():
+    """predistort(sig, filters=[exp_decay_filter(A, tau, 1e9)...], ker=...) cases:
+    (n, [(A, tau)...], initial, fir_taps)."""
+    return [
+        (5000, [(0.02, 150e-9)], 0.0, 0),
+        (60000, [(0.02, 150e-9), (-0.01, 2.5e-6)], 0.25, 0),
+        (30000, [(0.03, 40e-9), (0.01, 900e-9), (-0.005, 20e-6)], -0.1, 33),
+        (9, [(0.05, 10e-9)], 1.0, 0),
+    ]
+
+
+def predistort_inputs(i):
+    n, _, initial, k = predistort_cases()[i]
+    rng = np.random.default_rng(700 + i)
+    sig = rng.normal(size=n) + initial
+    ker = rng.normal(size=k) if k else None
+    return sig, ker

@@ -70,6 +70,10 @@ def lib():
         l.wfk_fir_plan_create.argtypes = [VP, I32, I64, I32, C.c_int, P(VP)]
         l.wfk_fir_apply.argtypes = [VP, VP, I64, VP, I64, VP]
         l.wfk_fir_plan_destroy.argtypes = [VP]
+        l.wfk_iir_plan_create.argtypes = [I32, VP, VP, VP, I64, I32, C.c_int, P(VP)]
+        l.wfk_iir_state_dim.argtypes = [VP]
+        l.wfk_iir_apply.argtypes = [VP, VP, I64, VP, I64, VP, VP, C.c_double, VP]
+        l.wfk_iir_plan_destroy.argtypes = [VP]
         l.wfk_malloc.argtypes = [P(VP), C.c_size_t]
         l.wfk_free.argtypes = [VP]
         l.wfk_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
@@ -171,6 +175,45 @@ class FirPlan:
     def close(self):
         if self._h:
             lib().wfk_fir_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class IirPlan:
+    """Cascade of direct-form-II-transposed sections along each of `batch` rows.
+
+    sections: list of (b, a) coefficient sequences; a section's order is
+    max(len(b), len(a)) - 1 (scipy.signal.lfilter convention).  An SOS matrix is the
+    list [(row[:3], row[3:]) for row in sos] (scipy.signal.sosfilt)."""
+
+    def __init__(self, sections, n: int, batch: int = 1, dtype=np.float64):
+        orders, bs, as_ = [], [], []
+        for b, a in sections:
+            b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+            a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+            m = max(len(b), len(a))
+            bs.append(np.concatenate([b, np.zeros(m - len(b))]))
+            as_.append(np.concatenate([a, np.zeros(m - len(a))]))
+            orders.append(m - 1)
+        orders = np.asarray(orders, dtype=np.int32)
+        bflat = np.ascontiguousarray(np.concatenate(bs))
+        aflat = np.ascontiguousarray(np.concatenate(as_))
+        self.n, self.batch, self.dtype = int(n), int(batch), np.dtype(dtype)
+        self._h = C.c_void_p()
+        check(lib().wfk_iir_plan_create(len(orders), orders.ctypes.data, bflat.ctypes.data,
+                                        aflat.ctypes.data, self.n, self.batch,
+                                        _KIND_OF[self.dtype], C.byref(self._h)))
+        self.state_dim = int(sum(orders))
+
+    def apply(self, in_ptr, in_stride, out_ptr, out_stride, zi_ptr=None, zf_ptr=None,
+              initial=0.0, stream=0):
+        check(lib().wfk_iir_apply(self._h, in_ptr, in_stride, out_ptr, out_stride, zi_ptr,
+                                  zf_ptr, float(initial), stream))
+
+    def close(self):
+        if self._h:
+            lib().wfk_iir_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

@@ -102,11 +102,48 @@ def call_vstack(w, x, function_lib=None):
         plan.close()
 
 
-def _sample_on_grid(w, grid, out, function_lib):
+def _sos_sections(sos):
+    sos = np.asarray(sos, dtype=np.float64).reshape(-1, 6)
+    return [(row[:3], row[3:]) for row in sos]
+
+
+def _sample_filtered(w, plan, sos, initial, zi):
+    """sampler -> SOS IIR cascade, both on the device; one download.
+    == sosfilt(sos, sig - initial, zi) + initial (reference waveform.py:193-203,244-251)."""
+    from .waveform import WaveVStack
+    if not isinstance(w, WaveVStack):
+        if _result_dtype(_live_pieces(plan, 0, w.seq)) is np.complex128:
+            raise NotImplementedError('IIR filters on a complex-valued waveform')
+    n = plan.n
+    iir = _engine.IirPlan(_sos_sections(sos), n, 1, np.float64)
+    D = iir.state_dim
+    buf = _engine.DeviceBuffer(max(n, 1) * 8)
+    dzi = _engine.DeviceBuffer(max(D, 1) * 8)
+    dzf = _engine.DeviceBuffer(max(D, 1) * 8)
+    try:
+        plan.launch(buf.ptr, n, _engine.OUT_F64)
+        dzi.upload(np.ascontiguousarray(np.zeros(D) if zi is None
+                                        else np.asarray(zi, dtype=np.float64).reshape(-1)))
+        iir.apply(buf.ptr, n, buf.ptr, n, dzi.ptr, dzf.ptr, initial or 0.0)   # in place
+        _engine.sync()
+        sig = buf.download((n, ), np.float64) if n else np.zeros(0)
+        zf = dzf.download((D, ), np.float64).reshape(-1, 2)
+    finally:
+        buf.close()
+        dzi.close()
+        dzf.close()
+        iir.close()
+    return sig, zf
+
+
+def _sample_on_grid(w, grid, out, function_lib, filters=None, zi=None):
     from .waveform import WaveVStack
     _check_function_lib(function_lib)
     plan = _engine.Plan(_flatten.flatten([w]), grid=grid)
     try:
+        if filters is not None:
+            sos, initial = filters
+            return _sample_filtered(w, plan, sos, initial, zi)
         if isinstance(w, WaveVStack):
             return plan.run_host(np.float64)[0]
         return _finish(w, plan, False, out, False)
@@ -123,21 +160,22 @@ def sample_waveform(w, sample_rate=None, out=None, chunk_size=None, function_lib
             f'Waveform is not initialized. {w.start=}, {w.stop=}, {sample_rate=}')
     if filters is None:
         filters = w.filters
-    if filters is not None:
-        raise NotImplementedError(
-            'SOS IIR filters in sample() are not implemented on the device yet '
-            '(SURVEY.md §8(f) N1); sample without filters')
     if chunk_size is None:
         grid = _flatten.grid_arange(w.start, w.stop, 1 / sample_rate)
+        if filters is not None:
+            # NB the reference passes out= to __call__ and then returns the FILTERED
+            # array, a new object (waveform.py:191-204)
+            return _sample_on_grid(w, grid, None, function_lib, filters)[0]
         return _sample_on_grid(w, grid, out, function_lib)
-    return _sample_iter(w, sample_rate, chunk_size, out, function_lib)
+    return _sample_iter(w, sample_rate, chunk_size, out, function_lib, filters)
 
 
-def _sample_iter(w, sample_rate, chunk_size, out, function_lib):
-    # chunk grid: np.linspace(start, stop, size, endpoint=False) per chunk
-    # (reference: waveforms/waveform.py:223-232, 256-257)
+def _sample_iter(w, sample_rate, chunk_size, out, function_lib, filters):
+    # chunk grid: np.linspace(start, stop, size, endpoint=False) per chunk; IIR state is
+    # carried from chunk to chunk (reference: waveforms/waveform.py:209-257)
     start, start_n = float(w.start), 0
     length = chunk_size / sample_rate
+    zi = None
     while start < w.stop:
         if start + length > w.stop:
             length = w.stop - start
@@ -147,8 +185,14 @@ def _sample_iter(w, sample_rate, chunk_size, out, function_lib):
             stop = start + length
             size = chunk_size
         grid = _flatten.grid_linspace(start, stop, size, endpoint=False)
-        yield _sample_on_grid(w, grid, None if out is None else out[start_n:],
-                              function_lib)
+        if filters is None:
+            yield _sample_on_grid(w, grid, None if out is None else out[start_n:],
+                                  function_lib)
+        else:
+            sig, zi = _sample_on_grid(w, grid, None, function_lib, filters, zi)
+            if out is not None:
+                out[start_n:start_n + size] = sig
+            yield sig
         start = stop
         start_n += chunk_size
 

@@ -1,0 +1,350 @@
+// wfk_iir.hip -- IIR stage: scipy.signal.sosfilt / lfilter semantics
+// applied along every row, as used by Waveform.sample(filters=(sos, initial))
+// (reference: waveforms/waveform.py:193-203, 244-251) and predistort(filters=...)
+// (waveforms/distortion.py:298-321).
+//
+// A filter is a cascade of direct-form-II-transposed sections (sosfilt: order-2 sections;
+// lfilter: one section of order max(len(a),len(b))-1), per sample and section:
+//     y = b0*x + z[0];   z[i] = b[i+1]*x - a[i+1]*y + z[i+1];   z[ord-1] = b[ord]*x - a[ord]*y
+// The recurrence is sequential in time; it is linear, so rows are cut into blocks of LB
+// samples and solved in three phases (state dimension D = sum of section orders <= 16):
+//   A  iir_pass<false>: every block from ZERO state -> its local final state f_b
+//   B  iir_scan       : S_b = T*S_{b-1} + f_b over the blocks of a row, one wave per row,
+//                       Hillis-Steele steps with the precomputed powers T^(2^k) and a
+//                       per-lane table T^(l+1) for the carry (T = LB-step transition matrix,
+//                       computed on the host by running the homogeneous system)
+//   C  iir_pass<true> : every block again from its true initial state S_{b-1}; writes y
+// HBM traffic 24 B/sample fp64 (x read twice, y written once) vs 16 algorithmic.
+// Lanes own blocks; a wave moves 64x64-sample tiles through LDS (transposed) so that
+// global loads/stores are 512-byte contiguous per instruction.  State is always double.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wfk.h"
+
+#define IIR_MAXD 16
+#define IIR_MAXSEC 8
+#define IIR_LB 2048   // block length (samples)
+#define IIR_SEG 64    // samples per LDS tile column
+
+extern "C" void wfk_internal_set_error(const char* msg);
+
+namespace {
+
+struct IirCoef {
+  int nsec;
+  int ord[IIR_MAXSEC];
+  int off[IIR_MAXSEC];          // state offset of each section
+  double b[IIR_MAXSEC][IIR_MAXD + 1];
+  double a[IIR_MAXSEC][IIR_MAXD + 1];
+  int D;
+};
+
+__host__ __device__ inline double iir_step(const IirCoef& c, double x, double* z) {
+  for (int s = 0; s < c.nsec; ++s) {
+    double* zs = z + c.off[s];
+    const int ord = c.ord[s];
+    const double y = c.b[s][0] * x + (ord > 0 ? zs[0] : 0.0);
+    for (int i = 0; i + 1 < ord; ++i) zs[i] = c.b[s][i + 1] * x - c.a[s][i + 1] * y + zs[i + 1];
+    if (ord > 0) zs[ord - 1] = c.b[s][ord] * x - c.a[s][ord] * y;
+    x = y;
+  }
+  return x;
+}
+
+// Compile-time shaped cascade (NSEC sections of order ORD each): every index is a
+// constant, so the state stays in registers.  NSEC == 0 selects the generic runtime-shaped
+// step (any mix of orders; state array then lives in scratch: correct, slower).
+template <int NSEC, int ORD>
+__device__ __forceinline__ double iir_step_t(const IirCoef& c, double x, double (&z)[IIR_MAXD]) {
+  if constexpr (NSEC == 0) {
+    return iir_step(c, x, z);
+  } else {
+#pragma unroll
+    for (int s = 0; s < NSEC; ++s) {
+      const double y = c.b[s][0] * x + z[s * ORD];
+#pragma unroll
+      for (int i = 0; i + 1 < ORD; ++i)
+        z[s * ORD + i] = c.b[s][i + 1] * x - c.a[s][i + 1] * y + z[s * ORD + i + 1];
+      z[s * ORD + ORD - 1] = c.b[s][ORD] * x - c.a[s][ORD] * y;
+      x = y;
+    }
+    return x;
+  }
+}
+
+// One wave per 64 consecutive blocks of one row.  WRITE=false: zero initial state, emit the
+// final state of each block.  WRITE=true: initial state from `init`, write y (+post).
+template <typename T, bool WRITE, int NSEC, int ORD>
+__global__ void __launch_bounds__(64) iir_pass(const IirCoef c, const T* __restrict__ in,
+                                               int64_t in_stride, T* __restrict__ out,
+                                               int64_t out_stride, double* __restrict__ state,
+                                               const double* __restrict__ init,
+                                               double* __restrict__ zf, int64_t n, int64_t nblk,
+                                               double pre_sub, double post_add) {
+  __shared__ T tile[64][IIR_SEG + 1];
+  const int lane = threadIdx.x;
+  const int64_t row = blockIdx.y;
+  const int64_t blk0 = (int64_t)blockIdx.x * 64;
+  const int64_t blk = blk0 + lane;
+  const T* x = in + row * in_stride;
+  T* y = WRITE ? out + row * out_stride : nullptr;
+  const int D = c.D;
+  double z[IIR_MAXD];
+#pragma unroll
+  for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
+  if (WRITE && blk < nblk) {
+    const double* s = init + (row * nblk + blk) * D;
+    for (int i = 0; i < D; ++i) z[i] = s[i];
+  }
+  const int nact = (int)(nblk - blk0 < 64 ? nblk - blk0 : 64);   // active blocks in this wave
+  for (int seg = 0; seg < IIR_LB / IIR_SEG; ++seg) {
+    // coalesced load of the 64 x 64 tile: row r of the tile = segment of block blk0+r
+    for (int r = 0; r < nact; ++r) {
+      const int64_t j = (blk0 + r) * IIR_LB + seg * IIR_SEG + lane;
+      tile[r][lane] = j < n ? x[j] : (T)0;
+    }
+    __syncthreads();
+    if (blk < nblk) {
+      const int64_t base = blk * IIR_LB + seg * IIR_SEG;
+      const int lim = (int)(n - base < IIR_SEG ? (n - base > 0 ? n - base : 0) : IIR_SEG);
+      for (int i = 0; i < lim; ++i) {
+        const double v = iir_step_t<NSEC, ORD>(c, (double)tile[lane][i] - pre_sub, z);
+        if (WRITE) tile[lane][i] = (T)(v + post_add);
+      }
+    }
+    __syncthreads();
+    if (WRITE) {
+      for (int r = 0; r < nact; ++r) {
+        const int64_t j = (blk0 + r) * IIR_LB + seg * IIR_SEG + lane;
+        if (j < n) y[j] = tile[r][lane];
+      }
+      __syncthreads();
+    }
+  }
+  if (blk < nblk) {
+    if (!WRITE) {
+      double* s = state + (row * nblk + blk) * D;
+      for (int i = 0; i < D; ++i) s[i] = z[i];
+    } else if (blk == nblk - 1 && zf) {
+      for (int i = 0; i < D; ++i) zf[row * D + i] = z[i];
+    }
+  }
+}
+
+// Phase B: in place, state[row][b] (local final states f_b) -> init[row][b] = S_{b-1}, the
+// true state at the START of block b.  pw: [7][D][D] = T^(2^k) (k=0..6; entry 6 = T^64),
+// lanep: [64][D][D] = T^(l+1).  zi: [row][D] or null.
+__global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const double* __restrict__ pw,
+                                               const double* __restrict__ lanep,
+                                               const double* __restrict__ zi, int64_t nblk, int D) {
+  const int lane = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  double carry[IIR_MAXD];   // S at the start of the current group (wave-uniform)
+  for (int i = 0; i < IIR_MAXD; ++i) carry[i] = (zi && i < D) ? zi[row * D + i] : 0.0;
+  for (int64_t g0 = 0; g0 < nblk; g0 += 64) {
+    const int64_t b = g0 + lane;
+    double v[IIR_MAXD];
+    for (int i = 0; i < IIR_MAXD; ++i) v[i] = 0.0;
+    if (b < nblk)
+      for (int i = 0; i < D; ++i) v[i] = state[(row * nblk + b) * D + i];
+    // inclusive scan: v_l = sum_{j<=l} T^(l-j) f_j
+    for (int k = 0; k < 6; ++k) {
+      const int d = 1 << k;
+      double u[IIR_MAXD];
+      for (int i = 0; i < IIR_MAXD; ++i) u[i] = i < D ? __shfl_up(v[i], d) : 0.0;
+      if (lane >= d) {
+        const double* M = pw + (int64_t)k * D * D;
+        for (int i = 0; i < D; ++i) {
+          double acc = v[i];
+          for (int j = 0; j < D; ++j) acc += M[i * D + j] * u[j];
+          v[i] = acc;
+        }
+      }
+    }
+    // S_b (state at END of block b) = v_l + T^(l+1) * carry
+    {
+      const double* M = lanep + (int64_t)lane * D * D;
+      for (int i = 0; i < D; ++i) {
+        double acc = v[i];
+        for (int j = 0; j < D; ++j) acc += M[i * D + j] * carry[j];
+        v[i] = acc;
+      }
+    }
+    // state at the START of block b = end state of block b-1 (lane 0: carry)
+    double st[IIR_MAXD];
+    for (int i = 0; i < IIR_MAXD; ++i) {
+      const double up = i < D ? __shfl_up(v[i], 1) : 0.0;
+      st[i] = lane == 0 ? carry[i] : up;
+    }
+    if (b < nblk)
+      for (int i = 0; i < D; ++i) state[(row * nblk + b) * D + i] = st[i];
+    for (int i = 0; i < IIR_MAXD; ++i) carry[i] = i < D ? __shfl(v[i], 63) : 0.0;
+  }
+}
+
+int iir_fail(int code, const std::string& m) {
+  wfk_internal_set_error(m.c_str());
+  return code;
+}
+
+void matmul(const std::vector<double>& A, const std::vector<double>& B, std::vector<double>& C, int D) {
+  std::vector<long double> t((size_t)D * D, 0.0L);
+  for (int i = 0; i < D; ++i)
+    for (int k = 0; k < D; ++k)
+      for (int j = 0; j < D; ++j) t[(size_t)i * D + j] += (long double)A[(size_t)i * D + k] * B[(size_t)k * D + j];
+  C.resize((size_t)D * D);
+  for (size_t i = 0; i < t.size(); ++i) C[i] = (double)t[i];
+}
+
+}  // namespace
+
+struct wfk_iir_plan {
+  IirCoef c;
+  int64_t n = 0, nblk = 0;
+  int32_t batch = 0, kind = 0;
+  double* state = nullptr;   // [batch][nblk][D]
+  double* pw = nullptr;      // [7][D][D]
+  double* lanep = nullptr;   // [64][D][D]
+};
+
+extern "C" {
+
+int wfk_iir_plan_destroy(wfk_iir_plan* p) {
+  if (!p) return WFK_OK;
+  (void)hipFree(p->state);
+  (void)hipFree(p->pw);
+  (void)hipFree(p->lanep);
+  delete p;
+  return WFK_OK;
+}
+
+int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double* b, const double* a,
+                        int64_t n, int32_t batch, int kind, wfk_iir_plan** out) {
+  if (!out) return iir_fail(WFK_EINVAL, "null out");
+  *out = nullptr;
+  if (n_sections < 1 || n_sections > IIR_MAXSEC || !orders || !b || !a || n < 0 || batch < 1 ||
+      batch > 65535)
+    return iir_fail(WFK_EINVAL, "bad IIR arguments");
+  if (kind != WFK_OUT_F64 && kind != WFK_OUT_F32) return iir_fail(WFK_EINVAL, "IIR kind must be F64 or F32");
+  wfk_iir_plan* p = new wfk_iir_plan();
+  IirCoef& c = p->c;
+  std::memset(&c, 0, sizeof c);
+  c.nsec = n_sections;
+  int D = 0, pos = 0;
+  for (int s = 0; s < n_sections; ++s) {
+    const int ord = orders[s];
+    if (ord < 0 || ord > IIR_MAXD || D + ord > IIR_MAXD) {
+      delete p;
+      return iir_fail(WFK_EINVAL, "IIR order too large (total state dimension <= 16)");
+    }
+    const double a0 = a[pos];
+    if (!(a0 != 0.0) || !std::isfinite(a0)) {
+      delete p;
+      return iir_fail(WFK_EINVAL, "a[0] must be finite and non-zero");
+    }
+    c.ord[s] = ord;
+    c.off[s] = D;
+    for (int i = 0; i <= ord; ++i) {   // scipy normalises by a[0]
+      c.b[s][i] = b[pos + i] / a0;
+      c.a[s][i] = a[pos + i] / a0;
+    }
+    pos += ord + 1;
+    D += ord;
+  }
+  c.D = D;
+  p->n = n; p->batch = batch; p->kind = kind;
+  p->nblk = n > 0 ? (n + IIR_LB - 1) / IIR_LB : 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    delete p;
+    return iir_fail(WFK_EHIP, "no HIP device visible");
+  }
+  if (n == 0 || D == 0) { *out = p; return WFK_OK; }
+  // LB-step transition matrix T: column i = homogeneous response to unit state e_i
+  std::vector<double> T((size_t)D * D);
+  for (int i = 0; i < D; ++i) {
+    double z[IIR_MAXD] = {0};
+    z[i] = 1.0;
+    for (int k = 0; k < IIR_LB; ++k) iir_step(c, 0.0, z);
+    for (int r = 0; r < D; ++r) T[(size_t)r * D + i] = z[r];
+  }
+  std::vector<double> pw((size_t)7 * D * D), lanep((size_t)64 * D * D), cur = T, nxt;
+  for (int k = 0; k < 7; ++k) {
+    std::copy(cur.begin(), cur.end(), pw.begin() + (size_t)k * D * D);
+    matmul(cur, cur, nxt, D);
+    cur = nxt;
+  }
+  cur = T;
+  for (int l = 0; l < 64; ++l) {
+    std::copy(cur.begin(), cur.end(), lanep.begin() + (size_t)l * D * D);
+    matmul(cur, T, nxt, D);
+    cur = nxt;
+  }
+  bool ok = hipMalloc(&p->state, (size_t)batch * p->nblk * D * 8) == hipSuccess;
+  ok = ok && hipMalloc(&p->pw, pw.size() * 8) == hipSuccess;
+  ok = ok && hipMalloc(&p->lanep, lanep.size() * 8) == hipSuccess;
+  ok = ok && hipMemcpy(p->pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(p->lanep, lanep.data(), lanep.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    wfk_iir_plan_destroy(p);
+    return iir_fail(WFK_ENOMEM, "IIR buffer allocation failed");
+  }
+  *out = p;
+  return WFK_OK;
+}
+
+int wfk_iir_state_dim(const wfk_iir_plan* p) { return p ? p->c.D : WFK_EINVAL; }
+
+}  // extern "C"
+
+template <typename T, int NSEC, int ORD>
+static void iir_launch_t(wfk_iir_plan* p, const void* in, int64_t is, void* out, int64_t os,
+                         const double* zi, double* zf, double initial, hipStream_t s) {
+  const dim3 g((unsigned)((p->nblk + 63) / 64), (unsigned)p->batch);
+  hipLaunchKernelGGL((iir_pass<T, false, NSEC, ORD>), g, dim3(64), 0, s, p->c, (const T*)in, is,
+                     (T*)nullptr, (int64_t)0, p->state, (const double*)nullptr, (double*)nullptr,
+                     p->n, p->nblk, initial, 0.0);
+  hipLaunchKernelGGL(iir_scan, dim3((unsigned)p->batch), dim3(64), 0, s, p->state, p->pw, p->lanep,
+                     zi, p->nblk, p->c.D);
+  hipLaunchKernelGGL((iir_pass<T, true, NSEC, ORD>), g, dim3(64), 0, s, p->c, (const T*)in, is,
+                     (T*)out, os, (double*)nullptr, p->state, zf, p->n, p->nblk, initial, initial);
+}
+
+template <typename T>
+static void iir_launch(wfk_iir_plan* p, const void* in, int64_t is, void* out, int64_t os,
+                       const double* zi, double* zf, double initial, hipStream_t s) {
+  const IirCoef& c = p->c;
+  bool uniform = true;
+  for (int k = 1; k < c.nsec; ++k) uniform = uniform && c.ord[k] == c.ord[0];
+  const int ns = c.nsec, od = c.ord[0];
+#define IIR_CASE(NS, OD) if (uniform && ns == NS && od == OD) return iir_launch_t<T, NS, OD>(p, in, is, out, os, zi, zf, initial, s)
+  IIR_CASE(1, 2); IIR_CASE(2, 2); IIR_CASE(3, 2); IIR_CASE(4, 2);      // sosfilt cascades
+  IIR_CASE(1, 1); IIR_CASE(1, 3); IIR_CASE(1, 4); IIR_CASE(1, 5); IIR_CASE(1, 6);  // lfilter
+#undef IIR_CASE
+  iir_launch_t<T, 0, 0>(p, in, is, out, os, zi, zf, initial, s);
+}
+
+extern "C" {
+
+int wfk_iir_apply(wfk_iir_plan* p, const void* in_dev, int64_t in_stride, void* out_dev,
+                  int64_t out_stride, const double* zi_dev, double* zf_dev, double initial,
+                  void* hip_stream) {
+  if (!p) return iir_fail(WFK_EINVAL, "null plan");
+  if (p->n == 0) return WFK_OK;
+  if (!in_dev || !out_dev) return iir_fail(WFK_EINVAL, "null buffer");
+  if (in_stride < p->n || out_stride < p->n) return iir_fail(WFK_EINVAL, "stride smaller than n");
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (p->c.D == 0) return iir_fail(WFK_EINVAL, "order-0 filter: use a scale instead");
+  if (p->kind == WFK_OUT_F32) iir_launch<float>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, s);
+  else iir_launch<double>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, s);
+  if (hipGetLastError() != hipSuccess) return iir_fail(WFK_EHIP, "IIR kernel launch failed");
+  return WFK_OK;
+}
+
+}  // extern "C"

@@ -1,12 +1,18 @@
-"""FIR stage of the hot path: `predistort(sig, ker=...)` on the GPU.
+"""Pre-distortion stages on the GPU: `predistort(sig, filters=..., ker=...)`.
 
 Signature and semantics follow the reference's `predistort`
-(waveforms/distortion.py:289-337).  Only the FIR branch (`ker=`) is on the device
-path this round: out[i] = sum_k ker[k] * sig[i + len(ker)//2 - k] with zero padding,
-what the reference computes with one giant `scipy.signal.fftconvolve`.  The IIR
-branch (`filters=`) is SURVEY.md §8(f) N1 and raises NotImplementedError.
+(waveforms/distortion.py:289-337):
+  * FIR branch (`ker=`): out[i] = sum_k ker[k] * sig[i + len(ker)//2 - k], zero padded --
+    what the reference computes with one giant `scipy.signal.fftconvolve`;
+  * IIR branch (`filters=`): the combined transfer function run as
+    `scipy.signal.lfilter(b, a, sig, zi=lfiltic(...))` -- here a
+    block-parallel linear-recurrence scan (csrc/wfk_iir.hip).
+Filter *design* (polynomial products, zpk conversions: O(order) host work, never per
+sample) uses NumPy/SciPy exactly as the reference does.
 """
 from __future__ import annotations
+
+import warnings
 
 import numpy as np
 
@@ -63,16 +69,116 @@ def fir_host(sig: np.ndarray, ker: np.ndarray) -> np.ndarray:
     return out.reshape(np.shape(sig))
 
 
+def combine_filters(filters):
+    """Product of the (b, a) transfer functions (reference: distortion.py:226-244)."""
+    b, a = np.poly1d([1.0]), np.poly1d([1.0])
+    for b_, a_ in filters:
+        b = b * np.poly1d(b_)
+        a = a * np.poly1d(a_)
+    return b.coeffs, a.coeffs
+
+
+def exp_decay_filter(amp, tau, sample_rate, inv=False, output='ba'):
+    """Multi-exponential step-response filter: u(t) -> u(t)(1 - sum A_i exp(-t/tau_i))
+    (reference: distortion.py:100-185).  Returns (b, a), sos or (z, p, k)."""
+    from scipy.signal import zpk2sos, zpk2tf
+    if isinstance(amp, (int, float, complex)):
+        amp, tau = [amp], [tau]
+    num, den = np.poly1d([0.0]), np.poly1d([1.0])
+    for i, (A, t) in enumerate(zip(amp, tau)):
+        den = den * np.poly1d([1, -1 / t])
+        term = np.poly1d([-A, 0.0])
+        for j, t_ in enumerate(tau):
+            if j != i:
+                term = term * np.poly1d([1, -1 / t_])
+        num = num + term
+    num = num + den
+    z = np.exp(-num.roots / sample_rate)
+    p = np.exp(-1 / (np.asarray(tau) * sample_rate))
+    if inv:
+        z, p = p, z
+    p = p[np.abs(p) < 1]
+    k = (np.prod(1 - p) / np.prod(1 - z)).real
+    if output == 'sos':
+        return zpk2sos(z, p, k)
+    if output == 'ba':
+        return zpk2tf(z, p, k)
+    if output == 'zpk':
+        return z, p, k
+    raise ValueError(f"Invalid output type: {output}")
+
+
+def iir_host(sig, sections, zi=None, initial=0.0, ker=None):
+    """NumPy in/out: upload, IIR scan (+ optional FIR) on the device, download.
+    Returns (y, zf) with zf the final filter state (scipy layout)."""
+    sig2 = np.ascontiguousarray(np.atleast_2d(sig), dtype=np.float64)
+    batch, n = sig2.shape
+    plan = _engine.IirPlan(sections, n, batch, np.float64)
+    D = plan.state_dim
+    bufs = []
+
+    def dev(nbytes):
+        b = _engine.DeviceBuffer(max(nbytes, 8))
+        bufs.append(b)
+        return b
+
+    fir = None
+    try:
+        x, y = dev(sig2.nbytes), dev(sig2.nbytes)
+        x.upload(sig2)
+        dzi = None
+        if zi is not None:
+            z = np.ascontiguousarray(np.broadcast_to(np.asarray(zi, dtype=np.float64).reshape(-1),
+                                                     (batch, D)))
+            dzi = dev(z.nbytes)
+            dzi.upload(z)
+        dzf = dev(batch * D * 8)
+        plan.apply(x.ptr, n, y.ptr, n, dzi.ptr if dzi else None, dzf.ptr, initial)
+        res = y
+        if ker is not None and n > 0:
+            fir = FirStage(ker, n, batch, np.float64)
+            fir.apply(y.ptr, n, x.ptr, n)
+            res = x
+        _engine.sync()
+        out = res.download(sig2.shape, np.float64) if n else sig2.copy()
+        zf = dzf.download((batch, D), np.float64) if n else np.zeros((batch, D))
+    finally:
+        for b in bufs:
+            b.close()
+        plan.close()
+        if fir is not None:
+            fir.close()
+    return out.reshape(np.shape(sig)), (zf[0] if np.ndim(sig) == 1 else zf)
+
+
 def predistort(sig, filters=None, ker=None, initial=0.0, initial_x=None,
                initial_y=None, zi=None, return_zf=False):
-    """reference: waveforms/distortion.py:289-337 (FIR branch on the GPU)."""
-    if filters is not None:
-        raise NotImplementedError(
-            'IIR pre-distortion (filters=) is not implemented on the device yet '
-            '(SURVEY.md §8(f) N1); only the FIR branch ker= is')
+    """reference: waveforms/distortion.py:289-337, both branches on the GPU."""
     sig = np.asarray(sig)
+    zf = None
+    if filters is not None:
+        from scipy.signal import lfiltic, tf2zpk
+        b, a = combine_filters(filters)
+        _, p, _ = tf2zpk(b, a)
+        if not np.all(np.abs(p) < 1):
+            warnings.warn('Warning: filter is unstable')
+        if zi is None:
+            ix = (np.full((len(b) - 1, ), initial) if initial_x is None else
+                  np.asarray(initial_x)[:len(b) - 1])
+            iy = (np.full((len(a) - 1, ), initial) if initial_y is None else
+                  np.asarray(initial_y)[:len(a) - 1])
+            zi = lfiltic(b, a, iy, ix)
+        sig, zf = iir_host(sig, [(b, a)], zi=zi, ker=ker)
+        return (sig, zf) if return_zf else sig
     if ker is None:
-        return sig
-    if return_zf:
-        raise NotImplementedError('return_zf requires the IIR branch')
-    return fir_host(sig, np.asarray(ker, dtype=np.float64))
+        return (sig, zf) if return_zf else sig
+    out = fir_host(sig, np.asarray(ker, dtype=np.float64))
+    return (out, zf) if return_zf else out
+
+
+def distort(points, params, sample_rate, initial=0.0):
+    """reference: waveforms/distortion.py:340-346."""
+    filters = []
+    for amp, tau in np.asarray(params).reshape(-1, 2):
+        filters.append(exp_decay_filter(amp, abs(tau), sample_rate))
+    return predistort(points, filters, initial=initial)
