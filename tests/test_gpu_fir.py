@@ -44,11 +44,9 @@ def test_fir_edge_semantics(fir_path):
         if n * k < 2e7:
             td = c_oracle.fir(sig, ker)
             assert np.max(np.abs(got - td)) <= 1e-12 * max(1.0, np.abs(td).max())
-    # ker=None passes the signal through; filters= is not on the device yet
+    # ker=None passes the signal through
     s = rng.normal(size=10)
     assert np.array_equal(distortion.predistort(s), s)
-    with pytest.raises(NotImplementedError):
-        distortion.predistort(s, filters=[([1.0], [1.0, -0.5])])
 
 
 def test_fir_batch_fp32_and_properties(fir_path):

@@ -16,6 +16,27 @@ pytestmark = pytest.mark.gpu
 IIR = golden_io.npz('iir.npz')
 
 
+def _lfilter_longdouble(b, a, x, initial):
+    """The lfilter recurrence (direct form II transposed, zi from lfiltic) in np.longdouble."""
+    ld = np.longdouble
+    zi = lfiltic(b, a, np.full(len(a) - 1, initial), np.full(len(b) - 1, initial))
+    m = max(len(a), len(b)) - 1
+    bb = np.zeros(m + 1, dtype=ld)
+    aa = np.zeros(m + 1, dtype=ld)
+    bb[:len(b)] = np.asarray(b, dtype=ld) / ld(a[0])
+    aa[:len(a)] = np.asarray(a, dtype=ld) / ld(a[0])
+    z = np.asarray(zi, dtype=ld).copy()
+    y = np.empty(len(x), dtype=ld)
+    for t in range(len(x)):
+        xx = ld(x[t])
+        yy = bb[0] * xx + z[0]
+        for j in range(m - 1):
+            z[j] = bb[j + 1] * xx - aa[j + 1] * yy + z[j + 1]
+        z[m - 1] = bb[m] * xx - aa[m] * yy
+        y[t] = yy
+    return y.astype(np.float64)
+
+
 def _configure(name):
     build, start, stop, rate, order, fc, initial = cases.iir_cases()[name]
     w = build(wf)
@@ -76,12 +97,25 @@ def test_predistort_filters(i):
     got, zf = distortion.predistort(sig, filters, ker=ker, initial=initial, return_zf=True)
     scale = max(1.0, np.abs(want).max())
     assert got.shape == want.shape
-    assert np.max(np.abs(got - want)) <= 1e-9 * scale
-    assert np.max(np.abs(zf - wzf)) <= 1e-9 * max(1.0, np.abs(wzf).max())
+    # Clustered poles (0.99995, 0.9989, 0.975 in case 2) make the direct-form filter
+    # ill-conditioned: the reference's own double-precision result is only good to
+    # `self_err` against an extended-precision evaluation of the same recurrence.  The
+    # bound is therefore 1e-9 * scale or a small multiple of that self error.
+    exact = _lfilter_longdouble(b, a, sig, initial)
+    ref_iir, _ = np_oracle.predistort(sig, filters, None, initial)
+    self_err = float(np.max(np.abs(ref_iir - exact)))
+    gain = float(np.abs(ker).sum()) if ker is not None else 1.0
+    tol = max(1e-9 * scale, 10 * self_err * gain)
+    assert np.max(np.abs(got - want)) <= tol, (np.max(np.abs(got - want)), tol)
+    assert np.max(np.abs(zf - wzf)) <= max(1e-9, 10 * self_err) * max(1.0, np.abs(wzf).max())
     ora, ozf = np_oracle.predistort(sig, filters, ker, initial)
-    assert np.max(np.abs(got - ora)) <= 1e-9 * scale
+    assert np.max(np.abs(got - ora)) <= tol
     d = distortion.distort(sig, np.asarray(params).reshape(-1), 1e9, initial)
-    assert np.max(np.abs(d - IIR[f'pd{i}.distort'])) <= 1e-9 * scale
+    assert np.max(np.abs(d - IIR[f'pd{i}.distort'])) <= max(1e-9 * scale, 10 * self_err)
+    # and the IIR stage alone stays within a small multiple of the reference's own
+    # distance from the extended-precision result
+    mine, _ = distortion.predistort(sig, filters, initial=initial, return_zf=True)
+    assert np.max(np.abs(mine - exact)) <= max(1e-10 * scale, 10 * self_err)
 
 
 def test_iir_batch_shapes_and_properties():

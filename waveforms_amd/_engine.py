@@ -128,8 +128,8 @@ class Plan:
         self.n_channels = int(info.n_channels)
 
     def close(self):
-        if self._h:
-            lib().wfk_plan_destroy(self._h)
+        if self._h and _lib is not None:
+            _lib.wfk_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -173,8 +173,8 @@ class FirPlan:
                                   stream))
 
     def close(self):
-        if self._h:
-            lib().wfk_fir_plan_destroy(self._h)
+        if self._h and _lib is not None:
+            _lib.wfk_fir_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -212,8 +212,8 @@ class IirPlan:
                                   zf_ptr, float(initial), stream))
 
     def close(self):
-        if self._h:
-            lib().wfk_iir_plan_destroy(self._h)
+        if self._h and _lib is not None:
+            _lib.wfk_iir_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -241,8 +241,8 @@ class DeviceBuffer:
         check(lib().wfk_memset(self.ptr, 0, self.nbytes))
 
     def close(self):
-        if getattr(self, 'ptr', None):
-            lib().wfk_free(self.ptr)
+        if getattr(self, 'ptr', None) and _lib is not None:
+            _lib.wfk_free(self.ptr)
             self.ptr = None
 
     __del__ = close

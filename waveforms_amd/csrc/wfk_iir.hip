@@ -136,9 +136,22 @@ __global__ void __launch_bounds__(64) iir_pass(const IirCoef c, const T* __restr
   }
 }
 
+// (sh + sl) += (th + tl) * x in double-double (TwoProd via fma, TwoSum)
+__device__ __forceinline__ void dd_acc(double& sh, double& sl, double th, double tl, double x) {
+  const double p = th * x;
+  const double e = fma(th, x, -p) + tl * x;
+  const double s = sh + p;
+  const double bb = s - sh;
+  sl += ((sh - (s - bb)) + (p - bb)) + e;
+  sh = s;
+}
+
 // Phase B: in place, state[row][b] (local final states f_b) -> init[row][b] = S_{b-1}, the
-// true state at the START of block b.  pw: [7][D][D] = T^(2^k) (k=0..6; entry 6 = T^64),
-// lanep: [64][D][D] = T^(l+1).  zi: [row][D] or null.
+// true state at the START of block b.  pw: [7][D][D][2] = T^(2^k) as (hi, lo) pairs,
+// lanep: [64][D][D][2] = T^(l+1).  zi: [row][D] or null.
+// T has entries ~1e5 that cancel against each other when applied to a state (see the host
+// note): the mat-vecs therefore run in double-double, so a block boundary perturbs the
+// state no more than one step of the sequential filter does.
 __global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const double* __restrict__ pw,
                                                const double* __restrict__ lanep,
                                                const double* __restrict__ zi, int64_t nblk, int D) {
@@ -158,22 +171,26 @@ __global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const
       double u[IIR_MAXD];
       for (int i = 0; i < IIR_MAXD; ++i) u[i] = i < D ? __shfl_up(v[i], d) : 0.0;
       if (lane >= d) {
-        const double* M = pw + (int64_t)k * D * D;
+        const double* M = pw + (int64_t)k * D * D * 2;
+        double nv[IIR_MAXD];
         for (int i = 0; i < D; ++i) {
-          double acc = v[i];
-          for (int j = 0; j < D; ++j) acc += M[i * D + j] * u[j];
-          v[i] = acc;
+          double sh = v[i], sl = 0.0;
+          for (int j = 0; j < D; ++j) dd_acc(sh, sl, M[(i * D + j) * 2], M[(i * D + j) * 2 + 1], u[j]);
+          nv[i] = sh + sl;
         }
+        for (int i = 0; i < D; ++i) v[i] = nv[i];
       }
     }
     // S_b (state at END of block b) = v_l + T^(l+1) * carry
     {
-      const double* M = lanep + (int64_t)lane * D * D;
+      const double* M = lanep + (int64_t)lane * D * D * 2;
+      double nv[IIR_MAXD];
       for (int i = 0; i < D; ++i) {
-        double acc = v[i];
-        for (int j = 0; j < D; ++j) acc += M[i * D + j] * carry[j];
-        v[i] = acc;
+        double sh = v[i], sl = 0.0;
+        for (int j = 0; j < D; ++j) dd_acc(sh, sl, M[(i * D + j) * 2], M[(i * D + j) * 2 + 1], carry[j]);
+        nv[i] = sh + sl;
       }
+      for (int i = 0; i < D; ++i) v[i] = nv[i];
     }
     // state at the START of block b = end state of block b-1 (lane 0: carry)
     double st[IIR_MAXD];
@@ -192,13 +209,30 @@ int iir_fail(int code, const std::string& m) {
   return code;
 }
 
-void matmul(const std::vector<double>& A, const std::vector<double>& B, std::vector<double>& C, int D) {
-  std::vector<long double> t((size_t)D * D, 0.0L);
+// Host-side transition matrices in quad precision.  In direct-form coordinates T is wildly
+// non-normal for clustered poles (entries ~1e5 while every eigenvalue is < 1): a T computed
+// by a double-precision recurrence is off by ~1e-9 relative, which the scan would amplify
+// into 1e-6 output errors.  Computed in __float128 and rounded once, T*S is as accurate as
+// the sequential filter itself.
+typedef __float128 quad;
+
+void quad_step(const IirCoef& c, quad x, quad* z) {
+  for (int s = 0; s < c.nsec; ++s) {
+    quad* zs = z + c.off[s];
+    const int ord = c.ord[s];
+    const quad y = (quad)c.b[s][0] * x + (ord > 0 ? zs[0] : (quad)0);
+    for (int i = 0; i + 1 < ord; ++i)
+      zs[i] = (quad)c.b[s][i + 1] * x - (quad)c.a[s][i + 1] * y + zs[i + 1];
+    if (ord > 0) zs[ord - 1] = (quad)c.b[s][ord] * x - (quad)c.a[s][ord] * y;
+    x = y;
+  }
+}
+
+void qmatmul(const std::vector<quad>& A, const std::vector<quad>& B, std::vector<quad>& C, int D) {
+  C.assign((size_t)D * D, (quad)0);
   for (int i = 0; i < D; ++i)
     for (int k = 0; k < D; ++k)
-      for (int j = 0; j < D; ++j) t[(size_t)i * D + j] += (long double)A[(size_t)i * D + k] * B[(size_t)k * D + j];
-  C.resize((size_t)D * D);
-  for (size_t i = 0; i < t.size(); ++i) C[i] = (double)t[i];
+      for (int j = 0; j < D; ++j) C[(size_t)i * D + j] += A[(size_t)i * D + k] * B[(size_t)k * D + j];
 }
 
 }  // namespace
@@ -267,23 +301,30 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
   }
   if (n == 0 || D == 0) { *out = p; return WFK_OK; }
   // LB-step transition matrix T: column i = homogeneous response to unit state e_i
-  std::vector<double> T((size_t)D * D);
+  std::vector<quad> T((size_t)D * D);
   for (int i = 0; i < D; ++i) {
-    double z[IIR_MAXD] = {0};
-    z[i] = 1.0;
-    for (int k = 0; k < IIR_LB; ++k) iir_step(c, 0.0, z);
+    quad z[IIR_MAXD];
+    for (int r = 0; r < IIR_MAXD; ++r) z[r] = 0;
+    z[i] = 1;
+    for (int k = 0; k < IIR_LB; ++k) quad_step(c, (quad)0, z);
     for (int r = 0; r < D; ++r) T[(size_t)r * D + i] = z[r];
   }
-  std::vector<double> pw((size_t)7 * D * D), lanep((size_t)64 * D * D), cur = T, nxt;
+  std::vector<double> pw((size_t)7 * D * D * 2), lanep((size_t)64 * D * D * 2);
+  auto put = [](std::vector<double>& dst, size_t at, quad q) {   // quad -> (hi, lo)
+    const double hi = (double)q;
+    dst[at] = hi;
+    dst[at + 1] = (double)(q - (quad)hi);
+  };
+  std::vector<quad> cur = T, nxt;
   for (int k = 0; k < 7; ++k) {
-    std::copy(cur.begin(), cur.end(), pw.begin() + (size_t)k * D * D);
-    matmul(cur, cur, nxt, D);
+    for (size_t e = 0; e < cur.size(); ++e) put(pw, ((size_t)k * D * D + e) * 2, cur[e]);
+    qmatmul(cur, cur, nxt, D);
     cur = nxt;
   }
   cur = T;
   for (int l = 0; l < 64; ++l) {
-    std::copy(cur.begin(), cur.end(), lanep.begin() + (size_t)l * D * D);
-    matmul(cur, T, nxt, D);
+    for (size_t e = 0; e < cur.size(); ++e) put(lanep, ((size_t)l * D * D + e) * 2, cur[e]);
+    qmatmul(cur, T, nxt, D);
     cur = nxt;
   }
   bool ok = hipMalloc(&p->state, (size_t)batch * p->nblk * D * 8) == hipSuccess;
