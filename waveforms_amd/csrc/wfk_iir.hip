@@ -29,7 +29,7 @@
 #define IIR_MAXD 16
 #define IIR_MAXSEC 8
 #define IIR_LB 2048   // block length (samples)
-#define IIR_SEG 64    // samples per LDS tile column
+#define IIR_SEG 16    // samples per block per LDS tile (64 blocks x 16 samples = 8.7 KB)
 
 extern "C" void wfk_internal_set_error(const char* msg);
 
@@ -102,26 +102,40 @@ __global__ void __launch_bounds__(64) iir_pass(const IirCoef c, const T* __restr
     for (int i = 0; i < D; ++i) z[i] = s[i];
   }
   const int nact = (int)(nblk - blk0 < 64 ? nblk - blk0 : 64);   // active blocks in this wave
+  constexpr int RPI = 64 / IIR_SEG;      // tile rows (blocks) moved per wave instruction
+  const int rsub = lane / IIR_SEG, col = lane % IIR_SEG;
   for (int seg = 0; seg < IIR_LB / IIR_SEG; ++seg) {
-    // coalesced load of the 64 x 64 tile: row r of the tile = segment of block blk0+r
-    for (int r = 0; r < nact; ++r) {
-      const int64_t j = (blk0 + r) * IIR_LB + seg * IIR_SEG + lane;
-      tile[r][lane] = j < n ? x[j] : (T)0;
+    // load the 64 x SEG tile: each instruction moves RPI rows of SEG contiguous samples
+#pragma unroll 4
+    for (int r0 = 0; r0 < 64; r0 += RPI) {
+      const int r = r0 + rsub;
+      const int64_t j = (blk0 + r) * IIR_LB + seg * IIR_SEG + col;
+      tile[r][col] = (r < nact && j < n) ? x[j] : (T)0;
     }
     __syncthreads();
     if (blk < nblk) {
       const int64_t base = blk * IIR_LB + seg * IIR_SEG;
       const int lim = (int)(n - base < IIR_SEG ? (n - base > 0 ? n - base : 0) : IIR_SEG);
-      for (int i = 0; i < lim; ++i) {
-        const double v = iir_step_t<NSEC, ORD>(c, (double)tile[lane][i] - pre_sub, z);
-        if (WRITE) tile[lane][i] = (T)(v + post_add);
+      if (lim == IIR_SEG) {
+#pragma unroll
+        for (int i = 0; i < IIR_SEG; ++i) {
+          const double v = iir_step_t<NSEC, ORD>(c, (double)tile[lane][i] - pre_sub, z);
+          if (WRITE) tile[lane][i] = (T)(v + post_add);
+        }
+      } else {
+        for (int i = 0; i < lim; ++i) {
+          const double v = iir_step_t<NSEC, ORD>(c, (double)tile[lane][i] - pre_sub, z);
+          if (WRITE) tile[lane][i] = (T)(v + post_add);
+        }
       }
     }
     __syncthreads();
     if (WRITE) {
-      for (int r = 0; r < nact; ++r) {
-        const int64_t j = (blk0 + r) * IIR_LB + seg * IIR_SEG + lane;
-        if (j < n) y[j] = tile[r][lane];
+#pragma unroll 4
+      for (int r0 = 0; r0 < 64; r0 += RPI) {
+        const int r = r0 + rsub;
+        const int64_t j = (blk0 + r) * IIR_LB + seg * IIR_SEG + col;
+        if (r < nact && j < n) y[j] = tile[r][col];
       }
       __syncthreads();
     }
