@@ -80,6 +80,8 @@ def main():
     ap.add_argument('--channels', type=int, default=None)
     ap.add_argument('--points', type=float, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=['f64', 'f32'], default=None,
+                    help='override the output dtype of the workload')
     args = ap.parse_args()
 
     import torch
@@ -102,6 +104,8 @@ def main():
     channels = args.channels or (1 if name == 'c2' else 256)
     points = int(args.points or (10**6 if name == 'c3' else 10**7))
     make_channel, grid, dtype, desc = workload(name, channels, points)
+    if args.dtype:
+        dtype = np.float64 if args.dtype == 'f64' else np.float32
     # weak scaling: every rank owns a block of `channels` channels of the global job
     sh = ShardedSampler(channels * world, make_channel, grid, rank, world)
     bs = sh.local
