@@ -9,6 +9,7 @@ Workloads (SURVEY.md §8(d) / BASELINE.json configs):
   sampler256 (default)  256 channels x 1e7 points, 100 gaussian+DRAG pulses per
                         channel (the C4/C5 channel spec), fp64, grid mode
   c2                    1 channel x 100 pulses x 1e7 points, fp64
+  c2_duty30 / c2_drag   C2 variants: 30 % duty cycle / built from the DRAG primitive
   c3                    256 WaveVStack channels x 20 pulses x 1e6 points, fp32
   c4                    sampler256 followed by the 1024-tap FIR stage
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); channels are
@@ -42,6 +43,12 @@ def workload(name, channels, points):
     if name == 'c2':
         return (lambda c: wl.c2_channel(wf)), wl.c2_grid(points), np.float64, (
             f'C2: 1 ch x 100 gaussian+DRAG pulses x {points:.0e} pts')
+    if name == 'c2_duty30':
+        return (lambda c: wl.c2_channel(wf, True)), wl.c2_grid(points, True), np.float64, (
+            f'C2 30 % duty: 1 ch x 100 pulses spaced 100 ns x {points:.0e} pts')
+    if name == 'c2_drag':
+        return (lambda c: wl.c2_drag_channel(wf)), wl.c2_grid(points), np.float64, (
+            f'C2 drag() primitive variant: 1 ch x 100 DRAG (type 13) pulses x {points:.0e} pts')
     if name == 'c3':
         return (lambda c: wl.vstack_channel(wf, 20, 100 + c)), wl.c3_grid(points), np.float32, (
             f'C3: {channels} WaveVStack ch/GPU x 20 pulses x {points:.0e} pts')
@@ -101,7 +108,7 @@ def main():
     _engine.set_device(local_rank)
 
     name = args.workload
-    channels = args.channels or (1 if name == 'c2' else 256)
+    channels = args.channels or (1 if name.startswith('c2') else 256)
     points = int(args.points or (10**6 if name == 'c3' else 10**7))
     make_channel, grid, dtype, desc = workload(name, channels, points)
     if args.dtype:

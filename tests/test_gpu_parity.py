@@ -253,7 +253,8 @@ def test_grid_formula_bit_exact_on_device(monkeypatch):
 
 @pytest.mark.parametrize('name', ['readme_x', 'c2_small', 'c3_small', 'mix_block',
                                   'tiny_pieces', 'exp_real', 'deriv2', 'vstack_ops',
-                                  'coarse_gauss_rec', 'trig3', 'pow3_term'])
+                                  'coarse_gauss_rec', 'trig3', 'pow3_term', 'drag_block',
+                                  'drag_plateau', 'drag_plain'])
 def test_three_evaluation_tiers_agree(name, monkeypatch):
     """fused carrier-envelope ops == per-factor fast paths == device libm."""
     build, grid = cases.CASES[name]
@@ -265,7 +266,8 @@ def test_three_evaluation_tiers_agree(name, monkeypatch):
     monkeypatch.setenv('WFK_DISABLE_FUSE', '1')
     perfac = _engine.Plan(prog, grid=g)
     assert perfac.info.n_fused == 0
-    assert perfac.info.n_fast > 0 or name == 'pow3_term'
+    assert perfac.info.n_fast > 0 or name in ('pow3_term', 'drag_block', 'drag_plateau',
+                                               'drag_plain')
     b = perfac.run_host(np.float64)[0]
     b32 = perfac.run_host(np.float32)[0]
     monkeypatch.setenv('WFK_DISABLE_FAST', '1')

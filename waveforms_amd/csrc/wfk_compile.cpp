@@ -127,6 +127,21 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   const bool nofast = nofast_env && nofast_env[0] == '1';
 
   // ---- validate structure ----------------------------------------------------
+  auto offsets_ok = [](const auto* off, int64_t count, int64_t total) {
+    if (off[0] != 0 || off[count] != total) return false;
+    for (int64_t i = 0; i < count; ++i)
+      if (off[i] > off[i + 1]) return false;
+    return true;
+  };
+  if (P->n_pieces < 0 || P->n_terms < 0 || P->n_factors < 0 || P->n_pool < 0 ||
+      !offsets_ok(P->ch_member_off, P->n_channels, P->n_members) ||
+      !offsets_ok(P->mb_piece_off, P->n_members, P->n_pieces) ||
+      !offsets_ok(P->pc_term_off, P->n_pieces, P->n_terms) ||
+      !offsets_ok(P->tm_factor_off, P->n_terms, P->n_factors) ||
+      !offsets_ok(P->fc_arg_off, P->n_factors, P->n_pool)) {
+    err = "offset arrays must start at 0, be non-decreasing and end at the element counts";
+    return WFK_EINVAL;
+  }
   for (int32_t c = 0; c < P->n_channels; ++c) {
     if (P->ch_member_off[c] > P->ch_member_off[c + 1]) { err = "ch_member_off not monotone"; return WFK_EINVAL; }
     if (std::isnan(P->ch_clip_lo[c]) || std::isnan(P->ch_clip_hi[c])) { err = "NaN clip"; return WFK_EINVAL; }
@@ -291,7 +306,24 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     int p = 0, ncos = 0;
     bool has_lin = false, has_env = false, env32 = false;
     double slin = 0, sigma = 0, sg = 0;
-    double cw[3], cs[3];
+    double first_cos_shift = 0;
+    struct Car { long double c, W, Psi; };   // c * cos(W t' - Psi),  t' = t - tshift
+    const long double PI = 3.141592653589793238462643383279502884L;
+    std::vector<Car> cars;                   // empty: no carrier factor seen yet
+    // multiply the running carrier sum by another sum of carriers:
+    //   cos a cos b = (cos(a+b) + cos(a-b)) / 2
+    auto times = [&](const std::vector<Car>& f) -> bool {
+      if (cars.empty()) { cars = f; return true; }
+      if (cars.size() * f.size() * 2 > 32) return false;
+      std::vector<Car> nx;
+      for (const Car& q : cars)
+        for (const Car& r : f) {
+          nx.push_back({q.c * r.c / 2, q.W + r.W, q.Psi + r.Psi});
+          nx.push_back({q.c * r.c / 2, q.W - r.W, q.Psi - r.Psi});
+        }
+      cars.swap(nx);
+      return true;
+    };
     for (int32_t f = f0; f < f1; ++f) {
       const double pw = P->fc_power[f], sh = P->fc_shift[f];
       const double* a = P->pool + P->fc_arg_off[f];
@@ -310,41 +342,47 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           break;
         }
         case WFK_COS:
-          if (pw != 1.0 || ncos == 3 || !std::isfinite(a[0]) || !std::isfinite(sh)) return false;
-          cw[ncos] = a[0]; cs[ncos] = sh; ++ncos;
+          if (pw != 1.0 || !std::isfinite(a[0]) || !std::isfinite(sh)) return false;
+          if (ncos == 0) first_cos_shift = sh;
+          ++ncos;
+          if (!times({{1.0L, (long double)a[0], (long double)a[0] * sh}})) return false;
           break;
+        case WFK_DRAG: {
+          // sin^2(o tau) cos(wt) + Oy sin(wt),  tau = u - t0,  Oy = -b o sin(2 o tau)
+          //   = cos(wt)/2 + (-1/4 + b o/2) cos(wt + 2 o tau) + (-1/4 - b o/2) cos(wt - 2 o tau)
+          // (reference: _waveform.pyx:343-356): three plain carriers, no libm per sample
+          const double t0 = a[0], freq = a[1], width = a[2], delta = a[3], bf = a[4], phase = a[5];
+          if (pw != 1.0 || !(width != 0.0) || !std::isfinite(sh)) return false;
+          for (int i = 0; i < 6; ++i)
+            if (i != 4 && !std::isfinite(a[i])) return false;
+          const long double o = PI / width;
+          const long double W = 2 * PI * ((long double)freq + delta);
+          const long double Psi0 = W * sh + (2 * PI * (long double)delta * t0 + phase);
+          const long double Om = 2 * o, Psi1 = Om * ((long double)sh + t0);
+          long double bo = 0.0L;
+          if (!std::isnan(bf) && bf - delta != 0.0) bo = o / (2 * PI * ((long double)bf - delta));
+          ncos += 2;   // reference shift is derived from Psi/W
+          if (!times({{0.5L, W, Psi0},
+                      {-0.25L + bo / 2, W + Om, Psi0 + Psi1},
+                      {-0.25L - bo / 2, W - Om, Psi0 - Psi1}}))
+            return false;
+          break;
+        }
         default:
           return false;
       }
     }
     if (p > 3 || !std::isfinite(P->tm_amp_re[k])) return false;
-    // product of cosines -> sum of single carriers:  cos a cos b = (cos(a+b) + cos(a-b)) / 2
-    struct Car { long double c, W, Psi; };   // c * cos(W t' - Psi)
-    std::vector<Car> cars;
-    if (ncos == 0) {
-      cars.push_back({(long double)P->tm_amp_re[k], 0.0L, 0.0L});
-    } else {
-      cars.push_back({(long double)P->tm_amp_re[k], (long double)cw[0],
-                      (long double)cw[0] * cs[0]});
-      for (int i = 1; i < ncos; ++i) {
-        std::vector<Car> nx;
-        const long double w = cw[i], ps = (long double)cw[i] * cs[i];
-        for (const Car& q : cars) {
-          nx.push_back({q.c / 2, q.W + w, q.Psi + ps});
-          nx.push_back({q.c / 2, q.W - w, q.Psi - ps});
-        }
-        cars.swap(nx);
-      }
-    }
+    if (cars.empty()) cars.push_back({1.0L, 0.0L, 0.0L});
+    for (Car& q : cars) q.c *= (long double)P->tm_amp_re[k];
+    const double cs[1] = {first_cos_shift};
     // stage the contributions; commit only if every carrier finds/creates a group
     std::vector<FceGroup> staged = groups;
     for (Car q : cars) {
       if (q.W < 0) { q.W = -q.W; q.Psi = -q.Psi; }
       const double W = (double)q.W;
-      if ((long double)W != q.W && ncos > 1) {
-        // sum/difference frequency not exactly representable: keep its rounded value
-        // (relative error <= 2^-53, i.e. the same class as the reference's own w*t rounding)
-      }
+      // (a sum/difference frequency is rounded to double: relative error <= 2^-53, the
+      //  same class as the reference's own rounding of w*t)
       FceGroup* G = nullptr;
       for (FceGroup& g : staged)
         if (g.W == W && g.has_env == has_env && (!has_env || (g.sigma == sigma && g.sg == sg))) { G = &g; break; }

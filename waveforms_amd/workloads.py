@@ -76,6 +76,26 @@ def c2_grid(n=10**7, duty30: bool = False):
     return ('linspace', 0.0, 100 * span, n, False)
 
 
+def c2_drag_channel(ns):
+    """C2 variant built from the DRAG primitive (type 13, reference waveform.py:1347-1379):
+    100 contiguous `drag()` pulses with random carrier, detuning, notch and phase."""
+    rng = np.random.default_rng(0)
+    width = SPAN
+    ws = []
+    for k in range(100):
+        A = rng.uniform(0.1, 1)
+        f = rng.uniform(-200e6, 200e6)
+        phi = rng.uniform(0, 2 * np.pi)
+        ws.append(A * ns.drag(f, width, delta=rng.uniform(-5e6, 5e6),
+                              block_freq=f - 250e6, phase=phi, t0=k * width))
+    while len(ws) > 1:
+        nxt = [ws[i] + ws[i + 1] for i in range(0, len(ws) - 1, 2)]
+        if len(ws) % 2:
+            nxt.append(ws[-1])
+        ws = nxt
+    return ws[0]
+
+
 def c3_channels(ns, nch=256):
     return [vstack_channel(ns, 20, 100 + c) for c in range(nch)]
 
