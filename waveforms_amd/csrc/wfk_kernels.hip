@@ -333,13 +333,23 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
   const S q = (S)r[WFK_FCE_Q];
   T u = (T)u0;
   const T Dt = (T)D;
+  // phasor table entries are wave-wide LDS broadcasts; batch kb+1 is fetched while batch
+  // kb computes (one batch of look-ahead: 16 more registers instead of an lgkmcnt stall
+  // at the head of every sub-batch)
+  double2 tb[2][SB];
+  if (CARRIER) {
+    WFK_EACH(SB, kk) tb[0][kk] = tab[kk]; WFK_END
+  }
   WFK_EACH(NS / SB, kb)
+    if constexpr (CARRIER && (kb + 1) * SB < NS) {
+      WFK_EACH(SB, kk) tb[(kb + 1) & 1][kk] = tab[(kb + 1) * SB + kk]; WFK_END
+    }
     WFK_EACH(SB, kk)
       constexpr int k = kb * SB + kk;
       T val;
       if (DEG == 0) {
         if (CARRIER) {
-          const double2 cs = tab[k];
+          const double2 cs = tb[kb & 1][kk];
           val = ac * (T)cs.x - as * (T)cs.y;
         } else {
           val = A0;
@@ -355,7 +365,7 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
         }
         u += Dt;
         if (CARRIER) {
-          const double2 cs = tab[k];
+          const double2 cs = tb[kb & 1][kk];
           const T ck = c0 * (T)cs.x - s0 * (T)cs.y;
           const T sk = s0 * (T)cs.x + c0 * (T)cs.y;
           val = pa * ck + pb * sk;
