@@ -52,12 +52,17 @@ extern "C" {
  *  13 DRAG              (t0, freq, width, delta, block_freq|NaN=None, phase)        pyx:343-356
  *  14 MOLLIFIER         (r, d)                  pyx:359-371
  *  15 D_GAUSSIAN        (std_sq2, n)            pyx:298-300
+ *  16 DRAG_SIN / 17 DRAG_SINX  multi-notch DRAG (waveforms/multy_drag.py:158-213), args in
+ *     COMPILED form (the per-pulse matrices folded into coefficient tables on the host,
+ *     waveforms_amd/multy_drag.py:device_args):
+ *       (t0, freq, width, delta, phase, plateau, tab_half_width, m, dq,
+ *        Px[0..m], Py[0..m], Cx, Cy [, QLx, QLy, QRx, QRy (dq+1 each, highest power first)])
  * Any other id -> WFK_EUNSUP (Python callables cannot run on the device).      */
 enum {
   WFK_LINEAR = 1, WFK_GAUSSIAN = 2, WFK_ERF = 3, WFK_COS = 4, WFK_SINC = 5,
   WFK_EXP = 6, WFK_INTERP = 7, WFK_LINEARCHIRP = 8, WFK_EXPONENTIALCHIRP = 9,
   WFK_HYPERBOLICCHIRP = 10, WFK_COSH = 11, WFK_SINH = 12, WFK_DRAG = 13,
-  WFK_MOLLIFIER = 14, WFK_D_GAUSSIAN = 15
+  WFK_MOLLIFIER = 14, WFK_D_GAUSSIAN = 15, WFK_DRAG_SIN = 16, WFK_DRAG_SINX = 17
 };
 
 /*

@@ -169,3 +169,92 @@ def predistort(sig, filters=None, ker=None, initial=0.0, zi=None):
     if ker is not None:
         sig = predistort_fir(sig, ker)
     return sig, zf
+
+
+# ---- multi-notch DRAG primitives, ids 16/17 (reference: waveforms/multy_drag.py) ----
+def _md_setup(width, delta, block_freq):
+    bs = []
+    if isinstance(block_freq, float):
+        block_freq = (block_freq, )
+    if block_freq is not None:
+        bs = list(1 / np.pi / 2 / (np.array(block_freq) - delta))
+    m = max((len(bs) + 2) >> 1 << 1, 2)
+    # B[n] = sum over n-subsets of prod(b) * J^n, J = [[0, 1], [-1, 0]]
+    B = np.zeros((len(bs) + 1, 2, 2))
+    B[0] = np.eye(2)
+    for b in bs:
+        B[1:] = B[1:] + B[:-1] @ np.array([[0, b], [-b, 0]])
+    o = np.pi / width
+    A = np.zeros((len(bs) + 1, m + 1))      # derivatives of sin^m in the (s^p, s^p c) basis
+    A[0, m] = 1
+    for i in range(1, len(bs) + 1):
+        if i % 2:
+            A[i][:-1] = A[i - 1][1:] * np.arange(1, m + 1) * o
+        else:
+            A[i][:-2] = A[i - 2][2:] * np.arange(1, m) * np.arange(2, m + 1)
+            A[i] = (A[i] - A[i - 2] * np.arange(m + 1)**2) * o**2
+    return bs, m, B, o, A
+
+
+def _md_envelope(t, t0, width, plateau, m, o, A):
+    rise, fall = t <= t0 + width / 2, t >= t0 + plateau + width / 2
+    mid = (t > t0 + width / 2) * (t < t0 + plateau + width / 2)
+    tau = np.where(fall, t - t0 - plateau, t - t0)
+    s = np.where(mid, 0.0, np.sin(o * tau))
+    c = np.where(mid, 0.0, np.cos(o * tau))
+    basis = s**np.arange(m + 1).reshape(-1, 1)
+    basis[1::2] = basis[1::2] * c
+    d = A @ basis                            # d[n] = n-th derivative of the envelope
+    d[0][mid] = 1
+    return d, mid
+
+
+def _md_crest(m, A, B):
+    top = np.ones(m + 1)
+    top[1::2] = 0
+    top = A @ top
+    return np.sqrt(np.sum(np.abs(np.einsum('ijk,ki->j', B, np.array([top, 0 * top])))**2))
+
+
+def _md_tab_poly(f, x):
+    import math
+    M = len(f)
+    rhs = np.copy(f)
+    rhs[0] -= 1
+    C = np.array([[x**(M + l - n) * math.factorial(M + l) / math.factorial(M + l - n)
+                   for l in range(M)] for n in range(M)])
+    from scipy.linalg import inv
+    return np.poly1d([*np.flip(inv(C) @ rhs), *np.zeros(M - 1), 1])
+
+
+def _drag_sin(t, t0, freq, width, delta, block_freq, phase, plateau=0):
+    bs, m, B, o, A = _md_setup(width, delta, block_freq)
+    d, _ = _md_envelope(t, t0, width, plateau, m, o, A)
+    om = np.einsum('ijk,kim->jm', B, np.array([d, 0 * d])) / _md_crest(m, A, B)
+    wt = 2 * np.pi * (freq + delta) * t - (2 * np.pi * delta * t0 + phase)
+    return om[0] * np.cos(wt) + om[1] * np.sin(wt)
+
+
+def _drag_sinx(t, t0, freq, width, delta, block_freq, phase, plateau=0, tab=0.618):
+    bs, m, B, o, A = _md_setup(width, delta, block_freq)
+    d, _ = _md_envelope(t, t0, width, plateau, m, o, A)
+
+    def at(x):
+        v = np.sin(o * x)**np.arange(m + 1)
+        v[1::2] = v[1::2] * np.cos(o * x)
+        return A @ v
+
+    left = _md_tab_poly(at((1 - tab) * width / 2), -tab * width / 2)
+    right = _md_tab_poly(at((1 + tab) * width / 2), tab * width / 2)
+    lm = (t >= t0 + width / 2 - tab * width / 2) * (t <= t0 + width / 2)
+    rm = (t >= t0 + plateau + width / 2) * (t <= t0 + plateau + width / 2 + tab * width / 2)
+    for n in range(len(bs) + 1):
+        d[n][lm] = np.polyder(left, m=n)(t[lm] - t0 - width / 2)
+        d[n][rm] = np.polyder(right, m=n)(t[rm] - t0 - plateau - width / 2)
+    om = np.einsum('ijk,kim->jm', B, np.array([d, 0 * d]))
+    wt = 2 * np.pi * (freq + delta) * t - (2 * np.pi * delta * t0 + phase)
+    return om[0] * np.cos(wt) + om[1] * np.sin(wt)
+
+
+PRIMITIVES[16] = _drag_sin
+PRIMITIVES[17] = _drag_sinx

@@ -144,6 +144,51 @@ static double drag(double t, const double* a) {
   return Ox * cos(wt) + Oy * sin(wt);
 }
 
+/* multi-notch DRAG (ids 16/17) from the compiled argument block (include/wfk.h);
+ * reference semantics: waveforms/multy_drag.py:31-155 */
+static double mdrag(double u, const double* a) {
+  double t0 = a[0], freq = a[1], width = a[2], delta = a[3], phase = a[4], plateau = a[5],
+         half = a[6];
+  int m = (int)a[7], dq = (int)a[8];
+  const double* px = a + 9;
+  const double* py = px + (m + 1);
+  const double* cst = py + (m + 1);
+  double o = M_PI / width, mid1 = t0 + width / 2, mid2 = t0 + plateau + width / 2;
+  double ox, oy;
+  int rising = u <= mid1, falling = u >= mid2;
+  if (rising || falling) {
+    double tau = falling ? u - t0 - plateau : u - t0;
+    double s = sin(o * tau), c = cos(o * tau), sp = 1.0;
+    double ex = 0, ey = 0, dx = 0, dy = 0;
+    for (int p = 0; p <= m; ++p) {
+      if (p & 1) { dx += px[p] * sp; dy += py[p] * sp; }
+      else { ex += px[p] * sp; ey += py[p] * sp; }
+      sp *= s;
+    }
+    ox = ex + c * dx;
+    oy = ey + c * dy;
+  } else {
+    ox = cst[0];
+    oy = cst[1];
+  }
+  if (dq >= 0) {
+    const double* q = cst + 2;
+    if (u >= mid1 - half && u <= mid1) {
+      double tau = u - t0 - width / 2, hx = 0, hy = 0;
+      for (int i = 0; i <= dq; ++i) { hx = hx * tau + q[i]; hy = hy * tau + q[dq + 1 + i]; }
+      ox = hx; oy = hy;
+    }
+    if (u >= mid2 && u <= mid2 + half) {
+      double tau = u - t0 - plateau - width / 2, hx = 0, hy = 0;
+      const double* qr = q + 2 * (dq + 1);
+      for (int i = 0; i <= dq; ++i) { hx = hx * tau + qr[i]; hy = hy * tau + qr[dq + 1 + i]; }
+      ox = hx; oy = hy;
+    }
+  }
+  double wt = 2 * M_PI * (freq + delta) * u - (2 * M_PI * delta * t0 + phase);
+  return ox * cos(wt) + oy * sin(wt);
+}
+
 static int prim(int type, double u, const double* a, int64_t na, double* out) {
   switch (type) {
     case WFK_LINEAR: *out = u; return 0;
@@ -172,6 +217,7 @@ static int prim(int type, double u, const double* a, int64_t na, double* out) {
     case WFK_DRAG: *out = drag(u, a); return 0;
     case WFK_MOLLIFIER: *out = mollifier(u, a[0], (int)a[1]); return 0;
     case WFK_D_GAUSSIAN: *out = d_gaussian(u, a[0], (int)a[1]); return 0;
+    case WFK_DRAG_SIN: case WFK_DRAG_SINX: *out = mdrag(u, a); return 0;
     default: return WFK_EUNSUP;
   }
 }

@@ -129,6 +129,17 @@ CASES = {
                                         block_freq=-0.5, t0=-8.0), LIN),
     'sampling_points': (lambda ns: ns.samplingPoints(
         -4.0, 6.0, [0.0, 1.0, -0.5, 2.0, 0.25, -1.0, 0.0]), LIN),
+    # --- multi-notch DRAG primitives (ids 16/17, reference multy_drag.py) ------
+    'mdrag_sin': (lambda ns: ns.drag_sin(0.4, 14.0, 0, 0.013, (0.9, 0.55, -0.7), 0.3, -7.0),
+                  LIN),
+    'mdrag_sin_plateau': (lambda ns: ns.drag_sin(0.4, 8.0, 5.0, -0.02, (0.8, -0.6, 1.3, -1.1, 0.45),
+                                                 -0.4, -6.5), LIN),
+    'mdrag_sin_single': (lambda ns: ns.drag_sin(0.3, 12.0, 0, 0.0, 0.75, 0.0, -6.0), LIN),
+    'mdrag_sin_none': (lambda ns: ns.drag_sin(0.3, 12.0, 0, 0.01, None, 0.2, -6.0), LIN),
+    'mdrag_sinx': (lambda ns: ns.drag_sinx(0.4, 14.0, 0, 0.013, (0.9, 0.55, -0.7), 0.3, -7.0,
+                                           0.45), LIN),
+    'mdrag_sinx_plateau': (lambda ns: ns.drag_sinx(0.4, 8.0, 5.0, -0.02, (0.8, -0.6, 1.3, -1.1),
+                                                   -0.4, -6.5, 0.7), LIN),
     # --- algebra -------------------------------------------------------------
     'pow2': (lambda ns: (ns.cos(1.3) + 0.5)**2, LIN),
     'pow3_term': (lambda ns: (ns.gaussian(9) * ns.cos(2))**3, LIN),

@@ -13,4 +13,6 @@ from .waveform import (D, Waveform, WaveVStack, chirp, const, cos, cosh,
                        registerBaseFunc, registerDerivative, samplingPoints,
                        sign, sin, sinc, sinh, slepian, square, step, t, zero)
 
+from .multy_drag import drag_sin, drag_sinx
+
 __version__ = "0.1.0"

@@ -19,7 +19,7 @@ _ARGC = {  # primitive id -> number of scalar args (None = variable)
     _ir.LINEAR: 0, _ir.GAUSSIAN: 1, _ir.ERF: 1, _ir.COS: 1, _ir.SINC: 1,
     _ir.EXP: 1, _ir.INTERP: None, _ir.LINEARCHIRP: 4, _ir.EXPONENTIALCHIRP: 3,
     _ir.HYPERBOLICCHIRP: 3, _ir.COSH: 1, _ir.SINH: 1, _ir.DRAG: 6,
-    _ir.MOLLIFIER: 2, _ir.D_GAUSSIAN: 2,
+    _ir.MOLLIFIER: 2, _ir.D_GAUSSIAN: 2, _ir.DRAG_SIN: None, _ir.DRAG_SINX: None,
 }
 
 
@@ -73,9 +73,14 @@ def _factor_args(factor):
     if type_id not in _ARGC:
         raise NotImplementedError(
             f'primitive id {type_id} has no device implementation '
-            f'(only the built-in ids 1..15 run on the GPU; Python callables '
+            f'(only the built-in ids 1..17 run on the GPU; Python callables '
             f'registered with registerBaseFunc/function() cannot)')
     want = _ARGC[type_id]
+    if type_id in (_ir.DRAG_SIN, _ir.DRAG_SINX):
+        if len(args) != (7 if type_id == _ir.DRAG_SIN else 8):
+            raise ValueError(f'{_ir.PRIMITIVE_NAMES[type_id]} factor has the wrong arity')
+        from .multy_drag import device_args
+        return device_args(type_id, args)
     if type_id == _ir.INTERP:
         if len(args) != 3:
             raise ValueError('INTERP factor must be (7, start, stop, points, shift)')

@@ -58,6 +58,7 @@ int argc_of(int type) {
     case WFK_LINEARCHIRP: return 4;
     case WFK_DRAG: return 6;
     case WFK_INTERP: return -1;
+    case WFK_DRAG_SIN: case WFK_DRAG_SINX: return -3;
     default: return -2;
   }
 }
@@ -159,6 +160,18 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     if (want == -2) {
       err = "primitive id " + std::to_string(P->fc_type[f]) + " has no device implementation";
       return WFK_EUNSUP;
+    }
+    if (want == -3) {   // compiled multi-notch DRAG: header + tables, lengths must agree
+      const double* a = P->pool + P->fc_arg_off[f];
+      bool ok = have >= 9;
+      if (ok) {
+        const double m = a[7], dq = a[8];
+        ok = m >= 0 && m <= 64 && m == std::floor(m) && dq >= -1 && dq <= 256 && dq == std::floor(dq) &&
+             have == 9 + 2 * ((int64_t)m + 1) + 2 + (dq >= 0 ? 4 * ((int64_t)dq + 1) : 0) &&
+             (P->fc_type[f] == WFK_DRAG_SINX) == (dq >= 0);
+      }
+      if (!ok) { err = "malformed compiled DRAG_SIN/DRAG_SINX argument block"; return WFK_EINVAL; }
+      continue;
     }
     if ((want >= 0 && have != want) || (want == -1 && have < 3)) {
       err = "wrong argument count for primitive id " + std::to_string(P->fc_type[f]);
@@ -264,6 +277,10 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         case WFK_D_GAUSSIAN:
           rec[3] = a[0]; rec[4] = a[1];
           rec[5] = std::pow(-1.0, a[1]) / std::pow(a[0], a[1]);
+          break;
+        case WFK_DRAG_SIN: case WFK_DRAG_SINX:
+          rec[3] = (double)H.pool.size();
+          H.pool.insert(H.pool.end(), a, a + na);
           break;
         default:
           for (int64_t k = 0; k < na && k < 6; ++k) rec[3 + k] = a[k];

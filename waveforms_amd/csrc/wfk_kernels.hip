@@ -160,6 +160,59 @@ __device__ double prim_dgauss(double u, const double* r) {
   return r[5] * h * exp(-(x * x));
 }
 
+// multi-notch DRAG (ids 16/17) from the compiled tables of waveforms_amd/multy_drag.py
+// (reference semantics: waveforms/multy_drag.py:31-155, incl. np.piecewise's "last
+// matching condition wins" at the region joints)
+__device__ double prim_mdrag(double u, const double* a) {
+  const double PI = 3.141592653589793;
+  const double t0 = a[0], freq = a[1], width = a[2], delta = a[3], phase = a[4], plateau = a[5],
+               half = a[6];
+  const int m = (int)a[7], dq = (int)a[8];
+  const double* px = a + 9;
+  const double* py = px + (m + 1);
+  const double* cst = py + (m + 1);
+  const double o = PI / width;
+  const double mid1 = t0 + width / 2, mid2 = t0 + plateau + width / 2;
+  double ox, oy;
+  const bool rising = u <= mid1, falling = u >= mid2;
+  if (rising || falling) {
+    const double tau = falling ? u - t0 - plateau : u - t0;
+    double s, c;
+    sincos(o * tau, &s, &c);
+    double ex = 0, ey = 0, dx = 0, dy = 0, sp = 1.0;   // even / odd parts
+    for (int p = 0; p <= m; ++p) {
+      if (p & 1) { dx += px[p] * sp; dy += py[p] * sp; }
+      else { ex += px[p] * sp; ey += py[p] * sp; }
+      sp *= s;
+    }
+    ox = ex + c * dx;
+    oy = ey + c * dy;
+  } else {
+    ox = cst[0];
+    oy = cst[1];
+  }
+  if (dq >= 0) {
+    const double* q = cst + 2;
+    if (u >= mid1 - half && u <= mid1) {
+      const double tau = u - t0 - width / 2;
+      double hx = 0, hy = 0;
+      for (int i = 0; i <= dq; ++i) { hx = hx * tau + q[i]; hy = hy * tau + q[dq + 1 + i]; }
+      ox = hx; oy = hy;
+    }
+    if (u >= mid2 && u <= mid2 + half) {
+      const double tau = u - t0 - plateau - width / 2;
+      const double* qr = q + 2 * (dq + 1);
+      double hx = 0, hy = 0;
+      for (int i = 0; i <= dq; ++i) { hx = hx * tau + qr[i]; hy = hy * tau + qr[dq + 1 + i]; }
+      ox = hx; oy = hy;
+    }
+  }
+  const double wt = 2 * PI * (freq + delta) * u - (2 * PI * delta * t0 + phase);
+  double sw, cw;
+  sincos(wt, &sw, &cw);
+  return ox * cw + oy * sw;
+}
+
 __device__ double prim_direct(int type, double u, const double* r, const double* pool) {
   const double PI = 3.141592653589793;
   switch (type) {
@@ -179,6 +232,7 @@ __device__ double prim_direct(int type, double u, const double* r, const double*
     case WFK_DRAG: return prim_drag(u, r);
     case WFK_MOLLIFIER: return prim_mollifier(u, r, pool);
     case WFK_D_GAUSSIAN: return prim_dgauss(u, r);
+    case WFK_DRAG_SIN: case WFK_DRAG_SINX: return prim_mdrag(u, pool + (int64_t)r[3]);
     default: return __builtin_nan("");
   }
 }
