@@ -12,6 +12,7 @@ input/output vectors derived by *running* it.
 
 Outputs
   tests/golden/frontend.json      reference tolist() for every case in tests/cases.py
+  tests/golden/frontend_simplified.json   reference simplify().tolist() per case
   tests/golden/samples.npz        reference wav(t) per case (+ searchsorted indices)
   tests/golden/sample_api.npz     reference wav.sample() per sos_case
   tests/golden/big.npz            C2 / C3 / C4: strided subsets, piece indices, sums
@@ -102,6 +103,14 @@ def main():
             samples[name + '.idx'] = np.searchsorted(t, w.bounds)
     with open(os.path.join(gold, 'frontend.json'), 'w') as f:
         json.dump(frontend, f)
+    simplified = {}
+    for name, (build, grid) in cases.CASES.items():
+        try:
+            simplified[name] = [enc(v) for v in build(ref).simplify().tolist()]
+        except Exception:
+            simplified[name] = None
+    with open(os.path.join(gold, 'frontend_simplified.json'), 'w') as f:
+        json.dump(simplified, f)
     np.savez_compressed(os.path.join(gold, 'samples.npz'), **samples)
 
     api = {}

@@ -23,3 +23,9 @@ def frontend_lists():
 
 def npz(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+def frontend_lists_named(fname):
+    with open(os.path.join(GOLDEN, fname)) as f:
+        raw = json.load(f)
+    return {k: (None if l is None else [dec(x) for x in l]) for k, l in raw.items()}

@@ -1,0 +1,107 @@
+"""Host-side symbolic layer beyond tree construction: simplify,
+equality-by-simplify, marker/mask, interp, WaveVStack.simplify, and the text front-end
+`wave_eval` (own parser for the reference's Waveform.g4).  No GPU involved."""
+import numpy as np
+import pytest
+from numpy import e, pi
+
+import cases
+import golden_io
+import waveforms_amd as wf
+from waveforms_amd import wave_eval
+from waveforms_amd._ir import wave_sum
+
+SIMPLE = golden_io.frontend_lists_named('frontend_simplified.json')
+
+
+@pytest.mark.parametrize('name', sorted(SIMPLE))
+def test_simplified_tree_matches_reference(name):
+    want = SIMPLE[name]
+    build = cases.CASES[name][0]
+    w = build(wf)
+    if want is None:                      # the reference raised as well
+        with pytest.raises(Exception):
+            w.simplify().tolist()
+        return
+    got = w.simplify().tolist()
+    assert len(got) == len(want)
+    for g, x in zip(got, want):
+        if isinstance(x, float) and isinstance(g, (float, np.floating)):
+            assert g == pytest.approx(x, rel=1e-13, abs=1e-300), name
+        else:
+            assert g == x, name
+
+
+def test_reference_test_parser():
+    # reference tests/test_waveform.py:141-166 (cannot run upstream without ANTLR/Java)
+    assert wave_eval("one()") == wf.one()
+    assert wave_eval("zero()") == wf.zero()
+    assert wave_eval("pi") == pi
+    assert wave_eval("e") == e
+    w1 = (wf.gaussian(10) << 100) + wf.square(20, edge=5, type='linear') * wf.cos(2 * pi * 23.1)
+    w2 = wave_eval("(gaussian(10) << 100) + square(20, edge=5, type='linear') * cos(2*pi*23.1)")
+    w3 = wave_eval("((gaussian(10) << 50) + ((square(20, 5, type='linear') * cos(2*pi*23.1)) >> 50)) << 50")
+    w4 = wave_eval("(gaussian(10) << 100) + square(20, 5, 'linear') * cos(2*pi*23.1)")
+    assert w1 == w2 and w1 == w3 and w1 == w4
+    p1 = wf.poly([1, -1 / 2, 1 / 6, -1 / 12])
+    assert p1 == wave_eval("poly([1, -1/2, 1/6, -1/12])")
+    assert p1 == wave_eval("poly((1, -1/2, 1/6, -1/12))")
+
+
+def test_parser_grammar_details():
+    # left-associative power; unary minus binds loosest (ANTLR alternative order)
+    assert wave_eval("2 ** 3 ** 2") == 64
+    assert wave_eval("-2 + 5") == -7
+    assert wave_eval("3 * -1 + 2") == -9
+    assert wave_eval("2 ^ 3") == 8
+    assert wave_eval("1e3 + .5") == 1000.5
+    assert wave_eval("(2j) * (2j)") == -4
+    assert wave_eval("cos(2) >> 1") == (wf.cos(2) >> 1)
+    assert wave_eval("gaussian(width=4, plateau=2)") == wf.gaussian(4, plateau=2)
+    assert wave_eval("drag_sin(0.4, 14.0, 0, 0.013, (0.9, 0.55), 0.3, -7.0)").tolist() == \
+        wf.drag_sin(0.4, 14.0, 0, 0.013, (0.9, 0.55), 0.3, -7.0).simplify().tolist()
+    for bad in ("x = cos(1)", "foo(1)", "cos(1", "cos(1) +", "bar", "cos(1) $ 2", "cos(a=1, 2)"):
+        with pytest.raises(SyntaxError):
+            wave_eval(bad)
+
+
+def test_reference_vstack_simplify_and_wave_sum():
+    # reference tests/test_wavevstack.py:91-110, 140-143
+    w1, w2 = wf.zero(), []
+    assert w1 == wf.WaveVStack(w2).simplify()
+    for freq in np.linspace(6.1, 6.5, 11) * 1e9:
+        pulse = wf.square(1e-6) >> 95e-6
+        w1 += pulse * wf.cos(2 * pi * freq)
+        w2.append(pulse * wf.cos(2 * pi * freq))
+        assert w1 == wf.WaveVStack(w2).simplify()
+    rng = np.random.default_rng(0)
+    for freq in np.linspace(6.1, 6.5, 3) * 1e9:
+        pulse = wf.square(1e-6) >> (95e-6 + rng.normal() * 1e-9)
+        w1 += pulse * wf.cos(2 * pi * freq)
+        w2.append(pulse * wf.cos(2 * pi * freq))
+        assert w1 == wf.WaveVStack(w2).simplify()
+    w1 += wf.cos(2 * pi * freq * 0.9)
+    w2.append(wf.cos(2 * pi * freq * 0.9))
+    assert w1 == wf.WaveVStack(w2).simplify()
+    assert wave_sum([((-1.0, np.inf), (((), ()), ((((), ()), ), (0.02, )))),
+                     ((-1.0, np.inf), (((), ()), ((((), ()), ), (-0.02, ))))
+                     ]) == ((np.inf, ), (((), ()), ))
+    wlist = [wf.cos(1), wf.sin(2), wf.gaussian(3), wf.poly([1, -1 / 2, 1 / 6, -1 / 12])]
+    tot = wf.zero()
+    for w in wlist:
+        tot += w
+    assert wf.WaveVStack(wlist).simplify() == tot     # reference test_wavevstack.py:16-17
+    assert wf.Waveform.fromlist(cases.CASES['ref_tolist'][0](wf).tolist()) == \
+        cases.CASES['ref_tolist'][0](wf)              # reference test_waveform.py:50
+
+
+def test_marker_mask_logic_interp():
+    w = (wf.gaussian(4) >> 3) + (wf.square(2) << 5)
+    m = w.marker
+    assert m.bounds == (-6.0, -4.0, 0.0, 6.0, np.inf) and m.seq[1] != m.seq[0]
+    assert (w | wf.zero()) == m and (w & wf.one()) == m
+    assert w.mask(0.5).bounds[0] == -6.5
+    f = wf.interp([0.0, 1.0, 3.0], [0.0, 2.0, -1.0])
+    assert f.bounds == (0.0, 1.0, 3.0, np.inf)
+    band = (wf.cos(2) + wf.cos(9) + 1).filter(low=5)
+    assert band == wf.cos(9)

@@ -9,10 +9,11 @@ from numpy import e, pi
 
 from .waveform import (D, Waveform, WaveVStack, chirp, const, cos, cosh,
                        coshPulse, cosPulse, cut, drag, exp, function, gaussian,
-                       general_cosine, hanning, mixing, mollifier, one, poly,
+                       general_cosine, hanning, interp, mixing, mollifier, one, poly,
                        registerBaseFunc, registerDerivative, samplingPoints,
                        sign, sin, sinc, sinh, slepian, square, step, t, zero)
 
 from .multy_drag import drag_sin, drag_sinx
+from .waveform_parser import wave_eval
 
 __version__ = "0.1.0"

@@ -329,3 +329,165 @@ def derivative(expr):
         return mul(_d_factor(f), const_expr(amp))
     lowered = ((((f, ), (n - 1, )), ), (n * amp, ))
     return mul(lowered, derivative(((((f, ), (1, )), ), (1, ))))
+
+
+# --------------------------------------------------------------------------
+# Symbolic normal form: simplify / filter.
+# Same results, term for term, as the reference (waveforms/_waveform.pyx:483-654):
+# products of cosines become sums (product-to-sum), EXP factors merge, Gaussian powers
+# fold into the width, and terms with the same (non-cosine part, frequency) are merged
+# into one cosine per real / imaginary amplitude.
+# --------------------------------------------------------------------------
+def _binom(n, k):
+    return math.comb(n, k) if 0 <= k <= n else 0
+
+
+def _cos_pow(factor, n):
+    """cos(w (t - s))**n as a sum of cosines of multiples of w."""
+    _, w, s = factor
+    out = ZERO
+    for k in range(n // 2 + 1):
+        if n == 2 * k:
+            out = add(out, const_expr(_binom(n, k) / 2**n))
+        else:
+            out = add(out, ((((((COS, (n - 2 * k) * w, s), ), (1, )), ),
+                             (_binom(n, k) / 2**(n - 1), ))))
+    return out
+
+
+def _cos_times_cos(x, y, v):
+    """v cos(a) cos(b) = v/2 cos(a+b) + v/2 cos(a-b), lower frequency first."""
+    _, w1, t1 = x
+    _, w2, t2 = y
+    if w2 > w1:
+        w1, w2, t1, t2 = w2, w1, t2, t1
+    hi = (COS, w1 + w2, (w1 * t1 + w2 * t2) / (w1 + w2))
+    if w1 == w2:
+        c = v * np.cos(w1 * t1 - w2 * t2) / 2
+        if c == 0:
+            return (((hi, ), (1, )), ), (0.5 * v, )
+        return (((), ()), ((hi, ), (1, ))), (c, 0.5 * v)
+    lo = (COS, w1 - w2, (w1 * t1 - w2 * t2) / (w1 - w2))
+    if lo[1] > hi[1]:
+        lo, hi = hi, lo
+    return (((lo, ), (1, )), ((hi, ), (1, ))), (0.5 * v, 0.5 * v)
+
+
+def _trig_product(x, y):
+    """Product of two expressions whose terms hold at most one COS factor each."""
+    if is_const(x) or is_const(y):
+        return mul(x, y)
+    out = ZERO
+    for (t1, t2), (v1, v2) in zip(itertools.product(x[0], y[0]),
+                                  itertools.product(x[1], y[1])):
+        v = v1 * v2
+        rest = ONE
+        trig = []
+        for f, n in zip(itertools.chain(t1[0], t2[0]), itertools.chain(t1[1], t2[1])):
+            if f[0] == COS:
+                trig.append(f)
+            else:
+                rest = mul(rest, ((((f, ), (n, )), ), (1, )))
+        if len(trig) == 1:
+            term = mul(rest, ((((trig[0], ), (1, )), ), (v, )))
+        elif len(trig) == 2:
+            term = mul(rest, _cos_times_cos(trig[0], trig[1], v))
+        else:
+            term = mul(rest, const_expr(v))
+        out = add(out, term)
+    return out
+
+
+def _reduce_term(term, v):
+    """One term -> sum of terms with at most one COS factor and at most one EXP."""
+    trig = ONE
+    alpha = shift_ = 0
+    keep_f, keep_n = [], []
+    for f, n in zip(*term):
+        if f[0] == COS:
+            trig = _trig_product(trig, _cos_pow(f, n))
+        elif f[0] == EXP:
+            x = alpha * shift_ + n * f[1] * f[-1]
+            alpha += n * f[1]
+            shift_ = 0 if alpha == 0 else x / alpha
+        elif f[0] == GAUSSIAN and n != 1:
+            keep_f.append((f[0], f[1] / np.sqrt(n), f[2]))
+            keep_n.append(1)
+        else:
+            keep_f.append(f)
+            keep_n.append(n)
+    out = (((tuple(keep_f), tuple(keep_n)), ), (v, ))
+    if alpha != 0:
+        out = mul(out, primitive(EXP, alpha, shift=shift_))
+    return mul(out, trig)
+
+
+def _split_carrier(term):
+    freq = shift_ = 0
+    rest_f, rest_n = [], []
+    for f, n in zip(*term):
+        if f[0] == COS:
+            if freq != 0:
+                raise ValueError("run _exp_trig_Reduce first")
+            freq, shift_ = f[1], f[-1]
+        else:
+            rest_f.append(f)
+            rest_n.append(n)
+    return freq, shift_, (tuple(rest_f), tuple(rest_n))
+
+
+def simplify(expr, eps):
+    merged = {}
+    v = 0
+    for t, v in zip(*expr):
+        for t, v in zip(*_reduce_term(t, v)):
+            freq, sh, t = _split_carrier(t)
+            v_r, v_i, sh_r, sh_i = v.real, v.imag, sh, sh
+            if (t, freq) in merged:
+                p_r, ps_r, p_i, ps_i = merged[(t, freq)]
+                if freq == 0:
+                    v_r, v_i = v.real + p_r, v.imag + p_i
+                else:
+                    a = p_r * np.cos(freq * ps_r) + v_r * np.cos(freq * sh_r)
+                    b = p_r * np.sin(freq * ps_r) + v_r * np.sin(freq * sh_r)
+                    sh_r, v_r = np.arctan2(b, a) / freq, np.sqrt(a**2 + b**2)
+                    a = p_i * np.cos(freq * ps_i) + v_i * np.cos(freq * sh_i)
+                    b = p_i * np.sin(freq * ps_i) + v_i * np.sin(freq * sh_i)
+                    sh_i, v_i = np.arctan2(b, a) / freq, np.sqrt(a**2 + b**2)
+            merged[(t, freq)] = v_r, sh_r, v_i, sh_i
+    out = ZERO
+    for (t, freq), (v_r, sh_r, v_i, sh_i) in merged.items():
+        # NB `v` is the amplitude of the LAST reduced term, not of this entry: the
+        # reference's stale loop variable (_waveform.pyx:615, SURVEY.md Appendix F.7),
+        # kept so that simplified trees are identical.
+        if freq == 0 and abs(v) >= eps:
+            out = add(out, ((t, ), (v_r if v_i == 0 else v_r + 1j * v_i, )))
+            continue
+        if abs(v_i) < eps and abs(v_r) < eps:
+            continue
+        if abs(v_i) < eps:
+            carrier = (((((COS, freq, sh_r), ), (1, )), ), (v_r, ))
+        elif abs(v_r) < eps:
+            carrier = (((((COS, freq, sh_i), ), (1, )), ), (v_i * 1j, ))
+        else:
+            carrier = (((((COS, freq, sh_r), ), (1, )), (((COS, freq, sh_i), ), (1, ))),
+                       (v_r, v_i * 1j))
+        out = add(out, mul(((t, ), (1, )), carrier))
+    return out
+
+
+def band_filter(expr, low, high, eps):
+    """Keep the terms whose carrier frequency lies in [low, high)
+    (reference: _waveform.pyx:638-654)."""
+    expr = simplify(expr, eps)
+    out = ZERO
+    for t, v in zip(*expr):
+        for f, n in zip(*t):
+            if f[0] == COS:
+                if low <= f[1] < high:
+                    out = add(out, ((t, ), (v, )))
+                break
+        else:
+            if low <= 0:
+                out = add(out, ((t, ), (v, )))
+    return out

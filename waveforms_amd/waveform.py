@@ -210,6 +210,68 @@ class Waveform:
         w.bounds, w.seq = tuple(bounds), tuple(seq)
         return w
 
+    # ---- symbolic normal form (reference: waveforms/waveform.py:384-400, 418-482) ---
+    def simplify(self, eps=1e-15):
+        seq = [_ir.simplify(self.seq[0], eps)]
+        bounds = [self.bounds[0]]
+        for expr, b in zip(self.seq[1:], self.bounds[1:]):
+            expr = _ir.simplify(expr, eps)
+            if expr == seq[-1]:
+                seq.pop()
+                bounds.pop()
+            seq.append(expr)
+            bounds.append(b)
+        return Waveform(tuple(bounds), tuple(seq))
+
+    def filter(self, low=0, high=inf, eps=1e-15):
+        return Waveform(self.bounds,
+                        tuple(_ir.band_filter(e, low, high, eps) for e in self.seq))
+
+    @property
+    def marker(self):
+        w = self.simplify()
+        return Waveform(w.bounds, tuple(ZERO if e == ZERO else ONE for e in w.seq))
+
+    def mask(self, edge: float = 0):
+        w = self.marker
+        bounds, seq = [], []
+        inside = w.seq[0] == ZERO
+        if w.seq[0] == ZERO:
+            inside = False
+            bounds.append(w.bounds[0] - edge)
+            seq.append(ZERO)
+        for b, e in zip(w.bounds[1:], w.seq[1:]):
+            if not inside and e != ZERO:
+                inside = True
+                bounds.append(b + edge)
+                seq.append(ONE)
+            elif inside and e == ZERO:
+                inside = False
+                b = b - edge
+                if b > bounds[-1]:
+                    bounds.append(b)
+                    seq.append(ZERO)
+                else:
+                    bounds.pop()
+                    bounds.append(b)
+        return Waveform(tuple(bounds), tuple(seq))
+
+    def __or__(self, other):
+        if isinstance(other, (int, float, complex)):
+            other = const(other)
+        return self._comb(other, lambda a, b: ONE if (a != ZERO or b != ZERO) else ZERO)
+
+    def __ior__(self, other):
+        return self | other
+
+    def __and__(self, other):
+        if isinstance(other, (int, float, complex)):
+            other = const(other)
+        return self._comb(other, lambda a, b: ONE if (a != ZERO and b != ZERO) else ZERO)
+
+    def __iand__(self, other):
+        return self & other
+
     # ---- algebra (reference: waveforms/waveform.py:402-515) ----------------
     def _comb(self, other, oper):
         return Waveform(*_ir.combine_pieces(self.bounds, self.seq,
@@ -260,14 +322,13 @@ class Waveform:
                      self.sample_rate, self.bounds, self.seq))
 
     def __eq__(self, o):
-        """Structural equality.  (The reference compares *simplified* trees,
-        waveforms/waveform.py:569-579; `simplify` is SURVEY.md §8(f) N4.)"""
+        """Equality of the simplified trees (reference: waveforms/waveform.py:569-579)."""
         if isinstance(o, (int, float, complex)):
             return self == const(o)
-        if isinstance(o, Waveform) and not isinstance(o, WaveVStack):
-            return (self.seq == o.seq and self.bounds == o.bounds and
-                    (self.max, self.min, self.start, self.stop) ==
-                    (o.max, o.min, o.start, o.stop))
+        if isinstance(o, Waveform):
+            a, b = self.simplify(), o.simplify()
+            return a.seq == b.seq and a.bounds == b.bounds and (
+                a.max, a.min, a.start, a.stop) == (b.max, b.min, b.start, b.stop)
         return False
 
 
@@ -302,6 +363,21 @@ class WaveVStack(Waveform):
         assert frag is False, 'WaveVStack does not support frag mode'
         from . import _sampling
         return _sampling.call_vstack(self, x, function_lib)
+
+    def simplify(self, eps=1e-15):
+        """Collapse the stack into one simplified Waveform
+        (reference: waveforms/waveform.py:734-749)."""
+        if not self.wlist:
+            return zero()
+        wav = Waveform(*_ir.wave_sum(self.wlist))
+        if self.offset != 0:
+            wav += self.offset
+        if self.shift != 0:
+            wav >>= self.shift
+        wav = wav.simplify(eps)
+        wav.start, wav.stop, wav.sample_rate = self.start, self.stop, self.sample_rate
+        wav.filters, wav.label = self.filters, self.label
+        return wav
 
     def tolist(self):
         l = [self.start, self.stop, self.offset, self.shift, self.sample_rate]
@@ -367,8 +443,7 @@ class WaveVStack(Waveform):
 
     def __mul__(self, other):
         if isinstance(other, Waveform):
-            # (the reference also simplify()s `other` first)
-            other = other << self.shift
+            other = other.simplify() << self.shift
             ret = WaveVStack([Waveform(*m) * other for m in self.wlist])
             if self.offset != 0:
                 w = other * self.offset
@@ -638,6 +713,21 @@ def chirp(f0: float, f1: float, T: float, phi0: float = 0,
     return _window(0, _rnd(T), body)
 
 
+def interp(x, y) -> Waveform:
+    """Piecewise-linear waveform through the points (x, y)
+    (reference: waveforms/waveform.py:1425-1440)."""
+    seq, bounds = [ZERO], [x[0]]
+    for x1, x2, y1, y2 in zip(x[:-1], x[1:], y[:-1], y[1:]):
+        if x2 == x1:
+            continue
+        seq.append(_ir.add(_ir.mul(const_expr((y2 - y1) / (x2 - x1)),
+                                   primitive(LINEAR, shift=x1)), const_expr(y1)))
+        bounds.append(x2)
+    bounds.append(inf)
+    seq.append(ZERO)
+    return Waveform(seq=tuple(seq), bounds=tuple(_rnd(b) for b in bounds)).simplify()
+
+
 def cut(wav: Waveform, start=None, stop=None, head=None, tail=None, min=None,
         max=None) -> Waveform:
     offset = 0
@@ -702,7 +792,7 @@ def mixing(I: Waveform, Q: Waveform | None = None, *, phase: float = 0.0,
 __all__ = [
     'D', 'Waveform', 'WaveVStack', 'chirp', 'const', 'cos', 'cosh', 'coshPulse',
     'cosPulse', 'cut', 'drag', 'exp', 'function', 'gaussian', 'general_cosine',
-    'hanning', 'mixing', 'mollifier', 'one', 'poly', 'registerBaseFunc',
+    'hanning', 'interp', 'mixing', 'mollifier', 'one', 'poly', 'registerBaseFunc',
     'registerDerivative', 'samplingPoints', 'sign', 'sin', 'sinc', 'sinh',
     'slepian', 'square', 'step', 't', 'zero'
 ]
