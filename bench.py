@@ -71,11 +71,24 @@ def cpu_baseline(chans, grid_desc, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {'value': done * len(t) / dt / 1e6, 'unit': 'Msamples/s', 'cores': 1,
+    base = {'value': done * len(t) / dt / 1e6, 'unit': 'Msamples/s', 'cores': 1,
             'kind': 'port',
             'sample': f'{done} channel(s) x {len(t)} pts of the same workload, '
                       f'NumPy restatement of the reference pass structure, '
-                      f'{dt:.1f} s, host has {os.cpu_count()} cores'}, outs
+                      f'{dt:.1f} s, host has {os.cpu_count()} cores'}
+    # second CPU figure: the plain-C scalar oracle on the flattened program (1 thread)
+    try:
+        from oracle import c_oracle
+        from waveforms_amd import _flatten
+        prog = _flatten.flatten(chans[:2])
+        g = _flatten.grid_from_desc(grid_desc)
+        t1 = time.perf_counter()
+        c_oracle.eval_grid(prog, g)
+        dc = time.perf_counter() - t1
+        base['c_oracle_msamples_per_s_1thread'] = 2 * len(t) / dc / 1e6
+    except Exception as exc:  # the C oracle is optional for the bench
+        base['c_oracle_error'] = repr(exc)
+    return base, outs
 
 
 def main():

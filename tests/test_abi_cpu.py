@@ -94,3 +94,40 @@ def test_arange_grid_formula():
         assert g.n == len(ref)
         i = np.arange(g.n, dtype=np.float64)
         assert np.array_equal(i * g.step + g.t0, ref)
+
+
+def test_malformed_programs_are_rejected():
+    """The host compiler validates the flattened forest before using it."""
+    import copy
+    grid = _flatten.grid_linspace(0.0, 1.0, 100)
+    good = _flatten.flatten([wf.gaussian(0.5) * wf.cos(3.0) >> 0.5])
+    _engine.Plan(good, grid=grid)
+
+    def broken(edit):
+        prog = _flatten.flatten([wf.gaussian(0.5) * wf.cos(3.0) >> 0.5])
+        edit(prog)
+        with pytest.raises(_engine.EngineError):
+            _engine.Plan(prog, grid=grid)
+
+    def bad_offsets(p):
+        p.arrays['pc_term_off'][1] = 99
+    broken(bad_offsets)
+
+    def bad_last_bound(p):
+        p.arrays['pc_bound'][-1] = 1.0
+    broken(bad_last_bound)
+
+    def descending_bounds(p):
+        p.arrays['pc_bound'][0], p.arrays['pc_bound'][1] = 5.0, -5.0
+    broken(descending_bounds)
+
+    def bad_argc(p):
+        p.arrays['fc_arg_off'][-1] += 1
+    broken(bad_argc)
+
+    prog = _flatten.flatten([wf.gaussian(0.5)])
+    prog.arrays['fc_type'][0] = 99
+    with pytest.raises(NotImplementedError):
+        _engine.Plan(prog, grid=grid)
+    with pytest.raises(_engine.EngineError):
+        _engine.Plan(good, grid=_flatten.wfk_grid(0.0, -1.0, 10, 0, 0.0))

@@ -104,14 +104,23 @@ __global__ void __launch_bounds__(64) iir_pass(const IirCoef c, const T* __restr
   const int nact = (int)(nblk - blk0 < 64 ? nblk - blk0 : 64);   // active blocks in this wave
   constexpr int RPI = 64 / IIR_SEG;      // tile rows (blocks) moved per wave instruction
   const int rsub = lane / IIR_SEG, col = lane % IIR_SEG;
-  for (int seg = 0; seg < IIR_LB / IIR_SEG; ++seg) {
-    // load the 64 x SEG tile: each instruction moves RPI rows of SEG contiguous samples
-#pragma unroll 4
-    for (int r0 = 0; r0 < 64; r0 += RPI) {
-      const int r = r0 + rsub;
-      const int64_t j = (blk0 + r) * IIR_LB + seg * IIR_SEG + col;
-      tile[r][col] = (r < nact && j < n) ? x[j] : (T)0;
+  // software pipeline: the global loads of segment seg+1 are in flight while segment seg
+  // is being filtered out of LDS
+  constexpr int NSEG = IIR_LB / IIR_SEG, NLD = 64 / RPI;
+  T pre[NLD];
+  auto fetch = [&](int seg) {
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int r = q * RPI + rsub;
+      const int64_t j = (blk0 + r) * IIR_LB + (int64_t)seg * IIR_SEG + col;
+      pre[q] = (r < nact && j < n) ? x[j] : (T)0;
     }
+  };
+  fetch(0);
+  for (int seg = 0; seg < NSEG; ++seg) {
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) tile[q * RPI + rsub][col] = pre[q];
+    if (seg + 1 < NSEG) fetch(seg + 1);
     __syncthreads();
     if (blk < nblk) {
       const int64_t base = blk * IIR_LB + seg * IIR_SEG;
