@@ -191,6 +191,16 @@ int wfk_iir_apply(wfk_iir_plan* plan, const void* in_dev, int64_t in_stride, voi
                   void* hip_stream);
 int wfk_iir_plan_destroy(wfk_iir_plan* plan);
 
+/* -- whole-signal transfer function ------------------- */
+/* out = irfft(rfft(in) * H) per row; rows contiguous (stride n); H_dev = n/2+1 complex128
+ * bins on the device (f_k = k*fs/n).  Replaces the scipy.fftpack calls of
+ * reflection / correct_reflection (waveforms/distortion.py:208-223).                  */
+typedef struct wfk_spectral_plan wfk_spectral_plan;
+int wfk_spectral_plan_create(int64_t n, int32_t batch, int kind, wfk_spectral_plan** out);
+int wfk_spectral_apply(wfk_spectral_plan* plan, const void* in_dev, void* out_dev,
+                       const void* H_dev, void* hip_stream);
+int wfk_spectral_plan_destroy(wfk_spectral_plan* plan);
+
 /* -- device memory helpers for FFI callers without a HIP binding ---------- */
 int wfk_malloc(void** dev_ptr, size_t bytes);
 int wfk_free(void* dev_ptr);

@@ -190,6 +190,16 @@ def main():
         iir[f'pd{i}.ba'] = np.concatenate([b, a])
         iir[f'pd{i}.distort'] = dist.distort(sig, np.asarray(params).reshape(-1), 1e9, initial)
     np.savez_compressed(os.path.join(gold, 'iir.npz'), **iir)
+
+    # ---- FFT-domain ops -------------------------------------
+    spec = {}
+    for i, (n, A, tau, fs) in enumerate(cases.spectral_cases()):
+        sig = cases.spectral_input(i)
+        spec[f'{i}.refl'] = dist.reflection(sig, A, tau, fs)
+        spec[f'{i}.corr'] = dist.correct_reflection(sig, A, tau, fs)
+        spec[f'{i}.shift'] = dist.shift(sig, 3.3 / fs * (1 if i % 2 else -1), 1 / fs)
+    spec['zker'] = dist.zDistortKernel(1e-9, [(50e-9, 0.02), (400e-9, -0.01)])
+    np.savez_compressed(os.path.join(gold, 'spectral.npz'), **spec)
     for f in sorted(os.listdir(gold)):
         print(f, os.path.getsize(os.path.join(gold, f)))
 

@@ -222,3 +222,14 @@ def predistort_inputs(i):
     sig = rng.normal(size=n) + initial
     ker = rng.normal(size=k) if k else None
     return sig, ker
+
+
+def spectral_cases():
+    """(n, A, tau, sample_rate) for reflection / correct_reflection / shift."""
+    return [(4096, 0.1, 12.5e-9, 1e9), (10007, -0.2, 31e-9, 2e9), (30000, 0.05, 3e-9, 1e9)]
+
+
+def spectral_input(i):
+    n = spectral_cases()[i][0]
+    rng = np.random.default_rng(900 + i)
+    return np.cumsum(rng.normal(size=n)) / 30 + rng.normal(size=n) * 0.01

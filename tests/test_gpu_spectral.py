@@ -1,0 +1,39 @@
+"""FFT-domain operations of distortion.py on the device, against
+golden outputs of the real reference (tests/golden/spectral.npz).  The reference has no
+tests for these functions: parity is pinned by reference-generated vectors only."""
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+from waveforms_amd import distortion
+import waveforms_amd as wf
+
+pytestmark = pytest.mark.gpu
+SPEC = golden_io.npz('spectral.npz')
+
+
+@pytest.mark.parametrize('i', range(len(cases.spectral_cases())))
+def test_reflection_and_shift(i):
+    n, A, tau, fs = cases.spectral_cases()[i]
+    sig = cases.spectral_input(i)
+    scale = max(1.0, np.abs(sig).max())
+    got = distortion.reflection(sig, A, tau, fs)
+    assert np.max(np.abs(got - SPEC[f'{i}.refl'])) <= 1e-11 * scale
+    back = distortion.correct_reflection(got, A, tau, fs)
+    assert np.max(np.abs(back - sig)) <= 1e-10 * scale              # round trip
+    corr = distortion.correct_reflection(sig, A, tau, fs)
+    assert np.max(np.abs(corr - SPEC[f'{i}.corr'])) <= 1e-11 * scale
+    sh = distortion.shift(sig, 3.3 / fs * (1 if i % 2 else -1), 1 / fs)
+    assert np.max(np.abs(sh - SPEC[f'{i}.shift'])) <= 1e-12 * scale
+
+
+def test_kernel_design_and_symbolic_branch():
+    zk = distortion.zDistortKernel(1e-9, [(50e-9, 0.02), (400e-9, -0.01)])
+    assert np.allclose(zk, SPEC['zker'], rtol=1e-12, atol=1e-15)
+    w = wf.gaussian(10e-9) >> 20e-9
+    c = distortion.correct_reflection(w, 0.1, 5e-9)
+    assert isinstance(c, wf.Waveform)
+    assert c == 1 / 0.9 * w - 0.1 / 0.9 * (w >> 5e-9)
+    with pytest.raises(ValueError):
+        distortion.correct_reflection(np.zeros(8), 0.1, 1e-9)

@@ -74,6 +74,9 @@ def lib():
         l.wfk_iir_state_dim.argtypes = [VP]
         l.wfk_iir_apply.argtypes = [VP, VP, I64, VP, I64, VP, VP, C.c_double, VP]
         l.wfk_iir_plan_destroy.argtypes = [VP]
+        l.wfk_spectral_plan_create.argtypes = [I64, I32, C.c_int, P(VP)]
+        l.wfk_spectral_apply.argtypes = [VP, VP, VP, VP, VP]
+        l.wfk_spectral_plan_destroy.argtypes = [VP]
         l.wfk_malloc.argtypes = [P(VP), C.c_size_t]
         l.wfk_free.argtypes = [VP]
         l.wfk_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
@@ -214,6 +217,26 @@ class IirPlan:
     def close(self):
         if self._h and _lib is not None:
             _lib.wfk_iir_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class SpectralPlan:
+    """out = irfft(rfft(x) * H) along each of `batch` contiguous rows of n samples."""
+
+    def __init__(self, n: int, batch: int = 1, dtype=np.float64):
+        self.n, self.batch, self.dtype = int(n), int(batch), np.dtype(dtype)
+        self._h = C.c_void_p()
+        check(lib().wfk_spectral_plan_create(self.n, self.batch, _KIND_OF[self.dtype],
+                                             C.byref(self._h)))
+
+    def apply(self, in_ptr, out_ptr, H_ptr, stream=0):
+        check(lib().wfk_spectral_apply(self._h, in_ptr, out_ptr, H_ptr, stream))
+
+    def close(self):
+        if self._h and _lib is not None:
+            _lib.wfk_spectral_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

@@ -182,3 +182,85 @@ def distort(points, params, sample_rate, initial=0.0):
     for amp, tau in np.asarray(params).reshape(-1, 2):
         filters.append(exp_decay_filter(amp, abs(tau), sample_rate))
     return predistort(points, filters, initial=initial)
+
+
+# --------------------------------------------------------------------------
+# FFT-domain operations
+# --------------------------------------------------------------------------
+def reflection_filter(f, A, tau):
+    """Transfer function of a single reflection (reference: distortion.py:188-205)."""
+    return (1 - A) / (1 - A * np.exp(-2j * np.pi * f * tau))
+
+
+def transfer_host(sig, H):
+    """irfft(rfft(sig) * H) on the device; H: the n//2+1 non-negative-frequency bins."""
+    sig = np.ascontiguousarray(sig, dtype=np.float64)
+    n = len(sig)
+    Hc = np.ascontiguousarray(H, dtype=np.complex128)
+    assert Hc.shape == (n // 2 + 1, )
+    plan = _engine.SpectralPlan(n, 1, np.float64)
+    x, y, h = (_engine.DeviceBuffer(n * 8), _engine.DeviceBuffer(n * 8),
+               _engine.DeviceBuffer(Hc.nbytes))
+    try:
+        x.upload(sig)
+        h.upload(Hc)
+        plan.apply(x.ptr, y.ptr, h.ptr)
+        _engine.sync()
+        return y.download((n, ), np.float64)
+    finally:
+        for b in (x, y, h):
+            b.close()
+        plan.close()
+
+
+def reflection(sig, A, tau, sample_rate):
+    """ifft(fft(sig) * H(f)).real with H the reflection filter
+    (reference: distortion.py:208-210); whole-signal FFT on the device."""
+    freq = np.fft.rfftfreq(len(sig), 1 / sample_rate)
+    return transfer_host(sig, reflection_filter(freq, A, tau))
+
+
+def correct_reflection(sig, A, tau, sample_rate=None):
+    """Inverse of `reflection` (reference: distortion.py:213-223); symbolic for a Waveform."""
+    from .waveform import Waveform
+    if isinstance(sig, Waveform):
+        return 1 / (1 - A) * sig - A / (1 - A) * (sig >> tau)
+    if sample_rate is None:
+        raise ValueError('sample_rate is not given')
+    freq = np.fft.rfftfreq(len(sig), 1 / sample_rate)
+    return transfer_host(sig, 1 / reflection_filter(freq, A, tau))
+
+
+def shift(signal, delay, dt):
+    """Delay a sampled signal by `delay` (3-tap fractional interpolation on the device +
+    integer shift; reference: distortion.py:12-39)."""
+    signal = np.asarray(signal, dtype=np.float64)
+    points = int(delay // dt)
+    delta = delay / dt - points
+    if delta > 0:
+        signal = fir_host(signal, np.array([0, 1 - delta, delta]))
+    if points == 0:
+        return signal
+    ret = np.zeros_like(signal)
+    if points < 0:
+        ret[:points] = signal[-points:]
+    else:
+        ret[points:] = signal[:-points]
+    return ret
+
+
+def zDistortKernel(dt, params):
+    """FIR kernel of a Z-line distortion model (filter DESIGN: one small FFT on the host,
+    reference: distortion.py:52-60)."""
+    t = 3 * np.asarray(params)[:, 0].max()
+    omega = 2 * np.pi * np.fft.fftfreq(int(t / dt) + 1, dt)
+    H = 1
+    for tau, A in params:
+        H = H + (1j * A * omega * tau) / (1j * omega * tau + 1)
+    return np.fft.ifftshift(np.fft.ifft(1 / H)).real
+
+
+def high_pass_filter(tau, sample_rate):
+    """reference: distortion.py:63-70"""
+    k = 2.0 * tau * sample_rate
+    return [k / (1 + k), -k / (1 + k)], [1.0, (1 - k) / (1 + k)]
