@@ -20,7 +20,12 @@
 namespace {
 
 constexpr int FL = 4096;        // transform length
-constexpr int RB = 273;         // padded row for the second exchange (elements)
+// LDS exchanges move real and imaginary parts in two rounds through ONE array of scalars
+// (half the footprint of a complex image: 37 KB fp64, so 3-4 workgroups fit per CU instead
+// of 2).  Row strides are padded for the 8-byte bank mapping: RA = 272 (== 16 mod 32) for the
+// first exchange, RB = 289 (== 1 mod 32) for the second.
+constexpr int RA = 272;
+constexpr int RB = 289;
 constexpr int LDS_ELEMS = 16 * RB;
 
 template <typename T>
@@ -108,7 +113,7 @@ __device__ __forceinline__ void twiddle16(cx<T> (&v)[16], cx<T> w) {
 
 // in: v[n1] = x[256*n1 + tid]; out: v[k3] = X[tid + 256*k3].  tw[j] = exp(-2 pi i j/4096), j<256
 template <bool INV, typename T>
-__device__ __forceinline__ void fft4096(cx<T> (&v)[16], cx<T>* lds, const cx<T>* __restrict__ tw,
+__device__ __forceinline__ void fft4096(cx<T> (&v)[16], T* lds, const cx<T>* __restrict__ tw,
                                         int tid) {
   // pass 1: DFT16 over n1, twiddle W_4096^{tid*k1}
   dft16<INV>(v);
@@ -117,30 +122,43 @@ __device__ __forceinline__ void fft4096(cx<T> (&v)[16], cx<T>* lds, const cx<T>*
     if (INV) w.y = -w.y;
     twiddle16(v, w);
   }
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) lds[k1 * 256 + tid] = v[k1];
-  __syncthreads();
-  // pass 2: thread (k1, n3): DFT16 over n2 of E1[k1][16*n2 + n3], twiddle W_256^{n3*k2}
+  // exchange 1: E1[k1][m = tid]  ->  thread (k1 = tid>>4, n3 = tid&15) reads m = 16*n2 + n3
   {
     const int k1 = tid >> 4, n3 = tid & 15;
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) v[n2] = lds[k1 * 256 + 16 * n2 + n3];
+    for (int k = 0; k < 16; ++k) lds[k * RA + tid] = v[k].x;
     __syncthreads();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2].x = lds[k1 * RA + 16 * n2 + n3];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[k * RA + tid] = v[k].y;
+    __syncthreads();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2].y = lds[k1 * RA + 16 * n2 + n3];
+    __syncthreads();
+    // pass 2: DFT16 over n2, twiddle W_256^{n3*k2}
     dft16<INV>(v);
     cx<T> w = tw[16 * n3];
     if (INV) w.y = -w.y;
     twiddle16(v, w);
+    // exchange 2: E2[k1][n3][k2] -> thread (k1' = tid&15, k2' = tid>>4) reads over n3
+    const int q1 = tid & 15, q2 = tid >> 4;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) lds[k1 * RB + n3 * 17 + k2] = v[k2];
-  }
-  __syncthreads();
-  // pass 3: thread (k1 = tid&15, k2 = tid>>4): DFT16 over n3 -> k3
-  {
-    const int k1 = tid & 15, k2 = tid >> 4;
+    for (int k2 = 0; k2 < 16; ++k2) lds[k1 * RB + n3 * 17 + k2] = v[k2].x;
+    __syncthreads();
 #pragma unroll
-    for (int n3 = 0; n3 < 16; ++n3) v[n3] = lds[k1 * RB + n3 * 17 + k2];
-    dft16<INV>(v);
+    for (int j = 0; j < 16; ++j) v[j].x = lds[q1 * RB + j * 17 + q2];
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) lds[k1 * RB + n3 * 17 + k2] = v[k2].y;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j].y = lds[q1 * RB + j * 17 + q2];
+    __syncthreads();
   }
+  // pass 3: DFT16 over n3 -> k3
+  dft16<INV>(v);
 }
 
 template <typename T>
@@ -149,7 +167,7 @@ __global__ void __launch_bounds__(256) fir_fused(const T* __restrict__ in, int64
                                                  const cx<T>* __restrict__ hspec,
                                                  const cx<T>* __restrict__ tw, int64_t n, int M,
                                                  int K, int lead) {
-  __shared__ __attribute__((aligned(16))) cx<T> lds[LDS_ELEMS];
+  __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
   const int tid = threadIdx.x;
   const int64_t pair = blockIdx.x, ch = blockIdx.y;
   const T* row = in + ch * in_stride;
@@ -168,7 +186,6 @@ __global__ void __launch_bounds__(256) fir_fused(const T* __restrict__ in, int64
   fft4096<false>(v, lds, tw, tid);
 #pragma unroll
   for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
-  __syncthreads();  // pass-3 reads of the forward transform are done
   fft4096<true>(v, lds, tw, tid);
 #pragma unroll
   for (int q3 = 0; q3 < 16; ++q3) {
