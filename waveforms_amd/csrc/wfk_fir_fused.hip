@@ -162,7 +162,10 @@ __device__ __forceinline__ void fft4096(cx<T> (&v)[16], T* lds, const cx<T>* __r
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) fir_fused(const T* __restrict__ in, int64_t in_stride,
+#ifndef WFK_FIR_WAVES
+#define WFK_FIR_WAVES 3   // 3 workgroups per CU (138 VGPRs fp64); 4 spills and measured slower
+#endif
+__global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restrict__ in, int64_t in_stride,
                                                  T* __restrict__ out, int64_t out_stride,
                                                  const cx<T>* __restrict__ hspec,
                                                  const cx<T>* __restrict__ tw, int64_t n, int M,
