@@ -38,9 +38,12 @@ def random_pulse(rng, scale):
         p = wf.mollifier(w)
     if rng.random() < 0.8:
         f = rng.uniform(-3, 3) / scale
+        no_d = kind == 4    # the DRAG primitive has no derivative rule (nor upstream)
         I, Q = wf.mixing(p, freq=f, phase=rng.uniform(0, 6),
-                         DRAGScaling=None if rng.random() < 0.4 else rng.uniform(-0.05, 0.05) * scale,
-                         block_freq=None if rng.random() < 0.8 else f + rng.uniform(0.5, 2) / scale)
+                         DRAGScaling=None if (no_d or rng.random() < 0.4)
+                         else rng.uniform(-0.05, 0.05) * scale,
+                         block_freq=None if (no_d or rng.random() < 0.8)
+                         else f + rng.uniform(0.5, 2) / scale)
         p = I if rng.random() < 0.5 else Q
     if rng.random() < 0.3:
         p = p * wf.cos(rng.uniform(0.5, 4) / scale, rng.uniform(0, 6))
