@@ -208,6 +208,30 @@ def main():
                             'traffic': traffic, 'kernel': 'fir_fused', 'kernel_ms': fir_ms,
                             'algorithmic_bytes_per_launch': fb,
                             'sampler_kernel_ms': kern_ms}
+    if name == 'sampler256' and world == 1 and not args.no_cpu_baseline:
+        # C4 = this workload followed by the 1024-tap FIR stage: time the FIR kernel on the
+        # buffer just sampled so that the one default line carries both stages
+        from waveforms_amd.distortion import FirStage
+        from waveforms_amd import workloads as wl
+        fst = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
+        out2 = torch.empty_like(out)
+        for _ in range(2):
+            fst.apply_torch(out, out2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fst.apply_torch(out, out2)
+        e1.record()
+        torch.cuda.synchronize()
+        fir_ms = e0.elapsed_time(e1) / 5
+        line['also'] = {
+            'c4_fir_kernel_ms': fir_ms,
+            'c4_fir_frac_of_hbm_peak': 2 * algo_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'c4_step_ms': kern_ms + fir_ms,
+            'c4_msamples_per_s': bs.n_channels * bs.n / ((kern_ms + fir_ms) * 1e-3) / 1e6,
+            'note': 'C4 (BASELINE configs[3]) = sampler256 + 1024-tap FIR (fused LDS-FFT kernel)'}
+        del out2
+        fst.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, outs = cpu_baseline(chans, grid)
         line['cpu_baseline'] = base
