@@ -131,3 +131,23 @@ def test_malformed_programs_are_rejected():
         _engine.Plan(prog, grid=grid)
     with pytest.raises(_engine.EngineError):
         _engine.Plan(good, grid=_flatten.wfk_grid(0.0, -1.0, 10, 0, 0.0))
+
+
+def test_plain_c_consumer(tmp_path):
+    """include/wfk.h is consumable from plain C (gcc), no Python/torch/HIP headers."""
+    import subprocess
+    exe = tmp_path / 'abi_smoke'
+    libdir = os.path.join(ROOT, 'waveforms_amd', 'csrc')
+    subprocess.run(['gcc', '-std=c11', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'c_abi', 'abi_smoke.c'), '-o', str(exe),
+                    '-L', libdir, '-lwfk_hip', '-lm', f'-Wl,-rpath,{libdir}'], check=True)
+    torch_lib = ''
+    try:   # same runtime-loading order as _engine.lib(): torch's bundled HIP runtime first
+        import torch
+        torch_lib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    except Exception:
+        pass
+    env = dict(os.environ, LD_LIBRARY_PATH=torch_lib + ':' + os.environ.get('LD_LIBRARY_PATH', ''))
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert 'abi_smoke' in r.stdout
