@@ -18,6 +18,7 @@ Outputs
   tests/golden/big.npz            C2 / C3 / C4: strided subsets, piece indices, sums
   tests/golden/fir.npz            distortion.predistort(sig, ker=...) vectors
   tests/golden/iir.npz            sample(filters=...) and predistort(filters=...) vectors
+  tests/golden/edges.npz          wav(x) on empty / single / off-support / non-uniform x
 """
 import json
 import os
@@ -86,6 +87,16 @@ def main():
 
     gold = os.path.join(REPO, 'tests', 'golden')
     os.makedirs(gold, exist_ok=True)
+
+    # ---- edge inputs of __call__: empty / single / off-support / non-uniform x ----
+    edges = {}
+    for name, (build, xs) in cases.edge_cases().items():
+        w = build(ref)
+        for k, x in enumerate(xs):
+            edges[f'{name}.{k}'] = np.asarray(w(x))
+    np.savez_compressed(os.path.join(gold, 'edges.npz'), **edges)
+    if sys.argv[1:] == ['edges']:          # regenerate this fixture only
+        return
 
     frontend, samples = {}, {}
     for name, (build, grid) in cases.CASES.items():

@@ -233,3 +233,67 @@ def spectral_input(i):
     n = spectral_cases()[i][0]
     rng = np.random.default_rng(900 + i)
     return np.cumsum(rng.normal(size=n)) / 30 + rng.normal(size=n) * 0.01
+
+
+# ---- edge inputs for Waveform.__call__ / WaveVStack.__call__ (tests/test_gpu_edges.py) ----
+def _edge_pulse(ns):
+    return (ns.gaussian(2.0) >> 1.0) * ns.cos(9.0) + 0.25 * ns.square(3.0, edge=0.4)
+
+
+def _edge_aligned(ns):
+    return (ns.square(2.0) >> 1.0) * ns.cos(5) + (ns.square(1.0) >> 3.5) * ns.gaussian(1.0)
+
+
+def _edge_tiny_pieces(ns):
+    w = ns.zero()
+    for k in range(300):
+        w = w + ((ns.square(0.01) >> (0.01 * k + 0.005)) * (0.1 + 0.01 * k)) * ns.cos(1.0 + k)
+    return w
+
+
+def _edge_complex(ns):
+    return (ns.gaussian(1.5) >> 0.5) * ns.exp(2j * pi * 1.3) * (0.5 - 0.25j)
+
+
+def _edge_clip(ns):
+    w = 3 * _edge_pulse(ns)
+    w.min, w.max = -0.5, 0.75
+    return w
+
+
+def _edge_scaled(scale):
+    def build(ns):
+        return (ns.gaussian(20 * scale) >> (60 * scale)) * ns.cos(2 * pi * 0.21 / scale, 0.3) \
+            + 0.5 * ((ns.cosPulse(30 * scale) >> (150 * scale)) * ns.sin(2 * pi * 0.05 / scale))
+    return build
+
+
+def _edge_xs():
+    rng = np.random.default_rng(2024)
+    rnd = np.sort(rng.uniform(-6, 6, 3001))
+    dup = np.sort(np.concatenate([rnd[::7], rnd[::7], [-0.5, -0.5, 2.5, 2.5, 1.0]]))
+    return [np.array([]), np.array([0.7]), np.array([1e9]), np.array([-1e9]),
+            np.linspace(50, 60, 1001), np.linspace(-90, -80, 77),
+            np.linspace(-6, 6, 5001), rnd, dup,
+            np.linspace(-6, 6, 2), np.linspace(-6, 6, 63), np.linspace(-6, 6, 65),
+            np.linspace(-6, 6, 1025), np.linspace(-6, 6, 16 * 1024 + 1)]
+
+
+def edge_cases():
+    """name -> (builder(ns), [x arrays]); x arrays are sorted but not always uniform."""
+    xs = _edge_xs()
+    out = {
+        'pulse': (_edge_pulse, xs),
+        'vstack': (lambda ns: ns.WaveVStack([_edge_pulse(ns), ns.sin(3) * ns.square(2)]) * 0.5 + 0.125, xs),
+        'aligned': (_edge_aligned, [np.linspace(0, 8, 8 * 64 + 1), np.linspace(0, 8, 9),
+                                    np.array([0.0, 2.0, 2.0, 3.0, 4.0, 4.0])]),
+        'tiny_pieces': (_edge_tiny_pieces, [np.linspace(0, 3, 301), np.linspace(0, 3, 30001)]),
+        'complex': (_edge_complex, xs[:6] + [np.linspace(-3, 3, 65), np.linspace(-3, 3, 1025)]),
+        'clip': (_edge_clip, xs[6:9]),
+        'carrier_only': (lambda ns: ns.cos(3.0, 0.2) * 0.5, xs[6:9]),
+        'step_exp': (lambda ns: ns.step(0.0) * ns.exp(-0.5), xs[6:9]),
+        'neg_half': (lambda ns: (1 - ns.step(0.0)) * ns.sin(2.0), xs[6:9]),
+    }
+    for scale in (1e-9, 1e-6, 1e3):
+        out[f'scaled_{scale:g}'] = (_edge_scaled(scale), [np.linspace(0, 200 * scale, 20001)])
+    return out

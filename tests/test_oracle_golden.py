@@ -97,3 +97,19 @@ def test_fir_oracles(i):
     assert np.max(np.abs(np_oracle.predistort_fir(sig, ker) - want)) <= 1e-13 * scale
     if len(sig) * len(ker) <= 5e7:
         assert np.max(np.abs(c_oracle.fir(sig, ker) - want)) <= 1e-12 * scale
+
+
+EDGES = golden_io.npz('edges.npz')
+
+
+@pytest.mark.parametrize('name', sorted(cases.edge_cases()))
+def test_oracles_on_edge_inputs(name):
+    """empty / single / off-support / duplicated / non-uniform x against the real reference."""
+    build, xs = cases.edge_cases()[name]
+    w = build(wf)
+    prog = _flatten.flatten([w])
+    for k, x in enumerate(xs):
+        want = EDGES[f'{name}.{k}']
+        close(np_oracle.call(w, x), want, rel=1e-14)
+        got = c_oracle.eval_tlist(prog, x, want.dtype == np.complex128)[0]
+        close(got, want)

@@ -19,7 +19,7 @@ def _check_function_lib(function_lib):
     if function_lib is not None:
         raise NotImplementedError(
             'function_lib overrides are Python callables and cannot run on the '
-            'device; only the built-in primitive ids 1..15 are implemented')
+            'device; only the built-in primitive ids 1..17 are implemented')
 
 
 def _as_time_array(x):
