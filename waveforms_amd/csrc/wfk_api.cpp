@@ -184,6 +184,7 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   a.ch_stride = ch_stride;
   a.n = p->h.n;
   a.chunks_per_ch = p->h.chunks_per_ch;
+  a.n_chunks = p->h.chunks_per_ch * p->h.n_channels;
   a.tiles_per_chunk = p->h.tiles_per_chunk;
   a.accumulate = (flags & WFK_ACCUMULATE) ? 1 : 0;
   a.t0 = p->h.t0;

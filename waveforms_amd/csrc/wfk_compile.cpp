@@ -571,10 +571,12 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   if (H.lean) H.tile = 64 * H.ns;
   int64_t tiles_per_ch = (ax.n + H.tile - 1) / H.tile;
   int64_t total_tiles = tiles_per_ch * P->n_channels;
-  // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves, and longer
-  // chunks amortise the exact reseeds (measured: C2 best at 4 tiles, headline at 32)
+  // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves.  Longer
+  // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
+  // any moment compact, which is what the HBM write rate depends on:
+  // measured best at 8 tiles (= one seed per chunk) on the headline config, 4 on C2.
   int64_t tpc = total_tiles / (H.lean ? 2048 : 8192);
-  H.tiles_per_chunk = (int32_t)std::min<int64_t>(H.lean ? 32 : 16, std::max<int64_t>(1, tpc));
+  H.tiles_per_chunk = (int32_t)std::min<int64_t>(H.lean ? 8 : 16, std::max<int64_t>(1, tpc));
   if (const char* e = std::getenv("WFK_TPC")) {   // tuning override
     int v = std::atoi(e);
     if (v >= 1 && v <= 64) H.tiles_per_chunk = v;

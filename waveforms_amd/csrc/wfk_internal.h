@@ -96,6 +96,7 @@ struct KArgs {
   int64_t ch_stride;           // elements
   int64_t n;                   // samples per channel
   int64_t chunks_per_ch;
+  int64_t n_chunks;            // n_channels * chunks_per_ch; the grid is rounded up to 8 * ceil(n_chunks / 8)
   int32_t tiles_per_chunk;     // workgroup tiles per workgroup
   int32_t accumulate;
   double t0, step, last;

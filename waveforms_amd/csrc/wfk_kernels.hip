@@ -32,6 +32,41 @@
 namespace {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// 64-bit values the compiler cannot prove wave-uniform (anything downstream of a 64-bit
+// division, which only exists on the VALU): pin them to SGPRs.  What hangs off them then
+// becomes scalar: s_load instead of global_load (lgkmcnt, so a wait for it does NOT also
+// wait for every store in flight, which on gfx9 share vmcnt with the vector loads), and
+// SGPR-base + 32-bit-offset addressing for the output stores.
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// Plan tables (pieces, channels) are never written by a kernel; reading them through the
+// constant address space lets the backend keep using s_load after the kernel's first store
+// (for plain global pointers it must assume the stores may have clobbered them).
+#define WFK_CONST __attribute__((address_space(4)))
+template <typename V>
+__device__ __forceinline__ V cload(const void* base, int byte_off) {
+  return *reinterpret_cast<const WFK_CONST V*>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+__device__ __forceinline__ DevPiece load_piece(const DevPiece* p) {
+  DevPiece P;
+  P.start = cload<int64_t>(p, offsetof(DevPiece, start));
+  P.stop = cload<int64_t>(p, offsetof(DevPiece, stop));
+  P.par_off = cload<int64_t>(p, offsetof(DevPiece, par_off));
+  P.n_blk = cload<int32_t>(p, offsetof(DevPiece, n_blk));
+  P.flags = cload<int32_t>(p, offsetof(DevPiece, flags));
+  P.first_len = cload<int32_t>(p, offsetof(DevPiece, first_len));
+  P.pad = 0;
+  return P;
+}
+template <typename P>
+__device__ __forceinline__ P* uniptr(P* p) {
+  // rebuilt as a GLOBAL pointer, or the integer round trip degrades the accesses to flat_*
+  using G = __attribute__((address_space(1))) P*;
+  return (P*)reinterpret_cast<G>(uni64(reinterpret_cast<int64_t>(p)));
+}
 
 // Compile-time unrolled loop.  Register arrays are only ever indexed with constants, so
 // SROA splits them into independent scalars up front (a `#pragma unroll` loop indexes them
@@ -570,6 +605,19 @@ __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, 
     store_tile_impl<T, CPLX, NS, false>(a, C, P, tr, tc, w0, lane, acc, acci);
 }
 
+// XCD-aware workgroup -> chunk map.  Workgroups are dealt round-robin to the 8 XCDs
+// (workgroup b runs on XCD b % 8), so a plain chunk = b makes every XCD touch every region
+// of the output at once.  Give XCD x the x-th contiguous eighth of the chunk list instead,
+// walked in order: each XCD's L2 / TLB then sees one compact, linearly advancing write
+// window (tools/store_pattern6.hip: 5.86 -> 6.26 TB/s for this walk with stores only).
+// Returns -1 for the padding workgroups of the rounded-up grid.
+__device__ __forceinline__ int64_t xcd_chunk(const KArgs& a) {
+  const int64_t b = blockIdx.x;
+  const int64_t per = (a.n_chunks + 7) >> 3;
+  const int64_t c = (b & 7) * per + (b >> 3);
+  return c < a.n_chunks ? c : -1;
+}
+
 // ---- lean kernel: fully fused plans ----------------------------------------------------
 // One wave per workgroup owns `tiles_per_chunk` CONSECUTIVE wave tiles of one channel.
 // Per piece (<= WFK_LEAN_OPS fused ops, one parameter block) the per-lane op state
@@ -590,28 +638,35 @@ __global__ void __launch_bounds__(64, WFK_LEAN_WAVES) wfk_sample_lean(const KArg
   using OutC = typename OutOps<T>::Cplx;
 
   const int lane = threadIdx.x;
-  const int64_t chunk = blockIdx.x;
-  const int ch = (int)(chunk / a.chunks_per_ch);
-  const int64_t cc = chunk - (int64_t)ch * a.chunks_per_ch;
+  const int64_t chunk = xcd_chunk(a);
+  if (chunk < 0) return;
+  const int ch = uni((int)(chunk / a.chunks_per_ch));
+  const int64_t cc = uni64(chunk - (int64_t)ch * a.chunks_per_ch);
   const DevChannel C = a.channels[ch];
-  int p = a.chunk_first[chunk];
+  int p = uni(a.chunk_first[chunk]);
+  DevPiece cur = load_piece(a.pieces + p);
   int64_t staged = -1;
   int state_piece = -1;       // piece whose op state sits in LDS ...
   int64_t state_w0 = -1;      // ... valid for the tile that starts here
   int since_seed = 0;
 
-  OutR* outr = reinterpret_cast<OutR*>(a.out) + (int64_t)ch * a.ch_stride;
-  OutC* outc = reinterpret_cast<OutC*>(a.out) + (int64_t)ch * a.ch_stride;
+  OutR* const outr = uniptr(reinterpret_cast<OutR*>(a.out) + (int64_t)ch * a.ch_stride);
+  OutC* const outc = uniptr(reinterpret_cast<OutC*>(a.out) + (int64_t)ch * a.ch_stride);
 
   for (int tt = 0; tt < a.tiles_per_chunk; ++tt) {
-    const int64_t w0 = (cc * a.tiles_per_chunk + tt) * WT;
+    const int64_t w0 = uni64((cc * a.tiles_per_chunk + tt) * WT);
     if (w0 >= a.n) break;
     const int64_t w1 = w0 + WT < a.n ? w0 + WT : a.n;
     const int64_t j0 = w0 + lane;
-    while (p < C.piece_end - 1 && a.pieces[p].stop <= w0) ++p;
+    // the piece record stays in SGPRs from tile to tile: a tile inside the current piece
+    // (the common case: pieces are ~100 tiles long) issues no table load at all
+    while (p < C.piece_end - 1 && cur.stop <= w0) {
+      p = uni(p + 1);
+      cur = load_piece(a.pieces + p);
+    }
 
-    for (int q = p; q < C.piece_end; ++q) {
-      const DevPiece P = a.pieces[q];
+    for (int q = p;;) {
+      const DevPiece P = cur;
       if (P.start >= w1) break;
       T acc[NS], acci[CPLX ? NS : 1];
       WFK_EACH(NS, k) acc[k] = (T)0; WFK_END
@@ -654,7 +709,13 @@ __global__ void __launch_bounds__(64, WFK_LEAN_WAVES) wfk_sample_lean(const KArg
         state_w0 = w0 + WT;
         ++since_seed;
       }
-      store_tile<T, CPLX, NS>(a, C, P, outr + w0, outc + w0, w0, lane, acc, acci);
+      // tile base pinned to SGPRs: the stores become `global_store v_lane_off, data, s[base]
+      // offset:k*512` (one address VGPR instead of a hoisted 64-bit pointer pair per store)
+      store_tile<T, CPLX, NS>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
+      if (P.stop >= w1 || q + 1 >= C.piece_end) break;   // the tile ends inside this piece
+      q = uni(q + 1);
+      cur = load_piece(a.pieces + q);
+      p = q;
     }
   }
 }
@@ -669,7 +730,8 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  const int64_t chunk = blockIdx.x;
+  const int64_t chunk = xcd_chunk(a);
+  if (chunk < 0) return;
   const int ch = (int)(chunk / a.chunks_per_ch);
   const int64_t cc = chunk - (int64_t)ch * a.chunks_per_ch;
   const DevChannel C = a.channels[ch];
@@ -765,7 +827,8 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
 
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, bool lean,
                        bool generic, bool direct, void* stream, std::string& err) {
-  const int64_t blocks = (int64_t)n_channels * a.chunks_per_ch;
+  if (a.n_chunks != (int64_t)n_channels * a.chunks_per_ch) { err = "n_chunks mismatch"; return WFK_EINVAL; }
+  const int64_t blocks = ((a.n_chunks + 7) >> 3) << 3;   // see xcd_chunk()
   if (blocks == 0) return WFK_OK;
   if (blocks > 0x7fffffffLL) { err = "grid too large"; return WFK_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
