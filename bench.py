@@ -150,6 +150,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Untimed device pre-warm, before the W warm-up steps: the first ~40 ms of launches after
+    # idle run ~10% slower (memory/fabric clocks still ramping; measured per launch in
+    # tools/placement_probe2.py), and W = 3 steps of a 3 ms kernel end well inside that ramp.
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while n_pre < 10 or time.perf_counter() - t_pre < 0.25:
+        step()
+        n_pre += 1
+        if n_pre % 10 == 0:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()

@@ -60,8 +60,8 @@ int main() {
   CK(hipFuncSetAttribute((const void*)k_chunk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)k_chunk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const long n_tiles = n / 1024;
-  for (int tpc : {4, 8, 32}) {
-    for (int wpc : {8, 12, 32}) {
+  for (int tpc : {1, 2, 4, 8, 32}) {
+    for (int wpc : {4, 8, 12, 32}) {
       const unsigned lds = wpc >= 32 ? 0 : ((160 * 1024 / wpc) & ~255u);
       const long n_chunks = (n_tiles + tpc - 1) / tpc;
       const unsigned g = (unsigned)(((n_chunks + 7) / 8) * 8);
