@@ -732,25 +732,27 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
   const int wave = uni(threadIdx.x >> 6);
   const int64_t chunk = xcd_chunk(a);
   if (chunk < 0) return;
-  const int ch = (int)(chunk / a.chunks_per_ch);
-  const int64_t cc = chunk - (int64_t)ch * a.chunks_per_ch;
+  // indices and bases pinned to SGPRs, plan tables read with s_load: see uni64()/cload()
+  const int ch = uni((int)(chunk / a.chunks_per_ch));
+  const int64_t cc = uni64(chunk - (int64_t)ch * a.chunks_per_ch);
   const DevChannel C = a.channels[ch];
-  int p = a.chunk_first[chunk];
+  int p = uni(a.chunk_first[chunk]);
   int64_t staged = -1;
 
-  OutR* outr = reinterpret_cast<OutR*>(a.out) + (int64_t)ch * a.ch_stride;
-  OutC* outc = reinterpret_cast<OutC*>(a.out) + (int64_t)ch * a.ch_stride;
+  OutR* const outr = uniptr(reinterpret_cast<OutR*>(a.out) + (int64_t)ch * a.ch_stride);
+  OutC* const outc = uniptr(reinterpret_cast<OutC*>(a.out) + (int64_t)ch * a.ch_stride);
 
   for (int tt = 0; tt < a.tiles_per_chunk; ++tt) {
-    const int64_t g0 = (cc * a.tiles_per_chunk + tt) * TILE;
+    const int64_t g0 = uni64((cc * a.tiles_per_chunk + tt) * TILE);
     if (g0 >= a.n) break;
     const int64_t g1 = g0 + TILE < a.n ? g0 + TILE : a.n;
-    const int64_t w0 = g0 + (int64_t)wave * WT;
+    const int64_t w0 = uni64(g0 + (int64_t)wave * WT);
     const int64_t j0 = w0 + lane;
-    while (p < C.piece_end - 1 && a.pieces[p].stop <= g0) ++p;
+    while (p < C.piece_end - 1 && cload<int64_t>(a.pieces + p, offsetof(DevPiece, stop)) <= g0)
+      p = uni(p + 1);
 
-    for (int q = p; q < C.piece_end; ++q) {
-      const DevPiece P = a.pieces[q];
+    for (int q = p; q < C.piece_end; q = uni(q + 1)) {
+      const DevPiece P = load_piece(a.pieces + q);
       if (P.start >= g1) break;
       const bool active = w0 < a.n && P.start < w0 + WT && P.stop > w0;  // wave-uniform
 
@@ -804,7 +806,8 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
         if (b + 1 < P.n_blk) len = (int)a.params[off];
       }
 
-      if (active) store_tile<T, CPLX, NS>(a, C, P, outr + w0, outc + w0, w0, lane, acc, acci);
+      if (active)
+        store_tile<T, CPLX, NS>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
     }
   }
 }
