@@ -8,12 +8,16 @@
 //     y = b0*x + z[0];   z[i] = b[i+1]*x - a[i+1]*y + z[i+1];   z[ord-1] = b[ord]*x - a[ord]*y
 // The recurrence is sequential in time; it is linear, so rows are cut into blocks of LB
 // samples and solved in three phases (state dimension D = sum of section orders <= 16):
-//   A  iir_pass<false>: every block from ZERO state -> its local final state f_b
-//   B  iir_scan       : S_b = T*S_{b-1} + f_b over the blocks of a row, one wave per row,
-//                       Hillis-Steele steps with the precomputed powers T^(2^k) and a
-//                       per-lane table T^(l+1) for the carry (T = LB-step transition matrix,
-//                       computed on the host by running the homogeneous system)
-//   C  iir_pass<true> : every block again from its true initial state S_{b-1}; writes y
+//   A  iir_pass<false>: every block from ZERO state -> its local final state f_b; the wave
+//                       (= one GROUP of 64 consecutive blocks) then scans them in registers,
+//                       v_l = sum_{j<=l} T^(l-j) f_j  (Hillis-Steele, T^(2^k) tables), and
+//                       writes the group-local prefixes v_l and the group total v_63
+//   B  iir_scan       : true state at the START of every group from the group totals: the
+//                       same scan one level up (U = T^64), one wave per row; 1/64 of the
+//                       blocks, so its serial part no longer shows (it was 28% of the stage)
+//   C  iir_pass<true> : every block again, from its true initial state
+//                       S = v_{l-1} + T^l * (state at its group's start); writes y
+// (T = LB-step transition matrix, computed on the host by running the homogeneous system.)
 // HBM traffic 24 B/sample fp64 (x read twice, y written once) vs 16 algorithmic.
 // Lanes own blocks; a wave moves 64x64-sample tiles through LDS (transposed) so that
 // global loads/stores are 512-byte contiguous per instruction.  State is always double.
@@ -77,15 +81,84 @@ __device__ __forceinline__ double iir_step_t(const IirCoef& c, double x, double 
   }
 }
 
+// (sh + sl) += (th + tl) * x in double-double (TwoProd via fma, TwoSum)
+__device__ __forceinline__ void dd_acc(double& sh, double& sl, double th, double tl, double x) {
+  const double p = th * x;
+  const double e = fma(th, x, -p) + tl * x;
+  const double s = sh + p;
+  const double bb = s - sh;
+  sl += ((sh - (s - bb)) + (p - bb)) + e;
+  sh = s;
+}
+
+// Inclusive scan over the 64 lanes of a wave: v_l <- sum_{j<=l} M^(l-j) v_j, with
+// pw[k] = M^(2^k) as (hi, lo) pairs.  DD > 0: compile-time state dimension (registers).
+// M has entries ~1e5 that cancel against each other when applied to a state (see the host
+// note): the mat-vecs therefore run in double-double, so a block boundary perturbs the
+// state no more than one step of the sequential filter does.
+template <int DD>
+__device__ __forceinline__ void wave_scan(double (&v)[IIR_MAXD], const double* __restrict__ pw,
+                                          int D_rt, int lane) {
+  const int D = DD > 0 ? DD : D_rt;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int d = 1 << k;
+    double u[IIR_MAXD];
+#pragma unroll
+    for (int i = 0; i < (DD > 0 ? DD : IIR_MAXD); ++i) u[i] = i < D ? __shfl_up(v[i], d) : 0.0;
+    if (lane >= d) {
+      const double* M = pw + (int64_t)k * D * D * 2;
+      double nv[IIR_MAXD];
+#pragma unroll
+      for (int i = 0; i < (DD > 0 ? DD : IIR_MAXD); ++i) {
+        if (i < D) {
+          double sh = v[i], sl = 0.0;
+#pragma unroll
+          for (int j = 0; j < (DD > 0 ? DD : IIR_MAXD); ++j)
+            if (j < D) dd_acc(sh, sl, M[(i * D + j) * 2], M[(i * D + j) * 2 + 1], u[j]);
+          nv[i] = sh + sl;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < (DD > 0 ? DD : IIR_MAXD); ++i)
+        if (i < D) v[i] = nv[i];
+    }
+  }
+}
+
+// v += M * c in double-double; M = D x D (hi, lo) pairs
+template <int DD>
+__device__ __forceinline__ void dd_matvec_add(double (&v)[IIR_MAXD], const double* __restrict__ M,
+                                              const double (&c)[IIR_MAXD], int D_rt) {
+  const int D = DD > 0 ? DD : D_rt;
+  double nv[IIR_MAXD];
+#pragma unroll
+  for (int i = 0; i < (DD > 0 ? DD : IIR_MAXD); ++i) {
+    if (i < D) {
+      double sh = v[i], sl = 0.0;
+#pragma unroll
+      for (int j = 0; j < (DD > 0 ? DD : IIR_MAXD); ++j)
+        if (j < D) dd_acc(sh, sl, M[(i * D + j) * 2], M[(i * D + j) * 2 + 1], c[j]);
+      nv[i] = sh + sl;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (DD > 0 ? DD : IIR_MAXD); ++i)
+    if (i < D) v[i] = nv[i];
+}
+
 // One wave per 64 consecutive blocks of one row.  WRITE=false: zero initial state, emit the
 // final state of each block.  WRITE=true: initial state from `init`, write y (+post).
 template <typename T, bool WRITE, int NSEC, int ORD>
 __global__ void __launch_bounds__(64) iir_pass(const IirCoef c, const T* __restrict__ in,
                                                int64_t in_stride, T* __restrict__ out,
                                                int64_t out_stride, double* __restrict__ state,
-                                               const double* __restrict__ init,
+                                               double* __restrict__ grp,
+                                               const double* __restrict__ pw,
+                                               const double* __restrict__ lanep,
                                                double* __restrict__ zf, int64_t n, int64_t nblk,
                                                double pre_sub, double post_add) {
+  constexpr int DD = NSEC * ORD;   // compile-time state dimension (0: runtime-shaped)
   __shared__ T tile[64][IIR_SEG + 1];
   const int lane = threadIdx.x;
   const int64_t row = blockIdx.y;
@@ -97,9 +170,23 @@ __global__ void __launch_bounds__(64) iir_pass(const IirCoef c, const T* __restr
   double z[IIR_MAXD];
 #pragma unroll
   for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
+  const int64_t ngrp = gridDim.x;
   if (WRITE && blk < nblk) {
-    const double* s = init + (row * nblk + blk) * D;
-    for (int i = 0; i < D; ++i) z[i] = s[i];
+    // true initial state: the state at the group's start (phase B) pushed through the l blocks
+    // before this one, plus the group-local prefix of the previous block (phase A)
+    double carry[IIR_MAXD];
+#pragma unroll
+    for (int i = 0; i < IIR_MAXD; ++i) carry[i] = i < D ? grp[(row * ngrp + blockIdx.x) * D + i] : 0.0;
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i) z[i] = carry[i];
+    } else {
+      const double* s = state + (row * nblk + blk - 1) * D;
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i)
+        if (i < D) z[i] = s[i];
+      dd_matvec_add<DD>(z, lanep + (int64_t)(lane - 1) * D * D * 2, carry, D);
+    }
   }
   const int nact = (int)(nblk - blk0 < 64 ? nblk - blk0 : 64);   // active blocks in this wave
   constexpr int RPI = 64 / IIR_SEG;      // tile rows (blocks) moved per wave instruction
@@ -149,32 +236,30 @@ __global__ void __launch_bounds__(64) iir_pass(const IirCoef c, const T* __restr
       __syncthreads();
     }
   }
-  if (blk < nblk) {
-    if (!WRITE) {
+  if (!WRITE) {
+    // scan the 64 local final states of this group in registers (lanes past the last block
+    // hold zeros and nothing downstream reads their results)
+    wave_scan<DD>(z, pw, D, lane);
+    if (blk < nblk) {
       double* s = state + (row * nblk + blk) * D;
-      for (int i = 0; i < D; ++i) s[i] = z[i];
-    } else if (blk == nblk - 1 && zf) {
-      for (int i = 0; i < D; ++i) zf[row * D + i] = z[i];
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i)
+        if (i < D) s[i] = z[i];
     }
+    if (lane == 63) {
+      double* s = grp + (row * ngrp + blockIdx.x) * D;
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i)
+        if (i < D) s[i] = z[i];
+    }
+  } else if (blk == nblk - 1 && zf) {
+    for (int i = 0; i < D; ++i) zf[row * D + i] = z[i];
   }
 }
 
-// (sh + sl) += (th + tl) * x in double-double (TwoProd via fma, TwoSum)
-__device__ __forceinline__ void dd_acc(double& sh, double& sl, double th, double tl, double x) {
-  const double p = th * x;
-  const double e = fma(th, x, -p) + tl * x;
-  const double s = sh + p;
-  const double bb = s - sh;
-  sl += ((sh - (s - bb)) + (p - bb)) + e;
-  sh = s;
-}
-
-// Phase B: in place, state[row][b] (local final states f_b) -> init[row][b] = S_{b-1}, the
-// true state at the START of block b.  pw: [7][D][D][2] = T^(2^k) as (hi, lo) pairs,
-// lanep: [64][D][D][2] = T^(l+1).  zi: [row][D] or null.
-// T has entries ~1e5 that cancel against each other when applied to a state (see the host
-// note): the mat-vecs therefore run in double-double, so a block boundary perturbs the
-// state no more than one step of the sequential filter does.
+// Phase B: in place, items[row][g] (group totals) -> the true state at the START of group g.
+// pw: [7][D][D][2] = U^(2^k) as (hi, lo) pairs, lanep: [64][D][D][2] = U^(l+1), U = T^64.
+// zi: [row][D] or null.  One wave per row, 64 groups (= 4096 blocks = 8.4M samples) per step.
 __global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const double* __restrict__ pw,
                                                const double* __restrict__ lanep,
                                                const double* __restrict__ zi, int64_t nblk, int D) {
@@ -264,9 +349,13 @@ struct wfk_iir_plan {
   IirCoef c;
   int64_t n = 0, nblk = 0;
   int32_t batch = 0, kind = 0;
-  double* state = nullptr;   // [batch][nblk][D]
-  double* pw = nullptr;      // [7][D][D]
-  double* lanep = nullptr;   // [64][D][D]
+  int64_t ngrp = 0;          // groups of 64 blocks per row
+  double* state = nullptr;   // [batch][nblk][D]  group-local prefixes
+  double* grp = nullptr;     // [batch][ngrp][D]  group totals -> group start states
+  double* pw = nullptr;      // [7][D][D][2]   T^(2^k)
+  double* lanep = nullptr;   // [64][D][D][2]  T^(l+1)
+  double* pw2 = nullptr;     // the same for U = T^64
+  double* lanep2 = nullptr;
 };
 
 extern "C" {
@@ -274,8 +363,11 @@ extern "C" {
 int wfk_iir_plan_destroy(wfk_iir_plan* p) {
   if (!p) return WFK_OK;
   (void)hipFree(p->state);
+  (void)hipFree(p->grp);
   (void)hipFree(p->pw);
   (void)hipFree(p->lanep);
+  (void)hipFree(p->pw2);
+  (void)hipFree(p->lanep2);
   delete p;
   return WFK_OK;
 }
@@ -316,6 +408,7 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
   c.D = D;
   p->n = n; p->batch = batch; p->kind = kind;
   p->nblk = n > 0 ? (n + IIR_LB - 1) / IIR_LB : 0;
+  p->ngrp = (p->nblk + 63) / 64;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     (void)hipGetLastError();
@@ -332,29 +425,41 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     for (int k = 0; k < IIR_LB; ++k) quad_step(c, (quad)0, z);
     for (int r = 0; r < D; ++r) T[(size_t)r * D + i] = z[r];
   }
-  std::vector<double> pw((size_t)7 * D * D * 2), lanep((size_t)64 * D * D * 2);
   auto put = [](std::vector<double>& dst, size_t at, quad q) {   // quad -> (hi, lo)
     const double hi = (double)q;
     dst[at] = hi;
     dst[at + 1] = (double)(q - (quad)hi);
   };
-  std::vector<quad> cur = T, nxt;
-  for (int k = 0; k < 7; ++k) {
-    for (size_t e = 0; e < cur.size(); ++e) put(pw, ((size_t)k * D * D + e) * 2, cur[e]);
-    qmatmul(cur, cur, nxt, D);
-    cur = nxt;
-  }
-  cur = T;
-  for (int l = 0; l < 64; ++l) {
-    for (size_t e = 0; e < cur.size(); ++e) put(lanep, ((size_t)l * D * D + e) * 2, cur[e]);
-    qmatmul(cur, T, nxt, D);
-    cur = nxt;
-  }
+  // tables of a base matrix B: pw[k] = B^(2^k) (k < 7), lanep[l] = B^(l+1) (l < 64); returns B^64
+  auto tables = [&](const std::vector<quad>& B, std::vector<double>& pw, std::vector<double>& lanep) {
+    pw.assign((size_t)7 * D * D * 2, 0.0);
+    lanep.assign((size_t)64 * D * D * 2, 0.0);
+    std::vector<quad> cur = B, nxt;
+    for (int k = 0; k < 7; ++k) {
+      for (size_t e = 0; e < cur.size(); ++e) put(pw, ((size_t)k * D * D + e) * 2, cur[e]);
+      qmatmul(cur, cur, nxt, D);
+      cur = nxt;
+    }
+    cur = B;
+    std::vector<quad> last;
+    for (int l = 0; l < 64; ++l) {
+      for (size_t e = 0; e < cur.size(); ++e) put(lanep, ((size_t)l * D * D + e) * 2, cur[e]);
+      last = cur;
+      qmatmul(cur, B, nxt, D);
+      cur = nxt;
+    }
+    return last;
+  };
+  std::vector<double> pw, lanep, pw2, lanep2;
+  const std::vector<quad> U = tables(T, pw, lanep);   // U = T^64: one group
+  tables(U, pw2, lanep2);
+  auto upload = [](double** dst, const std::vector<double>& src) {
+    return hipMalloc(dst, src.size() * 8) == hipSuccess &&
+           hipMemcpy(*dst, src.data(), src.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  };
   bool ok = hipMalloc(&p->state, (size_t)batch * p->nblk * D * 8) == hipSuccess;
-  ok = ok && hipMalloc(&p->pw, pw.size() * 8) == hipSuccess;
-  ok = ok && hipMalloc(&p->lanep, lanep.size() * 8) == hipSuccess;
-  ok = ok && hipMemcpy(p->pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(p->lanep, lanep.data(), lanep.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMalloc(&p->grp, (size_t)batch * p->ngrp * D * 8) == hipSuccess;
+  ok = ok && upload(&p->pw, pw) && upload(&p->lanep, lanep) && upload(&p->pw2, pw2) && upload(&p->lanep2, lanep2);
   if (!ok) {
     wfk_iir_plan_destroy(p);
     return iir_fail(WFK_ENOMEM, "IIR buffer allocation failed");
@@ -370,14 +475,15 @@ int wfk_iir_state_dim(const wfk_iir_plan* p) { return p ? p->c.D : WFK_EINVAL; }
 template <typename T, int NSEC, int ORD>
 static void iir_launch_t(wfk_iir_plan* p, const void* in, int64_t is, void* out, int64_t os,
                          const double* zi, double* zf, double initial, hipStream_t s) {
-  const dim3 g((unsigned)((p->nblk + 63) / 64), (unsigned)p->batch);
+  const dim3 g((unsigned)p->ngrp, (unsigned)p->batch);
   hipLaunchKernelGGL((iir_pass<T, false, NSEC, ORD>), g, dim3(64), 0, s, p->c, (const T*)in, is,
-                     (T*)nullptr, (int64_t)0, p->state, (const double*)nullptr, (double*)nullptr,
+                     (T*)nullptr, (int64_t)0, p->state, p->grp, p->pw, p->lanep, (double*)nullptr,
                      p->n, p->nblk, initial, 0.0);
-  hipLaunchKernelGGL(iir_scan, dim3((unsigned)p->batch), dim3(64), 0, s, p->state, p->pw, p->lanep,
-                     zi, p->nblk, p->c.D);
+  hipLaunchKernelGGL(iir_scan, dim3((unsigned)p->batch), dim3(64), 0, s, p->grp, p->pw2, p->lanep2,
+                     zi, p->ngrp, p->c.D);
   hipLaunchKernelGGL((iir_pass<T, true, NSEC, ORD>), g, dim3(64), 0, s, p->c, (const T*)in, is,
-                     (T*)out, os, (double*)nullptr, p->state, zf, p->n, p->nblk, initial, initial);
+                     (T*)out, os, p->state, p->grp, p->pw, p->lanep, zf, p->n, p->nblk, initial,
+                     initial);
 }
 
 template <typename T>
