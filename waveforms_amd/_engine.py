@@ -15,7 +15,8 @@ import numpy as np
 from ._flatten import Program, wfk_grid, wfk_program
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libwfk_hip.so')
+# WFK_LIB: developer knob for A/B builds of the same library (tools/*_bench.py)
+LIB_PATH = os.environ.get('WFK_LIB') or os.path.join(_HERE, 'csrc', 'libwfk_hip.so')
 
 OUT_F64, OUT_F32, OUT_C128, OUT_C64 = 0, 1, 2, 3
 ACCUMULATE = 1

@@ -89,7 +89,7 @@ __device__ __forceinline__ void dft16(cx<T> (&v)[16]) {
     }
 }
 
-// v[k] *= w^k, k = 1..15 (w = base twiddle); powers by a short product tree
+// v[k] *= w^k, k = 1..15 (w = base twiddle)
 template <typename T>
 __device__ __forceinline__ void twiddle16(cx<T> (&v)[16], cx<T> w) {
   const cx<T> w2 = cmul(w, w), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
@@ -113,14 +113,12 @@ __device__ __forceinline__ void twiddle16(cx<T> (&v)[16], cx<T> w) {
 
 // in: v[n1] = x[256*n1 + tid]; out: v[k3] = X[tid + 256*k3].  tw[j] = exp(-2 pi i j/4096), j<256
 template <bool INV, typename T>
-__device__ __forceinline__ void fft4096(cx<T> (&v)[16], T* lds, const cx<T>* __restrict__ tw,
-                                        int tid) {
+__device__ __forceinline__ void fft4096(cx<T> (&v)[16], T* lds, cx<T> wa, cx<T> wb, int tid) {
   // pass 1: DFT16 over n1, twiddle W_4096^{tid*k1}
   dft16<INV>(v);
   {
-    cx<T> w = tw[tid];
-    if (INV) w.y = -w.y;
-    twiddle16(v, w);
+    if (INV) wa.y = -wa.y;
+    twiddle16(v, wa);
   }
   // exchange 1: E1[k1][m = tid]  ->  thread (k1 = tid>>4, n3 = tid&15) reads m = 16*n2 + n3
   {
@@ -139,9 +137,8 @@ __device__ __forceinline__ void fft4096(cx<T> (&v)[16], T* lds, const cx<T>* __r
     __syncthreads();
     // pass 2: DFT16 over n2, twiddle W_256^{n3*k2}
     dft16<INV>(v);
-    cx<T> w = tw[16 * n3];
-    if (INV) w.y = -w.y;
-    twiddle16(v, w);
+    if (INV) wb.y = -wb.y;
+    twiddle16(v, wb);
     // exchange 2: E2[k1][n3][k2] -> thread (k1' = tid&15, k2' = tid>>4) reads over n3
     const int q1 = tid & 15, q2 = tid >> 4;
 #pragma unroll
@@ -186,10 +183,12 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
     v[n1].x = (j1 >= 0 && j1 < n) ? row[j1] : (T)0;
     v[n1].y = (j2 >= 0 && j2 < n) ? row[j2] : (T)0;
   }
-  fft4096<false>(v, lds, tw, tid);
+  // base twiddles loaded up front with the window (one wait), not between the passes
+  const cx<T> wa = tw[tid], wb = tw[16 * (tid & 15)];
+  fft4096<false>(v, lds, wa, wb, tid);
 #pragma unroll
   for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
-  fft4096<true>(v, lds, tw, tid);
+  fft4096<true>(v, lds, wa, wb, tid);
 #pragma unroll
   for (int q3 = 0; q3 < 16; ++q3) {
     const int r = tid + 256 * q3 - (K - 1);

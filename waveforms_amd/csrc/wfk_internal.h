@@ -65,7 +65,10 @@
 // "lean" plans: every piece is one block of <= WFK_LEAN_OPS fused ops and nothing else.
 // They run on the wave-per-workgroup kernel that carries per-lane op state across tiles.
 #define WFK_LEAN_OPS 4
-#define WFK_LEAN_PAR 512      // doubles of LDS parameter buffer per wave
+// doubles of LDS parameter buffer per wave: header + 4 ops x (22 record + 34 table) = 232.
+// With the 8 KB of per-lane op state that makes 10 KB per wave = 16 waves per CU, which the
+// fp32 kernel (<= 128 VGPRs) uses: 2.11 -> 1.95 ms on 256 x 1e7 fp32 against 512 doubles.
+#define WFK_LEAN_PAR 256
 #define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles
 
 #define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)

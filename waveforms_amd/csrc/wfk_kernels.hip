@@ -629,7 +629,11 @@ template <typename T, bool CPLX, int NS>
 #ifndef WFK_LEAN_WAVES
 #define WFK_LEAN_WAVES 3   // occupancy target (waves per SIMD) for the register allocator
 #endif
-__global__ void __launch_bounds__(64, WFK_LEAN_WAVES) wfk_sample_lean(const KArgs a) {
+#ifndef WFK_LEAN_WAVES_F32
+#define WFK_LEAN_WAVES_F32 4   // fp32: 120 VGPRs, 10 KB LDS per wave -> 4 waves per SIMD (latency-bound kernel)
+#endif
+__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? WFK_LEAN_WAVES_F32 : WFK_LEAN_WAVES))
+wfk_sample_lean(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LEAN_PAR];
   __shared__ double s_c[WFK_LEAN_OPS][64], s_s[WFK_LEAN_OPS][64], s_g[WFK_LEAN_OPS][64],
       s_r[WFK_LEAN_OPS][64];
