@@ -18,6 +18,7 @@ Outputs
   tests/golden/big.npz            C2 / C3 / C4: strided subsets, piece indices, sums
   tests/golden/fir.npz            distortion.predistort(sig, ker=...) vectors
   tests/golden/iir.npz            sample(filters=...) and predistort(filters=...) vectors
+  tests/golden/design.npz         extractKernel / exp_decay_filter_old / factor_filter / stable_filter
   tests/golden/edges.npz          wav(x) on empty / single / off-support / non-uniform x
 """
 import json
@@ -87,6 +88,23 @@ def main():
 
     gold = os.path.join(REPO, 'tests', 'golden')
     os.makedirs(gold, exist_ok=True)
+
+    # ---- filter-design helpers of distortion.py (host-side, no sampling) ----------
+    import waveforms.distortion as rdist
+    design = {}
+    for i, (n, fs, bw, skip) in enumerate(cases.extract_cases()):
+        a, b = cases.extract_input(i)
+        design[f'ek{i}'] = rdist.extractKernel(a, b, fs, bw, skip)
+    for i, (amp, tau, fs) in enumerate(cases.decay_old_cases()):
+        b, a = rdist.exp_decay_filter_old(amp, tau, fs)
+        design[f'old{i}'] = np.concatenate([b, a])
+    for i, (b, a) in enumerate(cases.factor_cases()):
+        secs = rdist.factor_filter(b, a)
+        design[f'fac{i}'] = np.array([list(x) + list(y) for x, y in secs], dtype=complex)
+    design['stable'] = np.array([rdist.stable_filter(f, fs) for f, fs in cases.stable_cases()])
+    np.savez_compressed(os.path.join(gold, 'design.npz'), **design)
+    if sys.argv[1:] == ['design']:         # regenerate this fixture only
+        return
 
     # ---- edge inputs of __call__: empty / single / off-support / non-uniform x ----
     edges = {}

@@ -297,3 +297,32 @@ def edge_cases():
     for scale in (1e-9, 1e-6, 1e3):
         out[f'scaled_{scale:g}'] = (_edge_scaled(scale), [np.linspace(0, 200 * scale, 20001)])
     return out
+
+
+# ---- filter-design helpers of distortion.py (tests/test_symbolic_cpu.py) ----
+def extract_cases():
+    """(n, sample_rate, bw, skip) for extractKernel."""
+    return [(2048, 1e9, None, 0), (4096, 2e9, 0.4e9, 16), (3001, 1e9, 0.7e9, 5)]
+
+
+def extract_input(i):
+    n = extract_cases()[i][0]
+    rng = np.random.default_rng(1200 + i)
+    a = np.cumsum(rng.normal(size=n)) / 20 + rng.normal(size=n)
+    k = np.exp(-np.arange(24) / 5.0)
+    b = np.convolve(a, k / k.sum(), mode='full')[:n] + 0.3 * a
+    return a, b
+
+
+def decay_old_cases():
+    return [(0.05, 200e-9, 1e9), (-0.03, 1.5e-6, 2e9), (0.4, 30e-9, 1e9), (0.0, 1e-6, 1e9)]
+
+
+def factor_cases():
+    return [([1.0, -0.5], [1.0, -0.9]), ([0.2, 0.1, -0.05], [1.0, -1.5, 0.56]),
+            ([2.0, -1.0], [1.0, -1.2, 0.35])]
+
+
+def stable_cases():
+    return [([(0.05, 200e-9)], 1e9), ([(0.05, 200e-9), (-0.02, 2e-6)], 1e9),
+            ([(-0.9, 50e-9), (0.3, 10e-9)], 2e9), ([(5.0, 1e-9)], 1e9)]

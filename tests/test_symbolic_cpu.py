@@ -105,3 +105,30 @@ def test_marker_mask_logic_interp():
     assert f.bounds == (0.0, 1.0, 3.0, np.inf)
     band = (wf.cos(2) + wf.cos(9) + 1).filter(low=5)
     assert band == wf.cos(9)
+
+
+# ---- filter-design helpers of distortion.py against reference-generated vectors ----
+def test_design_helpers_match_reference():
+    import warnings
+    import golden_io
+    from waveforms_amd import distortion as d
+    G = golden_io.npz('design.npz')
+    for i, (n, fs, bw, skip) in enumerate(cases.extract_cases()):
+        a, b = cases.extract_input(i)
+        got = d.extractKernel(a, b, fs, bw, skip)
+        assert got.shape == G[f'ek{i}'].shape
+        assert np.max(np.abs(got - G[f'ek{i}'])) <= 1e-12 * np.abs(G[f'ek{i}']).max()
+    for i, (amp, tau, fs) in enumerate(cases.decay_old_cases()):
+        b, a = d.exp_decay_filter_old(amp, tau, fs)
+        assert np.allclose(np.concatenate([b, a]), G[f'old{i}'], rtol=1e-13, atol=0)
+    for i, (b, a) in enumerate(cases.factor_cases()):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')        # negative gain ** fraction -> nan, as in the reference
+            secs = d.factor_filter(b, a)
+        got = np.array([list(x) + list(y) for x, y in secs], dtype=complex)
+        assert got.shape == G[f'fac{i}'].shape
+        assert np.allclose(got, G[f'fac{i}'], rtol=1e-12, atol=1e-15, equal_nan=True)
+    got = [d.stable_filter(f, fs) for f, fs in cases.stable_cases()]
+    assert got == [bool(x) for x in G['stable']]
+    from waveforms_amd.waveform import convolve
+    assert convolve(wf.one(), wf.one()) is None      # a stub in the reference too (not exported)

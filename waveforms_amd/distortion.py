@@ -264,3 +264,57 @@ def high_pass_filter(tau, sample_rate):
     """reference: distortion.py:63-70"""
     k = 2.0 * tau * sample_rate
     return [k / (1 + k), -k / (1 + k)], [1.0, (1 - k) / (1 + k)]
+
+
+# --------------------------------------------------------------------------
+# filter-design helpers (host, O(order) or one short FFT: design time, not the data path)
+# --------------------------------------------------------------------------
+def extractKernel(sig_in, sig_out, sample_rate, bw=None, skip=0):
+    """Deconvolution kernel that maps `sig_out` back onto `sig_in` (reference:
+    distortion.py:42-48): centred inverse FFT of the spectral ratio, optionally smoothed
+    with a +-3 sigma Gaussian of `2*sample_rate/bw` points, `skip` samples cut at each end."""
+    ratio = np.fft.fft(sig_in) / np.fft.fft(sig_out)
+    ker = np.fft.ifftshift(np.fft.ifft(ratio)).real
+    if bw is not None and bw < 0.5 * sample_rate:
+        g = np.exp(-0.5 * np.linspace(-3.0, 3.0, int(2 * sample_rate / bw))**2)
+        ker = np.convolve(ker, g / g.sum(), mode='same')
+    return ker[int(skip):len(ker) - int(skip)]
+
+
+def exp_decay_filter_old(amp, tau, sample_rate):
+    """First-order section of H(w) = A / (1 - 1j/(w tau)) in the reference's earlier
+    discretisation (distortion.py:73-99) -> (b, a)."""
+    decay = np.exp(-1 / (abs(sample_rate * tau) * (1 + amp)))      # = 1 - alpha
+    alpha = 1 - decay
+    if amp >= 0:
+        k = amp / (1 + amp - alpha)
+        a0, a1 = 1 - k + k * alpha, -(1 - k) * (1 - alpha)
+    else:
+        k = -amp / (1 + amp) / (1 - alpha)
+        a0, a1 = 1 + k - k * alpha, -(1 + k) * (1 - alpha)
+    return [1 / a0, -(1 - alpha) / a0], [1, a1 / a0]
+
+
+def factor_filter(b, a):
+    """Split (b, a) into first-order sections, one per pole/zero pair, the gain spread
+    evenly over them (reference: distortion.py:247-265).  Note np.poly1d indexing: `b[0]`
+    is the CONSTANT coefficient, as in the reference."""
+    from itertools import zip_longest
+    bp, ap = np.poly1d(b), np.poly1d(a)
+    poles, zeros = ap.roots, bp.roots
+    gain = (bp[0] / ap[0])**(1 / max(len(zeros), len(poles)))
+    return [([gain, -gain * z], [1, -p]) for p, z in zip_longest(poles, zeros, fillvalue=0)]
+
+
+def stable_filter(exp_decay_filters, sample_rate):
+    """True when every pole of the combined exp-decay cascade lies inside the unit circle
+    (reference: distortion.py:268-286; it unpacks exp_decay_filter's (b, a) as (a, b) and
+    swaps them back when combining, which is kept)."""
+    from scipy.signal import tf2zpk
+    pairs = []
+    for amp, tau in exp_decay_filters:
+        first, second = exp_decay_filter(amp, tau, sample_rate)
+        pairs.append((second, first))
+    b, a = combine_filters(pairs)
+    _, poles, _ = tf2zpk(b, a)
+    return bool(np.all(np.abs(poles) < 1))

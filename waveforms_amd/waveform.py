@@ -501,6 +501,11 @@ def D(wav: Waveform, d: int = 1) -> Waveform:
     return wav
 
 
+def convolve(a, b):
+    """Placeholder in the reference as well (waveform.py:1074-1075: `pass`)."""
+    return None
+
+
 def sign():
     return Waveform(bounds=(0, +inf), seq=(const_expr(-1), ONE))
 
