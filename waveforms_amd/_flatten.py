@@ -68,6 +68,10 @@ class Program:
         return self.arrays['pc_bound'][off[member]:off[member + 1]]
 
 
+# fixed-arity primitives whose args go to the pool as they are (the hot case of flatten())
+_SIMPLE_ARGC = {k: v for k, v in _ARGC.items() if v is not None and k != _ir.DRAG}
+
+
 def _factor_args(factor):
     type_id, *args, _shift = factor
     if type_id not in _ARGC:
@@ -139,10 +143,15 @@ def flatten(channels) -> Program:
                     for f, n in zip(factors, powers):
                         if isinstance(n, complex):
                             raise NotImplementedError('complex power')
-                        fc_type.append(int(f[0]))
-                        fc_power.append(float(n))
-                        fc_shift.append(float(f[-1]))
-                        pool.extend(_factor_args(f))
+                        fc_type.append(f[0])
+                        fc_power.append(n)
+                        fc_shift.append(f[-1])
+                        argc = _SIMPLE_ARGC.get(f[0])
+                        if argc is not None and len(f) == argc + 2:
+                            if argc:
+                                pool.extend(f[1:-1])    # converted to float64 in one go below
+                        else:
+                            pool.extend(_factor_args(f))
                         fc_arg_off.append(len(pool))
                     tm_factor_off.append(len(fc_type))
                 pc_term_off.append(len(amp_re))

@@ -5,8 +5,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "wfk.h"
 #include "wfk_internal.h"
@@ -25,9 +28,75 @@ static int fail(int code, const std::string& msg) {
       return fail(WFK_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
+// ---- device block cache ------------------------------------------------------------------
+// The drop-in calls (`wav(t)`: plan -> launch -> copy back -> destroy, reference
+// waveform.py:529-563) are dominated by hipMalloc/hipFree when the waveform is small: seven
+// allocations and frees per call cost more than the kernel.  Plans therefore take ONE block
+// for all their tables (and one for the run_host output) from a per-device cache of
+// power-of-two blocks, and give it back on destroy.  Cached bytes are capped; big blocks
+// (the 20 GB outputs belong to the caller anyway) go straight to hipMalloc/hipFree.
+namespace {
+
+struct DevBlockCache {
+  static constexpr size_t kMinBlock = 4096;
+  static constexpr size_t kMaxCachedBlock = size_t(64) << 20;
+  static constexpr size_t kMaxCachedTotal = size_t(512) << 20;
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_;   // (device, size) -> blocks
+  std::map<void*, size_t> handed_;                              // wfk_malloc blocks -> capacity
+  size_t cached = 0;
+
+  static size_t round_up(size_t bytes) {
+    size_t b = kMinBlock;
+    while (b < bytes) b <<= 1;
+    return b;
+  }
+  hipError_t get(size_t bytes, void** out, size_t* cap) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t b = bytes > kMaxCachedBlock ? bytes : round_up(bytes);
+    if (b <= kMaxCachedBlock) {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = free_.find({dev, b});
+      if (it != free_.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        cached -= b;
+        *cap = b;
+        return hipSuccess;
+      }
+    }
+    *cap = b;
+    return hipMalloc(out, b);
+  }
+  void put(void* ptr, size_t cap) {
+    if (!ptr) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (cap <= kMaxCachedBlock) {
+      std::lock_guard<std::mutex> g(mu);
+      if (cached + cap <= kMaxCachedTotal) {
+        free_[{dev, cap}].push_back(ptr);
+        cached += cap;
+        return;
+      }
+    }
+    (void)hipFree(ptr);
+  }
+};
+
+DevBlockCache& dev_cache() {
+  static DevBlockCache* c = new DevBlockCache();   // leaked on purpose: no teardown-order races
+  return *c;
+}
+
+}  // namespace
+
 struct wfk_plan {
   HostPlan h;
   bool on_device = false;
+  void* d_tables = nullptr;    // ONE block: channels | pieces | params | pool | chunk_first | tlist
+  size_t tables_cap = 0;
   DevChannel* d_channels = nullptr;
   DevPiece* d_pieces = nullptr;
   double* d_params = nullptr;
@@ -36,15 +105,11 @@ struct wfk_plan {
   double* d_tlist = nullptr;
   void* d_scratch = nullptr;   // wfk_plan_run_host output buffer
   size_t scratch_bytes = 0;
+  size_t scratch_cap = 0;
+  bool async_launch = false;   // launched on a caller stream since the last host-side sync
 };
 
-template <typename T>
-static int upload(T** dst, const T* src, size_t count) {
-  size_t bytes = (count ? count : 1) * sizeof(T);
-  HIP_TRY(hipMalloc((void**)dst, bytes));
-  if (count) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
-  return WFK_OK;
-}
+static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 static int plan_upload(wfk_plan* p, const double* tlist) {
   int ndev = 0;
@@ -53,13 +118,34 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
     p->on_device = false;  // host-only plan: index/info queries work, launch fails loudly
     return WFK_OK;
   }
-  int rc;
-  if ((rc = upload(&p->d_channels, p->h.channels.data(), p->h.channels.size()))) return rc;
-  if ((rc = upload(&p->d_pieces, p->h.pieces.data(), p->h.pieces.size()))) return rc;
-  if ((rc = upload(&p->d_params, p->h.params.data(), p->h.params.size()))) return rc;
-  if ((rc = upload(&p->d_pool, p->h.pool.data(), p->h.pool.size()))) return rc;
-  if ((rc = upload(&p->d_chunk_first, p->h.chunk_first.data(), p->h.chunk_first.size()))) return rc;
-  if (tlist && (rc = upload(&p->d_tlist, tlist, (size_t)p->h.n))) return rc;
+  const HostPlan& h = p->h;
+  const size_t b_ch = h.channels.size() * sizeof(DevChannel);
+  const size_t b_pc = h.pieces.size() * sizeof(DevPiece);
+  const size_t b_pa = h.params.size() * sizeof(double);
+  const size_t b_po = h.pool.size() * sizeof(double);
+  const size_t b_cf = h.chunk_first.size() * sizeof(int32_t);
+  const size_t o_ch = 0, o_pc = align256(o_ch + b_ch), o_pa = align256(o_pc + b_pc),
+               o_po = align256(o_pa + b_pa), o_cf = align256(o_po + b_po),
+               o_tl = align256(o_cf + b_cf);
+  const size_t b_tl = tlist ? (size_t)h.n * sizeof(double) : 0;
+  const size_t total = align256(o_tl + b_tl) + 256;
+  HIP_TRY(dev_cache().get(total, &p->d_tables, &p->tables_cap));
+  char* base = static_cast<char*>(p->d_tables);
+  p->d_channels = reinterpret_cast<DevChannel*>(base + o_ch);
+  p->d_pieces = reinterpret_cast<DevPiece*>(base + o_pc);
+  p->d_params = reinterpret_cast<double*>(base + o_pa);
+  p->d_pool = reinterpret_cast<double*>(base + o_po);
+  p->d_chunk_first = reinterpret_cast<int32_t*>(base + o_cf);
+  p->d_tlist = tlist ? reinterpret_cast<double*>(base + o_tl) : nullptr;
+  // the small tables travel in ONE copy; the time axis (as large as the output) on its own
+  std::vector<char> stage(o_tl);
+  if (b_ch) std::memcpy(stage.data() + o_ch, h.channels.data(), b_ch);
+  if (b_pc) std::memcpy(stage.data() + o_pc, h.pieces.data(), b_pc);
+  if (b_pa) std::memcpy(stage.data() + o_pa, h.params.data(), b_pa);
+  if (b_po) std::memcpy(stage.data() + o_po, h.pool.data(), b_po);
+  if (b_cf) std::memcpy(stage.data() + o_cf, h.chunk_first.data(), b_cf);
+  if (o_tl) HIP_TRY(hipMemcpy(base, stage.data(), o_tl, hipMemcpyHostToDevice));
+  if (b_tl) HIP_TRY(hipMemcpy(base + o_tl, tlist, b_tl, hipMemcpyHostToDevice));
   p->on_device = true;
   return WFK_OK;
 }
@@ -125,14 +211,12 @@ int wfk_plan_create_tlist(const wfk_program* prog, const double* t_host, int64_t
 
 int wfk_plan_destroy(wfk_plan* p) {
   if (!p) return WFK_OK;
-  if (p->on_device || p->d_channels) {
-    (void)hipFree(p->d_channels);
-    (void)hipFree(p->d_pieces);
-    (void)hipFree(p->d_params);
-    (void)hipFree(p->d_pool);
-    (void)hipFree(p->d_chunk_first);
-    (void)hipFree(p->d_tlist);
-    (void)hipFree(p->d_scratch);
+  if (p->d_tables || p->d_scratch) {
+    // blocks go back to the cache and may be handed to the next plan at once: work launched
+    // on a caller stream must have drained first (hipFree used to imply that)
+    if (p->async_launch) (void)hipDeviceSynchronize();
+    dev_cache().put(p->d_tables, p->tables_cap);
+    dev_cache().put(p->d_scratch, p->scratch_cap);
   }
   delete p;
   return WFK_OK;
@@ -191,8 +275,9 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   a.step = p->h.step;
   a.last = p->h.last;
   a.has_last = p->h.has_last;
+  if (hip_stream) p->async_launch = true;
   std::string err;
-  int rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.lean,
+  int rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.ns, p->h.lean,
                               p->h.n_generic > 0,
                               p->h.n_direct > 0,
                               hip_stream, err);
@@ -218,10 +303,10 @@ int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_ki
     return fail(WFK_EHIP, "plan has no device tables (no HIP device was visible at plan creation)");
   size_t bytes = (size_t)p->h.n_channels * (size_t)p->h.n * es;
   if (bytes > p->scratch_bytes) {
-    (void)hipFree(p->d_scratch);
+    dev_cache().put(p->d_scratch, p->scratch_cap);
     p->d_scratch = nullptr;
     p->scratch_bytes = 0;
-    HIP_TRY(hipMalloc(&p->d_scratch, bytes));
+    HIP_TRY(dev_cache().get(bytes, &p->d_scratch, &p->scratch_cap));
     p->scratch_bytes = bytes;
   }
   int rc = wfk_plan_launch(p, p->d_scratch, p->h.n, out_kind, 0, nullptr);
@@ -237,12 +322,26 @@ int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_ki
 
 int wfk_malloc(void** dev_ptr, size_t bytes) {
   if (!dev_ptr) return fail(WFK_EINVAL, "null dev_ptr");
-  HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
+  size_t cap = 0;
+  HIP_TRY(dev_cache().get(bytes ? bytes : 1, dev_ptr, &cap));
+  std::lock_guard<std::mutex> g(dev_cache().mu);
+  dev_cache().handed_[*dev_ptr] = cap;
   return WFK_OK;
 }
 
 int wfk_free(void* dev_ptr) {
-  HIP_TRY(hipFree(dev_ptr));
+  if (!dev_ptr) return WFK_OK;
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> g(dev_cache().mu);
+    auto it = dev_cache().handed_.find(dev_ptr);
+    if (it == dev_cache().handed_.end()) return fail(WFK_EINVAL, "wfk_free: not a wfk_malloc block");
+    cap = it->second;
+    dev_cache().handed_.erase(it);
+  }
+  // like hipFree, freeing waits for the device: the block may be reused at once
+  HIP_TRY(hipDeviceSynchronize());
+  dev_cache().put(dev_ptr, cap);
   return WFK_OK;
 }
 

@@ -24,6 +24,10 @@
 #define WFK_WG 256            // threads per workgroup (4 wave64)
 #define WFK_NS_GRID 16        // samples per lane per wave tile, grid mode
 #define WFK_NS_TLIST 8        // samples per lane per wave tile, tlist mode
+#define WFK_NS_TLIST_SMALL 1  // ... when n < WFK_TLIST_SMALL_N: a 10 001-point call (the README case)
+                              // then spreads over 40 workgroups instead of 5 (device libm per sample:
+                              // the launch is latency-bound, not byte-bound)
+#define WFK_TLIST_SMALL_N (1 << 20)
 #define WFK_LDS_DOUBLES 2048  // LDS parameter buffer (16 KiB)
 #define WFK_FREC 10           // doubles per factor record
 #define WFK_BLK_HDR 2
@@ -136,6 +140,6 @@ int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tli
                 int64_t n, HostPlan& out, std::string& err);
 
 // kernels (wfk_kernels.hip)
-int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist,
+int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns,
                        bool lean, bool generic, bool direct, void* stream, std::string& err);
 #endif

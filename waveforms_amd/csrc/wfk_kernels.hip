@@ -832,7 +832,7 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
 
 }  // namespace
 
-int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, bool lean,
+int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns, bool lean,
                        bool generic, bool direct, void* stream, std::string& err) {
   if (a.n_chunks != (int64_t)n_channels * a.chunks_per_ch) { err = "n_chunks mismatch"; return WFK_EINVAL; }
   const int64_t blocks = ((a.n_chunks + 7) >> 3) << 3;   // see xcd_chunk()
@@ -846,6 +846,14 @@ int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tl
       case WFK_OUT_F32: rc = launch<float, false, false, WFK_NS_GRID>(a, blocks, s, lean, generic, direct); break;
       case WFK_OUT_C128: rc = launch<double, true, false, WFK_NS_GRID>(a, blocks, s, lean, generic, direct); break;
       case WFK_OUT_C64: rc = launch<float, true, false, WFK_NS_GRID>(a, blocks, s, lean, generic, direct); break;
+      default: err = "bad out_kind"; return WFK_EINVAL;
+    }
+  } else if (ns == WFK_NS_TLIST_SMALL) {
+    switch (out_kind) {
+      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
       default: err = "bad out_kind"; return WFK_EINVAL;
     }
   } else {
