@@ -43,7 +43,7 @@ struct DevBlockCache {
   static constexpr size_t kMaxCachedTotal = size_t(512) << 20;
   std::mutex mu;
   std::map<std::pair<int, size_t>, std::vector<void*>> free_;   // (device, size) -> blocks
-  std::map<void*, size_t> handed_;                              // wfk_malloc blocks -> capacity
+  std::map<void*, std::pair<size_t, int>> handed_;              // wfk_malloc blocks -> (capacity, device)
   size_t cached = 0;
 
   static size_t round_up(size_t bytes) {
@@ -51,9 +51,11 @@ struct DevBlockCache {
     while (b < bytes) b <<= 1;
     return b;
   }
-  hipError_t get(size_t bytes, void** out, size_t* cap) {
+  // blocks are keyed by the device that was current when they were allocated (`*dev_out`)
+  hipError_t get(size_t bytes, void** out, size_t* cap, int* dev_out) {
     int dev = 0;
     (void)hipGetDevice(&dev);
+    *dev_out = dev;
     const size_t b = bytes > kMaxCachedBlock ? bytes : round_up(bytes);
     if (b <= kMaxCachedBlock) {
       std::lock_guard<std::mutex> g(mu);
@@ -69,10 +71,8 @@ struct DevBlockCache {
     *cap = b;
     return hipMalloc(out, b);
   }
-  void put(void* ptr, size_t cap) {
+  void put(void* ptr, size_t cap, int dev) {
     if (!ptr) return;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     if (cap <= kMaxCachedBlock) {
       std::lock_guard<std::mutex> g(mu);
       if (cached + cap <= kMaxCachedTotal) {
@@ -106,6 +106,7 @@ struct wfk_plan {
   void* d_scratch = nullptr;   // wfk_plan_run_host output buffer
   size_t scratch_bytes = 0;
   size_t scratch_cap = 0;
+  int dev = 0;                 // device the blocks live on
   bool async_launch = false;   // launched on a caller stream since the last host-side sync
 };
 
@@ -129,7 +130,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
                o_tl = align256(o_cf + b_cf);
   const size_t b_tl = tlist ? (size_t)h.n * sizeof(double) : 0;
   const size_t total = align256(o_tl + b_tl) + 256;
-  HIP_TRY(dev_cache().get(total, &p->d_tables, &p->tables_cap));
+  HIP_TRY(dev_cache().get(total, &p->d_tables, &p->tables_cap, &p->dev));
   char* base = static_cast<char*>(p->d_tables);
   p->d_channels = reinterpret_cast<DevChannel*>(base + o_ch);
   p->d_pieces = reinterpret_cast<DevPiece*>(base + o_pc);
@@ -215,8 +216,8 @@ int wfk_plan_destroy(wfk_plan* p) {
     // blocks go back to the cache and may be handed to the next plan at once: work launched
     // on a caller stream must have drained first (hipFree used to imply that)
     if (p->async_launch) (void)hipDeviceSynchronize();
-    dev_cache().put(p->d_tables, p->tables_cap);
-    dev_cache().put(p->d_scratch, p->scratch_cap);
+    dev_cache().put(p->d_tables, p->tables_cap, p->dev);
+    dev_cache().put(p->d_scratch, p->scratch_cap, p->dev);
   }
   delete p;
   return WFK_OK;
@@ -303,10 +304,11 @@ int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_ki
     return fail(WFK_EHIP, "plan has no device tables (no HIP device was visible at plan creation)");
   size_t bytes = (size_t)p->h.n_channels * (size_t)p->h.n * es;
   if (bytes > p->scratch_bytes) {
-    dev_cache().put(p->d_scratch, p->scratch_cap);
+    dev_cache().put(p->d_scratch, p->scratch_cap, p->dev);
     p->d_scratch = nullptr;
     p->scratch_bytes = 0;
-    HIP_TRY(dev_cache().get(bytes, &p->d_scratch, &p->scratch_cap));
+    int sdev = 0;
+    HIP_TRY(dev_cache().get(bytes, &p->d_scratch, &p->scratch_cap, &sdev));
     p->scratch_bytes = bytes;
   }
   int rc = wfk_plan_launch(p, p->d_scratch, p->h.n, out_kind, 0, nullptr);
@@ -323,25 +325,28 @@ int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_ki
 int wfk_malloc(void** dev_ptr, size_t bytes) {
   if (!dev_ptr) return fail(WFK_EINVAL, "null dev_ptr");
   size_t cap = 0;
-  HIP_TRY(dev_cache().get(bytes ? bytes : 1, dev_ptr, &cap));
+  int dev = 0;
+  HIP_TRY(dev_cache().get(bytes ? bytes : 1, dev_ptr, &cap, &dev));
   std::lock_guard<std::mutex> g(dev_cache().mu);
-  dev_cache().handed_[*dev_ptr] = cap;
+  dev_cache().handed_[*dev_ptr] = {cap, dev};
   return WFK_OK;
 }
 
 int wfk_free(void* dev_ptr) {
   if (!dev_ptr) return WFK_OK;
   size_t cap = 0;
+  int dev = 0;
   {
     std::lock_guard<std::mutex> g(dev_cache().mu);
     auto it = dev_cache().handed_.find(dev_ptr);
     if (it == dev_cache().handed_.end()) return fail(WFK_EINVAL, "wfk_free: not a wfk_malloc block");
-    cap = it->second;
+    cap = it->second.first;
+    dev = it->second.second;
     dev_cache().handed_.erase(it);
   }
   // like hipFree, freeing waits for the device: the block may be reused at once
   HIP_TRY(hipDeviceSynchronize());
-  dev_cache().put(dev_ptr, cap);
+  dev_cache().put(dev_ptr, cap, dev);
   return WFK_OK;
 }
 
