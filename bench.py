@@ -100,6 +100,10 @@ def main():
     ap.add_argument('--channels', type=int, default=None)
     ap.add_argument('--points', type=float, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather-rows', type=int, default=0,
+                    help='N > 1 only: after the timed steps, also time an RCCL all_gather of this '
+                         'many rows per rank (result placement, SURVEY 8(e); reported under '
+                         '"gather", never part of `value`: results stay sharded by default)')
     ap.add_argument('--dtype', choices=['f64', 'f32'], default=None,
                     help='override the output dtype of the workload')
     args = ap.parse_args()
@@ -249,6 +253,29 @@ def main():
         got = out[:len(outs)].cpu().numpy().astype(np.float64)
         line['max_abs_err_vs_numpy_ref'] = float(
             max(np.max(np.abs(got[i] - outs[i])) for i in range(len(outs))))
+    if dist is not None and args.gather_rows > 0:
+        # optional result placement over xGMI, timed on its own (a full 20 GB block per rank is
+        # gather-bound by > 10x over the compute): bounded slice, extrapolated
+        try:
+            rows = min(args.gather_rows, bs.n_channels)
+            src = out[:rows].contiguous()
+            dst = torch.empty((world * rows, bs.n), dtype=out.dtype, device='cuda')
+            dist.all_gather_into_tensor(dst, src)
+            fence()
+            g0 = time.perf_counter()
+            for _ in range(3):
+                dist.all_gather_into_tensor(dst, src)
+            fence()
+            g_ms = (time.perf_counter() - g0) / 3 * 1e3
+            nbytes = rows * bs.n * elem
+            line['gather'] = {
+                'rows_per_rank': rows, 'bytes_per_rank': nbytes, 'ms': g_ms,
+                'ingress_GBps_per_rank': (world - 1) * nbytes / (g_ms * 1e-3) / 1e9,
+                'full_block_est_ms': g_ms * bs.n_channels / rows,
+                'note': 'all_gather (RCCL over xGMI) of a row slice; full block extrapolated linearly'}
+            del dst
+        except Exception as exc:   # placement is optional: never lose the bench line over it
+            line['gather'] = {'error': repr(exc)}
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:
