@@ -19,6 +19,7 @@ Outputs
   tests/golden/fir.npz            distortion.predistort(sig, ker=...) vectors
   tests/golden/iir.npz            sample(filters=...) and predistort(filters=...) vectors
   tests/golden/design.npz         extractKernel / exp_decay_filter_old / factor_filter / stable_filter
+  tests/golden/fuzz.npz           reference wav(t) for random scripts (+ fuzz_frontend.json: tolist())
   tests/golden/edges.npz          wav(x) on empty / single / off-support / non-uniform x
 """
 import json
@@ -104,6 +105,20 @@ def main():
     design['stable'] = np.array([rdist.stable_filter(f, fs) for f, fs in cases.stable_cases()])
     np.savez_compressed(os.path.join(gold, 'design.npz'), **design)
     if sys.argv[1:] == ['design']:         # regenerate this fixture only
+        return
+
+    # ---- random scripts (tests/cases.py: random_channel), evaluated by the reference ----
+    fuzz, fuzz_lists = {}, {}
+    for seed in range(cases.FUZZ_GOLD):
+        w, grid = cases.fuzz_golden_case(ref, seed)
+        y = np.asarray(w(wl.make_grid(grid)))
+        assert not np.iscomplexobj(y) or np.all(y.imag == 0)
+        fuzz[f'{seed}.y'] = y.real.astype(np.float64)
+        fuzz_lists[str(seed)] = [enc(v) for v in w.tolist()]
+    np.savez_compressed(os.path.join(gold, 'fuzz.npz'), **fuzz)
+    with open(os.path.join(gold, 'fuzz_frontend.json'), 'w') as f:
+        json.dump(fuzz_lists, f)
+    if sys.argv[1:] == ['fuzz']:           # regenerate these fixtures only
         return
 
     # ---- edge inputs of __call__: empty / single / off-support / non-uniform x ----

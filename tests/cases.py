@@ -326,3 +326,82 @@ def factor_cases():
 def stable_cases():
     return [([(0.05, 200e-9)], 1e9), ([(0.05, 200e-9), (-0.02, 2e-6)], 1e9),
             ([(-0.9, 50e-9), (0.3, 10e-9)], 2e9), ([(5.0, 1e-9)], 1e9)]
+
+
+# ---- random pulse scripts (tests/test_gpu_fuzz.py, tests/test_oracle_golden.py) ----
+# `wf` is the namespace the script is built in: this package, or the real reference when
+# oracle/make_golden.py generates tests/golden/fuzz.npz.  The rng draws do not depend on it.
+def random_pulse(wf, rng, scale):
+    kind = rng.integers(0, 9)
+    w = scale * rng.uniform(0.5, 6.0)
+    if kind == 0:
+        p = wf.gaussian(w)
+    elif kind == 1:
+        p = wf.cosPulse(w, plateau=scale * rng.uniform(0, 2) * (rng.random() < 0.4))
+    elif kind == 2:
+        p = wf.square(w, edge=w * rng.uniform(0.05, 0.3) * (rng.random() < 0.6),
+                      type=str(rng.choice(['erf', 'cos', 'linear'])))
+    elif kind == 3:
+        p = wf.gaussian(w, plateau=scale * rng.uniform(0.1, 2))
+    elif kind == 4:
+        p = wf.drag(rng.uniform(-2, 2) / scale, w, delta=rng.uniform(-0.1, 0.1) / scale,
+                    block_freq=None if rng.random() < 0.3 else rng.uniform(1, 3) / scale,
+                    phase=rng.uniform(0, 6), t0=-w / 2)
+    elif kind == 5:
+        p = wf.coshPulse(w, eps=rng.uniform(0.5, 3))
+    elif kind == 6:
+        p = wf.gaussian(w) * wf.poly([rng.uniform(-1, 1), rng.uniform(-1, 1) / scale,
+                                      rng.uniform(-1, 1) / scale**2])
+    elif kind == 7:
+        p = wf.D(wf.gaussian(w)) * (scale * 0.3)
+    else:
+        p = wf.mollifier(w)
+    if rng.random() < 0.8:
+        f = rng.uniform(-3, 3) / scale
+        no_d = kind == 4    # the DRAG primitive has no derivative rule (nor upstream)
+        I, Q = wf.mixing(p, freq=f, phase=rng.uniform(0, 6),
+                         DRAGScaling=None if (no_d or rng.random() < 0.4)
+                         else rng.uniform(-0.05, 0.05) * scale,
+                         block_freq=None if (no_d or rng.random() < 0.8)
+                         else f + rng.uniform(0.5, 2) / scale)
+        p = I if rng.random() < 0.5 else Q
+    if rng.random() < 0.3:
+        p = p * wf.cos(rng.uniform(0.5, 4) / scale, rng.uniform(0, 6))
+    return rng.uniform(0.1, 2.0) * (p >> (scale * rng.uniform(-8, 8)))
+
+
+def random_channel(wf, rng):
+    scale = 10.0**rng.uniform(-9, 0)
+    n = int(rng.integers(1, 7))
+    pulses = [random_pulse(wf, rng, scale) for _ in range(n)]
+    if rng.random() < 0.4:
+        ch = wf.WaveVStack(pulses)
+        if rng.random() < 0.5:
+            ch = (ch + rng.uniform(-0.5, 0.5)) >> (scale * rng.uniform(-1, 1))
+    else:
+        ch = pulses[0]
+        for p in pulses[1:]:
+            ch = ch + p
+        if rng.random() < 0.2:
+            ch = wf.cut(ch, min=-0.4, max=0.6)
+    npts = int(rng.integers(1, 60000))
+    a = scale * rng.uniform(-14, -6)
+    b = a + scale * rng.uniform(2, 30)
+    grid = (('linspace', a, b, npts, bool(rng.random() < 0.5)) if rng.random() < 0.7
+            else ('arange', a, b, (b - a) / npts))
+    return ch, grid
+
+
+FUZZ_GOLD = 120      # seeds evaluated by the real reference (oracle/make_golden.py -> fuzz.npz)
+
+
+def fuzz_golden_case(wf, seed):
+    """Random script `seed` on a reduced grid (<= 1500 points: keeps the fixture small)."""
+    rng = np.random.default_rng(10_000 + seed)
+    ch, grid = random_channel(wf, rng)
+    if grid[0] == 'linspace':
+        grid = ('linspace', grid[1], grid[2], min(grid[3], 1500), grid[4])
+    else:
+        n = max(1, min(1500, int(np.ceil((grid[2] - grid[1]) / grid[3]))))
+        grid = ('arange', grid[1], grid[2], (grid[2] - grid[1]) / n)
+    return ch, grid

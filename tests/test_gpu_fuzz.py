@@ -4,6 +4,8 @@ the same flattened program.  Seeded; every failure prints its seed."""
 import numpy as np
 import pytest
 
+import cases
+import golden_io
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -11,65 +13,8 @@ from waveforms_amd import _engine, _flatten
 pytestmark = pytest.mark.gpu
 
 
-def random_pulse(rng, scale):
-    kind = rng.integers(0, 9)
-    w = scale * rng.uniform(0.5, 6.0)
-    if kind == 0:
-        p = wf.gaussian(w)
-    elif kind == 1:
-        p = wf.cosPulse(w, plateau=scale * rng.uniform(0, 2) * (rng.random() < 0.4))
-    elif kind == 2:
-        p = wf.square(w, edge=w * rng.uniform(0.05, 0.3) * (rng.random() < 0.6),
-                      type=str(rng.choice(['erf', 'cos', 'linear'])))
-    elif kind == 3:
-        p = wf.gaussian(w, plateau=scale * rng.uniform(0.1, 2))
-    elif kind == 4:
-        p = wf.drag(rng.uniform(-2, 2) / scale, w, delta=rng.uniform(-0.1, 0.1) / scale,
-                    block_freq=None if rng.random() < 0.3 else rng.uniform(1, 3) / scale,
-                    phase=rng.uniform(0, 6), t0=-w / 2)
-    elif kind == 5:
-        p = wf.coshPulse(w, eps=rng.uniform(0.5, 3))
-    elif kind == 6:
-        p = wf.gaussian(w) * wf.poly([rng.uniform(-1, 1), rng.uniform(-1, 1) / scale,
-                                      rng.uniform(-1, 1) / scale**2])
-    elif kind == 7:
-        p = wf.D(wf.gaussian(w)) * (scale * 0.3)
-    else:
-        p = wf.mollifier(w)
-    if rng.random() < 0.8:
-        f = rng.uniform(-3, 3) / scale
-        no_d = kind == 4    # the DRAG primitive has no derivative rule (nor upstream)
-        I, Q = wf.mixing(p, freq=f, phase=rng.uniform(0, 6),
-                         DRAGScaling=None if (no_d or rng.random() < 0.4)
-                         else rng.uniform(-0.05, 0.05) * scale,
-                         block_freq=None if (no_d or rng.random() < 0.8)
-                         else f + rng.uniform(0.5, 2) / scale)
-        p = I if rng.random() < 0.5 else Q
-    if rng.random() < 0.3:
-        p = p * wf.cos(rng.uniform(0.5, 4) / scale, rng.uniform(0, 6))
-    return rng.uniform(0.1, 2.0) * (p >> (scale * rng.uniform(-8, 8)))
-
-
-def random_channel(rng):
-    scale = 10.0**rng.uniform(-9, 0)
-    n = int(rng.integers(1, 7))
-    pulses = [random_pulse(rng, scale) for _ in range(n)]
-    if rng.random() < 0.4:
-        ch = wf.WaveVStack(pulses)
-        if rng.random() < 0.5:
-            ch = (ch + rng.uniform(-0.5, 0.5)) >> (scale * rng.uniform(-1, 1))
-    else:
-        ch = pulses[0]
-        for p in pulses[1:]:
-            ch = ch + p
-        if rng.random() < 0.2:
-            ch = wf.cut(ch, min=-0.4, max=0.6)
-    npts = int(rng.integers(1, 60000))
-    a = scale * rng.uniform(-14, -6)
-    b = a + scale * rng.uniform(2, 30)
-    grid = (('linspace', a, b, npts, bool(rng.random() < 0.5)) if rng.random() < 0.7
-            else ('arange', a, b, (b - a) / npts))
-    return ch, grid
+random_pulse = lambda rng, scale: cases.random_pulse(wf, rng, scale)      # noqa: E731
+random_channel = lambda rng: cases.random_channel(wf, rng)                 # noqa: E731
 
 
 @pytest.mark.parametrize('seed', range(160))
@@ -109,3 +54,22 @@ def test_random_batches():
         ora = c_oracle.eval_grid(prog, g)
         got = _engine.Plan(prog, grid=g).run_host(np.float64)
         assert np.max(np.abs(got - ora)) <= 1e-9 * max(1.0, np.abs(ora).max())
+
+
+# ---- the same random scripts against outputs of the REAL reference (tests/golden/fuzz.npz,
+# oracle/make_golden.py): the reference evaluated seeds 0..FUZZ_GOLD-1 on a reduced grid ----
+FUZZ = golden_io.npz('fuzz.npz')
+
+
+@pytest.mark.parametrize('seed', range(cases.FUZZ_GOLD))
+def test_random_script_vs_reference_golden(seed):
+    ch, grid = cases.fuzz_golden_case(wf, seed)
+    want = FUZZ[f'{seed}.y']
+    prog = _flatten.flatten([ch])
+    g = _flatten.grid_from_desc(grid)
+    pk = max(1.0, float(np.max(np.abs(want)))) if want.size else 1.0
+    got = _engine.Plan(prog, grid=g).run_host(np.float64)[0]
+    assert np.max(np.abs(got - want), initial=0.0) <= 1e-9 * pk, seed
+    t = c_oracle.grid_values(g)
+    tl = ch(t)                                   # drop-in __call__ (tlist mode)
+    assert np.max(np.abs(np.real(tl) - want), initial=0.0) <= 1e-9 * pk, seed

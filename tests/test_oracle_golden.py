@@ -113,3 +113,26 @@ def test_oracles_on_edge_inputs(name):
         close(np_oracle.call(w, x), want, rel=1e-14)
         got = c_oracle.eval_tlist(prog, x, want.dtype == np.complex128)[0]
         close(got, want)
+
+
+# ---- random pulse scripts: both oracles and the front-end against the REAL reference ----
+FUZZ = golden_io.npz('fuzz.npz')
+FUZZ_LISTS = golden_io.frontend_lists_named('fuzz_frontend.json')
+
+
+@pytest.mark.parametrize('seed', range(cases.FUZZ_GOLD))
+def test_oracles_match_reference_on_random_scripts(seed):
+    from test_frontend_golden import same
+    w, grid = cases.fuzz_golden_case(wf, seed)
+    want = FUZZ[f'{seed}.y']
+    # front-end: the flat list of the script equals the reference's tolist() element by element
+    got_l, want_l = w.tolist(), FUZZ_LISTS[str(seed)]
+    assert len(got_l) == len(want_l)
+    assert all(same(a, b) for a, b in zip(got_l, want_l)), seed
+    t = wl.make_grid(grid)
+    y = np.asarray(np_oracle.call(w, t))
+    close(y.real.astype(np.float64), want, rel=1e-13)
+    prog = _flatten.flatten([w])
+    g = _flatten.grid_from_desc(grid)
+    assert np.array_equal(c_oracle.grid_values(g), t)
+    close(c_oracle.eval_grid(prog, g)[0], want, rel=1e-11)
