@@ -68,7 +68,9 @@
 
 // "lean" plans: every piece is one block of <= WFK_LEAN_OPS fused ops and nothing else.
 // They run on the wave-per-workgroup kernel that carries per-lane op state across tiles.
+#ifndef WFK_LEAN_OPS
 #define WFK_LEAN_OPS 4
+#endif
 // doubles of LDS parameter buffer per wave: header + 4 ops x (22 record + 34 table) = 232.
 // With the 8 KB of per-lane op state that makes 10 KB per wave = 16 waves per CU, which the
 // fp32 kernel (<= 128 VGPRs) uses: 2.11 -> 1.95 ms on 256 x 1e7 fp32 against 512 doubles.
