@@ -36,7 +36,10 @@ def test_fir_matches_reference_vectors(i, fir_path):
 def test_fir_edge_semantics(fir_path):
     rng = np.random.default_rng(3)
     for n, k in [(1, 1), (2, 5), (17, 2), (7168, 1024), (7169, 1024), (7170, 1024),
-                 (20000, 1), (50, 1024), (9000, 1537), (9000, 1538), (5000, 3000)]:
+                 (20000, 1), (50, 1024), (9000, 1537), (9000, 1538), (5000, 3000),
+                 # long kernels: 2, 3, 4 accumulated segments of the fused kernel; 5 -> rocFFT
+                 (30000, 2401), (30001, 3075), (12345, 4611), (40000, 6148), (9000, 6149),
+                 (300, 2401), (1, 5000)]:
         sig, ker = rng.normal(size=n), rng.normal(size=k)
         want = np_oracle.predistort_fir(sig, ker)
         got = distortion.predistort(sig, ker=ker)
@@ -108,3 +111,26 @@ def test_c4_sampler_then_fir_against_reference():
         assert np.max(np.abs(sig_h[row][pick] - BIG[f'c4_{c}.y'])) <= 1e-9
         assert np.max(np.abs(out_h[row][pick] - BIG[f'c4_{c}.fir'])) <= 1e-9
         assert abs(out_h[row].sum() - BIG[f'c4_{c}.firsum'][0]) <= 1e-6
+
+
+def test_long_kernel_segments_batch_and_fp32():
+    """K = 2401 (the Z-line kernel of a 400 ns time constant at 2 GS/s) takes two accumulated
+    passes of the fused kernel; rows, strides and fp32 as for the short kernels."""
+    import torch
+    rng = np.random.default_rng(11)
+    n, batch, K = 200_001, 3, 2401
+    ker = rng.normal(size=K)
+    ker /= np.abs(ker).sum()
+    x = rng.normal(size=(batch, n))
+    want = np.stack([np_oracle.predistort_fir(r, ker) for r in x])
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 1e-5)):
+        st = distortion.FirStage(ker, n, batch, dt)
+        tdt = torch.float64 if dt == np.float64 else torch.float32
+        xd = torch.from_numpy(x).to('cuda', tdt)
+        yd = torch.full((batch, n + 13), 7.0, dtype=tdt, device='cuda')   # padded rows
+        st.apply_torch(xd, yd)
+        torch.cuda.synchronize()
+        got = yd.cpu().numpy().astype(np.float64)
+        assert np.max(np.abs(got[:, :n] - want)) <= tol
+        assert np.all(got[:, n:] == 7.0)                                  # padding untouched
+        st.close()

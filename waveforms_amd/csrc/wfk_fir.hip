@@ -75,11 +75,13 @@ std::once_flag g_rocfft_once;
 extern "C" int wfk_internal_fir_fused_launch(int kind, const void* in, int64_t in_stride, void* out,
                                              int64_t out_stride, const void* hspec, const void* tw,
                                              int64_t n, int M, int K, int lead, int64_t nblk,
-                                             int32_t batch, void* stream);
+                                             int32_t batch, int accumulate, void* stream);
 extern "C" int wfk_internal_fir_fused_len(void);
 
 struct wfk_fir_plan {
   bool fused = false;
+  int32_t nseg = 1, Kseg = 0;  // fused: the kernel is cut into nseg segments of Kseg taps, one
+                               // pass of the fused kernel each (passes after the first accumulate)
   void* tw = nullptr;          // fused: exp(-2 pi i j / L), j < 256
   int32_t K = 0, batch = 0, kind = 0, L = 0, M = 0, lead = 0, chunk = 0;
   int64_t n = 0, nblk = 0;
@@ -204,12 +206,22 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
   p->K = K; p->n = n; p->batch = batch; p->kind = kind;
   const int FL = wfk_internal_fir_fused_len();
   const char* force = getenv("WFK_FIR_ROCFFT");
-  p->fused = K <= FL - 2559 && batch <= 65535 && !(force && force[0] == '1');
+  // The fused kernel takes kernels up to FL - 2559 = 1537 taps (hop >= 2560 = 5/8 of the
+  // transform).  Longer kernels are cut into up to WFK_FIR_MAXSEG equal segments,
+  //   out[i] = sum_j sum_k' ker[j*Kseg + k'] sig[(i + K//2 - j*Kseg) - k'],
+  // i.e. one pass per segment with its own input offset, accumulating: 2-4 x 9.4 ms (+ the
+  // re-read of `out`) against ~66 ms of the rocFFT pipeline on 256 x 1e7 fp64.
+  const int KMAX = FL - 2559, WFK_FIR_MAXSEG = 4;
+  p->nseg = (K + KMAX - 1) / KMAX;
+  p->Kseg = (K + p->nseg - 1) / p->nseg;
+  p->fused = p->nseg <= WFK_FIR_MAXSEG && batch <= 65535 && !(force && force[0] == '1');
+  if (!p->fused) { p->nseg = 1; p->Kseg = K; }
   int L = 1024;
   while (L < 8 * K) L *= 2;               // hop M = L - K + 1 >= 7/8 L
   if (const char* e = getenv("WFK_FIR_L")) { int v = atoi(e); if (v >= 2 * K && (v & (v - 1)) == 0) L = v; }
   if (p->fused) L = FL;
-  p->L = L; p->M = L - K + 1; p->lead = (K - 1) - K / 2;
+  const int Kt = p->fused ? p->Kseg : K;             // taps per transform
+  p->L = L; p->M = L - Kt + 1; p->lead = (Kt - 1) - K / 2;   // fused: + j*Kseg for segment j
   p->nblk = n > 0 ? (n + p->M - 1) / p->M : 0;
   if (n == 0) { *out = p; return WFK_OK; }
   const size_t es = kind == WFK_OUT_F32 ? 4 : 8;
@@ -238,7 +250,7 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
     return fir_fail(WFK_ENOMEM, "FIR buffer allocation failed");
   }
   }
-  if (hipMalloc(&p->kspec, nf * 2 * es) != hipSuccess ||
+  if (hipMalloc(&p->kspec, (size_t)p->nseg * nf * 2 * es) != hipSuccess ||
       (p->fused && hipMalloc(&p->tw, 256 * 2 * es) != hipSuccess)) {
     wfk_fir_plan_destroy(p);
     return fir_fail(WFK_ENOMEM, "FIR buffer allocation failed");
@@ -249,18 +261,23 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
     long double th = -2.0L * 3.141592653589793238462643383279502884L * i / L;
     tw[i] = {cosl(th), sinl(th)};
   }
-  std::vector<double> ks64(2 * nf);
-  std::vector<float> ks32(2 * nf);
-  for (size_t f = 0; f < nf; ++f) {
-    std::complex<long double> acc = 0;
-    for (int k = 0; k < K; ++k) acc += (long double)ker_host[k] * tw[(size_t)((f * (size_t)k) % L)];
-    acc /= (long double)L;
-    ks64[2 * f] = (double)acc.real(); ks64[2 * f + 1] = (double)acc.imag();
-    ks32[2 * f] = (float)acc.real(); ks32[2 * f + 1] = (float)acc.imag();
+  std::vector<double> ks64(2 * nf * p->nseg);
+  std::vector<float> ks32(2 * nf * p->nseg);
+  for (int sg = 0; sg < p->nseg; ++sg) {
+    const int k0 = sg * p->Kseg, k1 = std::min(K, k0 + (p->fused ? p->Kseg : K));
+    for (size_t f = 0; f < nf; ++f) {
+      std::complex<long double> acc = 0;
+      for (int k = k0; k < k1; ++k)
+        acc += (long double)ker_host[k] * tw[(size_t)((f * (size_t)(k - k0)) % L)];
+      acc /= (long double)L;
+      const size_t at = 2 * (sg * nf + f);
+      ks64[at] = (double)acc.real(); ks64[at + 1] = (double)acc.imag();
+      ks32[at] = (float)acc.real(); ks32[at + 1] = (float)acc.imag();
+    }
   }
   hipError_t e = kind == WFK_OUT_F32
-                     ? hipMemcpy(p->kspec, ks32.data(), nf * 8, hipMemcpyHostToDevice)
-                     : hipMemcpy(p->kspec, ks64.data(), nf * 16, hipMemcpyHostToDevice);
+                     ? hipMemcpy(p->kspec, ks32.data(), ks32.size() * 4, hipMemcpyHostToDevice)
+                     : hipMemcpy(p->kspec, ks64.data(), ks64.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess && p->fused) {
     std::vector<double> t64(512);
     std::vector<float> t32(512);
@@ -287,9 +304,12 @@ int wfk_fir_apply(wfk_fir_plan* p, const void* in_dev, int64_t in_stride, void* 
   if (in_stride < p->n || out_stride < p->n) return fir_fail(WFK_EINVAL, "stride smaller than n");
   hipStream_t s = (hipStream_t)hip_stream;
   if (p->fused) {
-    if (wfk_internal_fir_fused_launch(p->kind, in_dev, in_stride, out_dev, out_stride, p->kspec,
-                                      p->tw, p->n, p->M, p->K, p->lead, p->nblk, p->batch, s))
-      return fir_fail(WFK_EHIP, "fused FIR kernel launch failed");
+    const size_t seg_bytes = (size_t)p->L * 2 * (p->kind == WFK_OUT_F32 ? 4 : 8);
+    for (int sg = 0; sg < p->nseg; ++sg)
+      if (wfk_internal_fir_fused_launch(p->kind, in_dev, in_stride, out_dev, out_stride,
+                                        (const char*)p->kspec + sg * seg_bytes, p->tw, p->n, p->M,
+                                        p->Kseg, p->lead + sg * p->Kseg, p->nblk, p->batch, sg > 0, s))
+        return fir_fail(WFK_EHIP, "fused FIR kernel launch failed");
     return WFK_OK;
   }
   if (p->nblk > 65535) return fir_fail(WFK_EINVAL, "signal too long for one rocFFT FIR plan (blocks > 65535)");

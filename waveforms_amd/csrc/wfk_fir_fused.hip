@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
                                                  T* __restrict__ out, int64_t out_stride,
                                                  const cx<T>* __restrict__ hspec,
                                                  const cx<T>* __restrict__ tw, int64_t n, int M,
-                                                 int K, int lead) {
+                                                 int K, int lead, int accumulate) {
   __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
   const int tid = threadIdx.x;
   const int64_t pair = blockIdx.x, ch = blockIdx.y;
@@ -200,8 +200,9 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
     const int r = tid + 256 * q3 - (K - 1);
     if (r >= 0 && r < M) {
       const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
-      if (d1 < n) orow[d1] = v[q3].x;
-      if (d2 < n) orow[d2] = v[q3].y;
+      // accumulate: a later segment of a kernel longer than one transform allows (wfk_fir.hip)
+      if (d1 < n) orow[d1] = accumulate ? orow[d1] + v[q3].x : v[q3].x;
+      if (d2 < n) orow[d2] = accumulate ? orow[d2] + v[q3].y : v[q3].y;
     }
   }
 }
@@ -212,17 +213,17 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
 extern "C" int wfk_internal_fir_fused_launch(int kind, const void* in, int64_t in_stride, void* out,
                                              int64_t out_stride, const void* hspec, const void* tw,
                                              int64_t n, int M, int K, int lead, int64_t nblk,
-                                             int32_t batch, void* stream) {
+                                             int32_t batch, int accumulate, void* stream) {
   const dim3 grid((unsigned)((nblk + 1) / 2), (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   if (kind == WFK_OUT_F32)
     hipLaunchKernelGGL(fir_fused<float>, grid, dim3(256), 0, s, (const float*)in, in_stride,
                        (float*)out, out_stride, (const cx<float>*)hspec, (const cx<float>*)tw, n, M,
-                       K, lead);
+                       K, lead, accumulate);
   else
     hipLaunchKernelGGL(fir_fused<double>, grid, dim3(256), 0, s, (const double*)in, in_stride,
                        (double*)out, out_stride, (const cx<double>*)hspec, (const cx<double>*)tw, n,
-                       M, K, lead);
+                       M, K, lead, accumulate);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
