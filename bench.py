@@ -55,6 +55,31 @@ def workload(name, channels, points):
     raise SystemExit(f'unknown workload {name}')
 
 
+def _c_oracle_worker(job):
+    """One channel of the headline workload through the plain-C oracle (own process)."""
+    seed, grid_desc = job
+    import waveforms_amd as wf
+    from oracle import c_oracle
+    from waveforms_amd import _flatten, workloads as wl
+    prog = _flatten.flatten([wl.sum_channel(wf, 100, seed)])
+    y = c_oracle.eval_grid(prog, _flatten.grid_from_desc(grid_desc))
+    return float(y.sum())
+
+
+def c_oracle_all_cores(grid_desc, n_points, procs=16):
+    """The plain-C oracle on `procs` host cores at once (one channel per process, spawned:
+    the parent holds a HIP context and must not be forked)."""
+    import multiprocessing as mp
+    procs = max(1, min(procs, os.cpu_count() or 1))
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(procs) as pool:
+        pool.map(_c_oracle_worker, [(1000 + c, ('linspace', 0.0, 1e-9, 8, False)) for c in range(procs)])
+        t0 = time.perf_counter()                      # workers are up and the library is loaded
+        pool.map(_c_oracle_worker, [(1000 + c, grid_desc) for c in range(procs)], chunksize=1)
+        dt = time.perf_counter() - t0
+    return procs * n_points / dt / 1e6, procs
+
+
 def cpu_baseline(chans, grid_desc, budget_s=12.0):
     """Reference-like NumPy path (oracle/np_oracle.py: same pass structure as the
     reference's calc_parts/_calc/_fill_parts) timed single-threaded on this box's
@@ -86,6 +111,10 @@ def cpu_baseline(chans, grid_desc, budget_s=12.0):
         c_oracle.eval_grid(prog, g)
         dc = time.perf_counter() - t1
         base['c_oracle_msamples_per_s_1thread'] = 2 * len(t) / dc / 1e6
+        # third figure: the same C oracle on 16 host cores at once (the box's CPU share)
+        rate, procs = c_oracle_all_cores(grid_desc, len(t))
+        base['c_oracle_msamples_per_s_multi'] = rate
+        base['c_oracle_multi_procs'] = procs
     except Exception as exc:  # the C oracle is optional for the bench
         base['c_oracle_error'] = repr(exc)
     return base, outs
