@@ -1,0 +1,30 @@
+"""Where the time of a drop-in call on 1e7 points goes (C2 channel): tlist `wav(t)` and grid `wav.sample()`."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import waveforms_amd as wf
+from waveforms_amd import workloads as wl, _flatten, _engine
+
+w = wl.c2_channel(wf)
+n = 10**7
+t = np.linspace(0, 100 * wl.SPAN, n, endpoint=False)
+c = time.perf_counter
+for rep in range(3):
+    t0 = c(); prog = _flatten.flatten([w])
+    t1 = c(); plan = _engine.Plan(prog, t=t)
+    t2 = c(); out = np.empty((1, n))
+    t3 = c(); _engine.check(_engine.lib().wfk_plan_run_host(plan._h, out.ctypes.data, n, 0))
+    t4 = c(); _engine.check(_engine.lib().wfk_plan_run_host(plan._h, out.ctypes.data, n, 0))
+    t5 = c(); plan.close()
+    print('tlist: flatten %.2f  plan(create+upload t) %.2f  empty %.3f  run_host(fresh out) %.2f  run_host(touched out) %.2f ms'
+          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3))
+g = _flatten.grid_from_desc(('linspace', 0.0, 100 * wl.SPAN, n, False))
+for rep in range(3):
+    t1 = c(); plan = _engine.Plan(prog, grid=g)
+    t2 = c(); out = np.empty((1, n))
+    t3 = c(); _engine.check(_engine.lib().wfk_plan_run_host(plan._h, out.ctypes.data, n, 0))
+    t4 = c(); _engine.check(_engine.lib().wfk_plan_run_host(plan._h, out.ctypes.data, n, 0))
+    t5 = c(); plan.close()
+    print('grid : plan %.2f  run_host(fresh out) %.2f  run_host(touched out) %.2f ms' % ((t2 - t1) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3))
+t0 = c(); y = w(t); print('w(t) total %.2f ms' % ((c() - t0) * 1e3))
+t0 = c(); y = w(t); print('w(t) total %.2f ms' % ((c() - t0) * 1e3))
