@@ -1,0 +1,41 @@
+"""Long differential fuzz (not part of the suite): random scripts x grids, HIP vs the C oracle.
+usage: python tools/fuzz_soak.py [first_seed] [count]   -> prints failing seeds"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import cases
+import waveforms_amd as wf
+from oracle import c_oracle
+from waveforms_amd import _engine, _flatten
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad, t0 = [], time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(10_000 + seed)
+    try:
+        ch, grid = cases.random_channel(wf, rng)
+        prog = _flatten.flatten([ch])
+        g = _flatten.grid_from_desc(grid)
+        ora = c_oracle.eval_grid(prog, g)[0]
+        pk = max(1.0, float(np.max(np.abs(ora)))) if ora.size else 1.0
+        plan = _engine.Plan(prog, grid=g)
+        got = plan.run_host(np.float64)[0]
+        e64 = float(np.max(np.abs(got - ora), initial=0.0))
+        got32 = plan.run_host(np.float32)[0].astype(np.float64)
+        e32 = float(np.max(np.abs(got32 - ora), initial=0.0))
+        tl = _engine.Plan(prog, t=c_oracle.grid_values(g)).run_host(np.float64)[0]
+        etl = float(np.max(np.abs(tl - ora), initial=0.0))
+        if not (e64 <= 1e-9 * pk and e32 <= 5e-5 * pk and etl <= 1e-11 * pk) or \
+                (np.all(np.isfinite(ora)) and not np.all(np.isfinite(got))):
+            bad.append((seed, e64 / pk, e32 / pk, etl / pk))
+            print('FAIL', bad[-1], flush=True)
+    except NotImplementedError as e:
+        pass
+    except Exception as e:
+        bad.append((seed, repr(e)))
+        print('ERROR', bad[-1], flush=True)
+    if (seed - first) % 250 == 249:
+        print(f'{seed - first + 1} scripts, {len(bad)} failures, {time.time() - t0:.0f} s', flush=True)
+print('done', count, 'scripts;', len(bad), 'failures', bad[:10])
