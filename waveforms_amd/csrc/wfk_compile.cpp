@@ -226,6 +226,22 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     f32_ok = f64_ok && vext <= 8.0 && 2.0 * vext * Hs + Hs * Hs <= 80.0;
   };
 
+  // The uniform-grid fast paths evaluate sample j0 + 64 k at t(j0) + k * 64 * step, the reference
+  // at NumPy's rounded grid value fl(fl(i*step) + t0).  The two differ by up to ~one ulp of
+  // |i*step| + |t_i|; a carrier turns that into a phase difference W * dt_jitter, a Gaussian into
+  // (u/sigma^2) * dt_jitter.  Negligible for the BASELINE configs (1e-12), but a waveform sampled
+  // 16 ms away from t = 0 with a 300 MHz carrier sees 3e-9.  Where the bound exceeds
+  // WFK_JITTER_TOL the factor keeps the exact per-sample time (device libm) instead.
+  constexpr double WFK_JITTER_TOL = 2.5e-10;
+  auto grid_jitter = [&](int64_t s0, int64_t s1) -> double {
+    if (!grid || s1 <= s0) return 0.0;
+    const double m = std::max(std::fabs(ax.at(s0)), std::fabs(ax.at(s1 - 1)));
+    return 1.2e-16 * (m + std::fabs((double)(s1 - 1) * grid->step));
+  };
+  auto rate_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {   // |d value / dt| <= rate
+    return std::fabs(rate) * grid_jitter(s0, s1) <= WFK_JITTER_TOL;
+  };
+
   // ---- factor record emission -------------------------------------------------
   auto emit_factor = [&](BlockBuilder& B, int32_t f, double tshift, int64_t s0, int64_t s1) {
     const int type = P->fc_type[f];
@@ -241,7 +257,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       double umax = std::max(std::fabs(ua), std::fabs(ub));
       if (type == WFK_LINEAR) {
         rec[0] = WFK_M_LIN_REC; rec[3] = dstride; fast = true;
-      } else if (type == WFK_COS && std::isfinite(a[0])) {
+      } else if (type == WFK_COS && std::isfinite(a[0]) && rate_safe(a[0], s0, s1)) {
         rec[0] = WFK_M_COS_TAB; rec[3] = a[0]; fast = true;
         table = table_for(B, a[0] * dstride);
       } else if (type == WFK_GAUSSIAN) {
@@ -249,14 +265,14 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         // outside the piece, so the range check includes that overhang.
         bool ok64, ok32;
         gauss_range(a[0], shift, tshift, s0, s1, ok64, ok32);
-        if (ok64) {                                // exp(-676) ~ 1e-294: normal fp64
+        if (ok64 && rate_safe(0.86 / a[0], s0, s1)) {   // exp(-676) ~ 1e-294: normal fp64
           double Hh = dstride / a[0];
           rec[0] = WFK_M_GAUSS_REC; rec[3] = a[0]; rec[4] = Hh; rec[5] = std::exp(-2.0 * Hh * Hh);
           // fp32 state is safe only while g and r stay inside float's exponent range
           rec[9] = ok32 ? 1.0 : 0.0;
           fast = true;
         }
-      } else if (type == WFK_EXP && std::isfinite(a[0])) {
+      } else if (type == WFK_EXP && std::isfinite(a[0]) && rate_safe(a[0], s0, s1)) {
         double ext = std::fabs(a[0]) * (umax + dstride * NS);
         if (ext <= 600.0) {
           rec[0] = WFK_M_EXP_REC; rec[3] = a[0]; rec[4] = std::exp(a[0] * dstride);
@@ -362,7 +378,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           if (pw != 1.0 || has_env) return false;
           bool ok64;
           gauss_range(a[0], sh, tshift, s0, s1, ok64, env32);
-          if (!ok64) return false;
+          if (!ok64 || !rate_safe(0.86 / a[0], s0, s1)) return false;
           has_env = true; sigma = a[0]; sg = sh;
           break;
         }
@@ -403,6 +419,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     const double cs[1] = {first_cos_shift};
     // stage the contributions; commit only if every carrier finds/creates a group
     std::vector<FceGroup> staged = groups;
+    for (const Car& q : cars)
+      if (!rate_safe((double)q.W, s0, s1)) return false;
     for (Car q : cars) {
       if (q.W < 0) { q.W = -q.W; q.Psi = -q.Psi; }
       const double W = (double)q.W;
@@ -429,7 +447,15 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       // multiply by u_term^p with u_term = u_group + d
       long double d = 0.0L;
       if (p > 0) {
-        if (!G->has_lin) { G->has_lin = true; G->slin = slin; }
+        // the group's polynomial variable is centred on the piece (u = t' - slin with slin the
+        // mid time of [s0, s1)), not on the first term's own origin: |u| stays <= half the piece
+        // span, which keeps the float evaluation of A(u), B(u) free of the cancellation a far
+        // origin brings (poly() terms have theirs at t = 0)
+        if (!G->has_lin) {
+          G->has_lin = true;
+          G->slin = 0.5 * (ax.at(s0) + ax.at(s1 - 1)) - tshift;
+          if (!std::isfinite(G->slin)) G->slin = slin;
+        }
         d = (long double)G->slin - slin;
       }
       static const int binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
