@@ -13,6 +13,11 @@ for seed in [int(a) for a in sys.argv[1:]]:
     nch = int(rng.integers(1, 4))
     chans = [ch] + [cases.random_channel(wf, rng)[0] for _ in range(nch - 1)]
     npts = int(rng.integers(100000, 3000000))
+    if os.environ.get('OFFSET'):
+        off = (grid[2] - grid[1]) * 10.0**rng.uniform(2, 7) * (1 if rng.random() < 0.5 else -1)
+        chans = [c >> off for c in chans]
+        grid = (grid[0], grid[1] + off, grid[2] + off) + tuple(grid[3:])
+        npts = int(rng.integers(1000, 300000))
     grid = ('linspace', grid[1], grid[2], npts, bool(rng.random() < 0.5))
     g = _flatten.grid_from_desc(grid)
     t = wl.make_grid(grid)
@@ -34,3 +39,11 @@ for seed in [int(a) for a in sys.argv[1:]]:
               '| worst at i=%d t=%.6g' % (i, t[i]))
         if np.abs(gpu - ora).max() / pk > 1e-9 or np.abs(g32 - ora).max() / pk > 5e-5:
             print('   script:', w.tolist()[:60])
+        if os.environ.get('WHERE') and np.abs(gpu - ora).max() / pk > 1e-9:
+            badi = np.nonzero(np.abs(gpu - ora) > 1e-9 * pk)[0]
+            print('   bad count', len(badi), 'first', badi[:8], 'last', badi[-3:])
+            i0 = badi[0]
+            print('   around first: gpu', gpu[i0 - 2:i0 + 3], '\n                 C  ', ora[i0 - 2:i0 + 3])
+            m0, m1 = prog.member_range(0)
+            for m in range(m0, min(m1, m0 + 6)):
+                print('   member', m, 'idx', plan.member_index(m)[:12])

@@ -11,6 +11,7 @@ from waveforms_amd import _engine, _flatten
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+OFFSET = len(sys.argv) > 3 and sys.argv[3] == 'offset'
 bad, t0 = [], time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(77_000 + seed)
@@ -20,6 +21,12 @@ for seed in range(first, first + count):
     scale = (grid[2] - grid[1])
     chans = [ch] + [cases.random_channel(wf, rng)[0] for _ in range(nch - 1)]
     npts = int(rng.integers(100000, 3000000))
+    if OFFSET:
+        # everything (pulses and grid) far from t = 0: offsets of 1e2..1e7 grid spans
+        off = (grid[2] - grid[1]) * 10.0**rng.uniform(2, 7) * (1 if rng.random() < 0.5 else -1)
+        chans = [c >> off for c in chans]
+        grid = (grid[0], grid[1] + off, grid[2] + off) + tuple(grid[3:])
+        npts = int(rng.integers(1000, 300000))
     grid = ('linspace', grid[1], grid[2], npts, bool(rng.random() < 0.5))
     try:
         prog = _flatten.flatten(chans)

@@ -255,7 +255,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       // time range of the piece on this channel's shifted axis
       double ua = (ax.at(s0) - tshift) - shift, ub = (ax.at(s1 - 1) - tshift) - shift;
       double umax = std::max(std::fabs(ua), std::fabs(ub));
-      if (type == WFK_LINEAR) {
+      if (type == WFK_LINEAR && (umax > 0.0 ? rate_safe(1.0 / umax, s0, s1) : grid_jitter(s0, s1) == 0.0)) {
+        // (u itself: the jitter must be negligible against the largest |u| of the piece)
         rec[0] = WFK_M_LIN_REC; rec[3] = dstride; fast = true;
       } else if (type == WFK_COS && std::isfinite(a[0]) && rate_safe(a[0], s0, s1)) {
         rec[0] = WFK_M_COS_TAB; rec[3] = a[0]; fast = true;
@@ -369,11 +370,15 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       const double pw = P->fc_power[f], sh = P->fc_shift[f];
       const double* a = P->pool + P->fc_arg_off[f];
       switch (P->fc_type[f]) {
-        case WFK_LINEAR:
+        case WFK_LINEAR: {
           if (!(pw == 1.0 || pw == 2.0 || pw == 3.0)) return false;
           if (has_lin && sh != slin) return false;
+          const double ua = (ax.at(s0) - tshift) - sh, ub = (ax.at(s1 - 1) - tshift) - sh;
+          const double um = std::max(std::fabs(ua), std::fabs(ub));
+          if (!(um > 0.0) || !rate_safe(pw / um, s0, s1)) return false;   // grid jitter vs |u|
           has_lin = true; slin = sh; p += (int)pw;
           break;
+        }
         case WFK_GAUSSIAN: {
           if (pw != 1.0 || has_env) return false;
           bool ok64;
