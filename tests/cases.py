@@ -405,3 +405,17 @@ def fuzz_golden_case(wf, seed):
         n = max(1, min(1500, int(np.ceil((grid[2] - grid[1]) / grid[3]))))
         grid = ('arange', grid[1], grid[2], (grid[2] - grid[1]) / n)
     return ch, grid
+
+
+def far_from_origin_case(wf, seed):
+    """Random script and grid moved 1e2..1e7 grid spans away from t = 0 (tools/fuzz_soak_big.py
+    'offset'): the regime in which NumPy's grid rounding is visible through fast carriers."""
+    rng = np.random.default_rng(77_000 + seed)
+    ch, grid = random_channel(wf, rng)
+    nch = int(rng.integers(1, 4))
+    chans = [ch] + [random_channel(wf, rng)[0] for _ in range(nch - 1)]
+    rng.integers(100000, 3000000)
+    off = (grid[2] - grid[1]) * 10.0**rng.uniform(2, 7) * (1 if rng.random() < 0.5 else -1)
+    chans = [c >> off for c in chans]
+    npts = int(rng.integers(1000, 300000))
+    return chans, ('linspace', grid[1] + off, grid[2] + off, npts, bool(rng.random() < 0.5))

@@ -73,3 +73,19 @@ def test_random_script_vs_reference_golden(seed):
     t = c_oracle.grid_values(g)
     tl = ch(t)                                   # drop-in __call__ (tlist mode)
     assert np.max(np.abs(np.real(tl) - want), initial=0.0) <= 1e-9 * pk, seed
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_far_from_origin(seed):
+    """Pulses and grid 1e2..1e7 spans away from t = 0: NumPy's grid values are then visibly
+    rounded (one ulp of |t|), the reference evaluates AT those rounded times, and a fast carrier
+    turns the rounding into phase.  The host takes such factors off the uniform-grid fast paths
+    (wfk_compile.cpp: grid_jitter / rate_safe); before that guard 289 of 1500 such scripts were
+    off by up to 4e-6."""
+    chans, grid = cases.far_from_origin_case(wf, seed)
+    prog = _flatten.flatten(chans)
+    g = _flatten.grid_from_desc(grid)
+    ora = c_oracle.eval_grid(prog, g)
+    pk = max(1.0, float(np.max(np.abs(ora))))
+    got = _engine.Plan(prog, grid=g).run_host(np.float64)
+    assert np.max(np.abs(got - ora)) <= 1e-9 * pk, seed
