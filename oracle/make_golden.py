@@ -115,6 +115,11 @@ def main():
         assert not np.iscomplexobj(y) or np.all(y.imag == 0)
         fuzz[f'{seed}.y'] = y.real.astype(np.float64)
         fuzz_lists[str(seed)] = [enc(v) for v in w.tolist()]
+    for seed in range(cases.FAR_GOLD):     # the same generator, everything far from t = 0
+        chans, grid = cases.far_golden_case(ref, seed)
+        t = wl.make_grid(grid)
+        for c, w in enumerate(chans):
+            fuzz[f'far{seed}.{c}'] = np.asarray(w(t)).real.astype(np.float64)
     np.savez_compressed(os.path.join(gold, 'fuzz.npz'), **fuzz)
     with open(os.path.join(gold, 'fuzz_frontend.json'), 'w') as f:
         json.dump(fuzz_lists, f)

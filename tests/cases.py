@@ -419,3 +419,11 @@ def far_from_origin_case(wf, seed):
     chans = [c >> off for c in chans]
     npts = int(rng.integers(1000, 300000))
     return chans, ('linspace', grid[1] + off, grid[2] + off, npts, bool(rng.random() < 0.5))
+
+
+FAR_GOLD = 40        # far-from-origin scripts evaluated by the real reference (fuzz.npz: far<seed>.<ch>)
+
+
+def far_golden_case(wf, seed):
+    chans, grid = far_from_origin_case(wf, seed)
+    return chans, (grid[0], grid[1], grid[2], min(grid[3], 1500), grid[4])

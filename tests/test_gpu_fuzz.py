@@ -89,3 +89,16 @@ def test_far_from_origin(seed):
     pk = max(1.0, float(np.max(np.abs(ora))))
     got = _engine.Plan(prog, grid=g).run_host(np.float64)
     assert np.max(np.abs(got - ora)) <= 1e-9 * pk, seed
+
+
+@pytest.mark.parametrize('seed', range(cases.FAR_GOLD))
+def test_far_from_origin_vs_reference_golden(seed):
+    chans, grid = cases.far_golden_case(wf, seed)
+    g = _flatten.grid_from_desc(grid)
+    got = _engine.Plan(_flatten.flatten(chans), grid=g).run_host(np.float64)
+    t = c_oracle.grid_values(g)
+    for c, w in enumerate(chans):
+        want = FUZZ[f'far{seed}.{c}']
+        pk = max(1.0, float(np.max(np.abs(want))))
+        assert np.max(np.abs(got[c] - want)) <= 1e-9 * pk, (seed, c)
+        assert np.max(np.abs(np.real(w(t)) - want)) <= 1e-9 * pk, (seed, c)     # drop-in, tlist

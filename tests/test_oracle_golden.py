@@ -136,3 +136,17 @@ def test_oracles_match_reference_on_random_scripts(seed):
     g = _flatten.grid_from_desc(grid)
     assert np.array_equal(c_oracle.grid_values(g), t)
     close(c_oracle.eval_grid(prog, g)[0], want, rel=1e-11)
+
+
+@pytest.mark.parametrize('seed', range(cases.FAR_GOLD))
+def test_oracles_match_reference_far_from_origin(seed):
+    """Pulses and grid far from t = 0 (NumPy's grid rounding visible through the carriers): the
+    oracles evaluate at the rounded grid values exactly like the reference."""
+    chans, grid = cases.far_golden_case(wf, seed)
+    t = wl.make_grid(grid)
+    g = _flatten.grid_from_desc(grid)
+    assert np.array_equal(c_oracle.grid_values(g), t)
+    for c, w in enumerate(chans):
+        want = FUZZ[f'far{seed}.{c}']
+        close(np.asarray(np_oracle.call(w, t)).real.astype(np.float64), want, rel=1e-13)
+        close(c_oracle.eval_grid(_flatten.flatten([w]), g)[0], want, rel=1e-11)
