@@ -189,6 +189,10 @@ def _sample_iter(w, sample_rate, chunk_size, out, function_lib, filters):
             yield _sample_on_grid(w, grid, None if out is None else out[start_n:],
                                   function_lib)
         else:
+            if size == 0:
+                # a last chunk of zero samples (start one ulp short of stop): the reference hands
+                # it to scipy.signal.sosfilt, which rejects an empty signal (waveform.py:249)
+                raise ValueError('cannot reshape array of size 0 into shape (0)')
             sig, zi = _sample_on_grid(w, grid, None, function_lib, filters, zi)
             if out is not None:
                 out[start_n:start_n + size] = sig
