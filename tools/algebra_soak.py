@@ -1,0 +1,93 @@
+"""Differential fuzz of the symbolic front-end against the REAL reference, run in the build
+container only (imports /root/reference through oracle/make_golden.import_reference; never
+part of the suite, nothing from the reference is stored).  Random expression trees over both
+namespaces in lockstep: constructors, + - * / ** >> <<, D(), mixing(), cut/clip, simplify(),
+filter(), vstacks; compares tolist() element by element (and == / simplify results).
+usage: python tools/algebra_soak.py [count]"""
+import os, sys, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import numpy as np
+import make_golden
+ref = make_golden.import_reference()
+import waveforms_amd as ours
+from test_frontend_golden import same
+
+
+def leaf(ns, rng, scale):
+    k = int(rng.integers(0, 14))
+    w = scale * rng.uniform(0.5, 5)
+    if k == 0: return ns.gaussian(w)
+    if k == 1: return ns.cosPulse(w)
+    if k == 2: return ns.square(w, edge=w * rng.uniform(0.05, 0.3), type=str(rng.choice(['erf', 'cos', 'linear'])))
+    if k == 3: return ns.square(w)
+    if k == 4: return ns.cos(rng.uniform(0.5, 5) / scale, rng.uniform(0, 6))
+    if k == 5: return ns.sin(rng.uniform(0.5, 5) / scale, rng.uniform(0, 6))
+    if k == 6: return ns.const(rng.uniform(-2, 2))
+    if k == 7: return ns.t()
+    if k == 8: return ns.exp(rng.uniform(-1, 1) / scale)
+    if k == 9: return ns.sinc(rng.uniform(0.5, 3) / scale)
+    if k == 10: return ns.step(w * 0.2, type=str(rng.choice(['erf', 'cos', 'linear'])))
+    if k == 11: return ns.poly([rng.uniform(-1, 1), rng.uniform(-1, 1) / scale, rng.uniform(-1, 1) / scale**2])
+    if k == 12: return ns.gaussian(w, plateau=scale * rng.uniform(0.1, 2))
+    return ns.zero() if rng.random() < 0.3 else ns.one()
+
+
+def tree(ns, rng, scale, depth):
+    if depth == 0 or rng.random() < 0.25:
+        return leaf(ns, rng, scale)
+    op = int(rng.integers(0, 11))
+    a = tree(ns, rng, scale, depth - 1)
+    if op == 0: return a + tree(ns, rng, scale, depth - 1)
+    if op == 1: return a - tree(ns, rng, scale, depth - 1)
+    if op == 2: return a * tree(ns, rng, scale, depth - 1)
+    if op == 3: return a * rng.uniform(-2, 2)
+    if op == 4: return a / rng.uniform(0.5, 2)
+    if op == 5: return a >> (scale * rng.uniform(-5, 5))
+    if op == 6: return a << (scale * rng.uniform(-5, 5))
+    if op == 7: return a ** int(rng.integers(2, 4))
+    if op == 8: return -a
+    if op == 9: return rng.uniform(-1, 1) + a
+    return a * leaf(ns, rng, scale)
+
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+bad = []
+for it in range(count):
+    res = []
+    for ns in (ref, ours):
+        rng = np.random.default_rng(55_000 + it)
+        scale = 10.0**rng.uniform(-9, 0)
+        try:
+            w = tree(ns, rng, scale, int(rng.integers(1, 5)))
+            post = int(rng.integers(0, 6))
+            if post == 1:
+                w = w.simplify()
+            elif post == 2:
+                I, Q = ns.mixing(w, freq=rng.uniform(-3, 3) / scale, phase=rng.uniform(0, 6),
+                                 DRAGScaling=None if rng.random() < 0.5 else rng.uniform(-0.1, 0.1) * scale)
+                w = I if rng.random() < 0.5 else Q
+            elif post == 3:
+                w = ns.D(w)
+            elif post == 4:
+                w = ns.cut(w, start=-scale, stop=scale, min=-0.5, max=0.7)
+            elif post == 5:
+                w = w.filter(low=0, high=rng.uniform(0.5, 5) / scale) if hasattr(w, 'filter') else w
+            res.append(('ok', w.tolist(), w))
+        except Exception as e:
+            res.append(('exc', type(e).__name__, None))
+    (ka, la, wa), (kb, lb, wb) = res
+    if ka != kb:
+        bad.append((it, 'ref ' + str((ka, la if ka == 'exc' else '')), 'ours ' + str((kb, lb if kb == 'exc' else ''))))
+    elif ka == 'exc':
+        if la != lb:
+            bad.append((it, 'exception types', la, lb))
+    else:
+        if len(la) != len(lb) or not all(same(x, y) for x, y in zip(lb, la)):
+            n = next((i for i, (x, y) in enumerate(zip(la, lb)) if not same(y, x)), min(len(la), len(lb)))
+            bad.append((it, 'list differs at', n, la[max(0, n - 2):n + 3], lb[max(0, n - 2):n + 3], len(la), len(lb)))
+    if bad and bad[-1][0] == it:
+        print('FAIL', bad[-1], flush=True)
+    if it % 500 == 499:
+        print(f'{it + 1} trees, {len(bad)} mismatches', flush=True)
+print('done', count, 'trees;', len(bad), 'mismatches')
