@@ -69,7 +69,21 @@ struct DevBlockCache {
       }
     }
     *cap = b;
-    return hipMalloc(out, b);
+    hipError_t e = hipMalloc(out, b);
+    if (e != hipSuccess) {
+      // out of device memory with blocks parked here: give them back and try once more
+      (void)hipGetLastError();
+      trim();
+      e = hipMalloc(out, b);
+    }
+    return e;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& kv : free_)
+      for (void* p : kv.second) (void)hipFree(p);
+    free_.clear();
+    cached = 0;
   }
   void put(void* ptr, size_t cap, int dev) {
     if (!ptr) return;
