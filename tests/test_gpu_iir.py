@@ -128,7 +128,7 @@ def test_iir_batch_shapes_and_properties():
     for order in (1, 2, 3, 4, 5, 6):
         b, a = butter(order, 0.05 + 0.02 * order)
         shapes.append([(b, a)])
-    for order in (2, 4, 6, 8):
+    for order in (2, 4, 6, 8, 10, 12, 16):     # 5+ biquads: consecutive passes of <= 4 each
         sos = butter(order, 0.08, output='sos')
         shapes.append([(r[:3], r[3:]) for r in sos])
     b1, a1 = butter(1, 0.1)
@@ -169,3 +169,19 @@ def test_iir_batch_shapes_and_properties():
     plan.apply(xd.data_ptr(), n, xd.data_ptr(), n, None, None, 0.7)
     torch.cuda.synchronize()
     assert np.max(np.abs(xd.cpu().numpy().astype(np.float64) - want)) <= 1e-5
+
+
+def test_long_cascade_fp32_initial_in_place():
+    """8 biquads = two passes of four; fp32 I/O, DC `initial`, in place, no zi/zf."""
+    import torch
+    rng = np.random.default_rng(12)
+    n = 70_001
+    sos = butter(16, 0.1, output='sos')
+    x = rng.normal(size=(2, n)) + 0.3
+    want = np.stack([sosfilt(sos, r - 0.3) + 0.3 for r in x])
+    plan = _engine.IirPlan([(r[:3], r[3:]) for r in sos], n, 2, np.float32)
+    assert plan.state_dim == 16
+    xd = torch.from_numpy(x).float().cuda()
+    plan.apply(xd.data_ptr(), n, xd.data_ptr(), n, None, None, 0.3)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(xd.cpu().numpy().astype(np.float64) - want)) <= 2e-5

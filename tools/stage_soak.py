@@ -23,7 +23,7 @@ for it in range(count):
     if not e <= 1e-11:
         bad.append(('fir', n, K, e)); print('FAIL', bad[-1], flush=True)
     # IIR: random stable cascade
-    nsec = int(rng.integers(1, 5))
+    nsec = int(rng.integers(1, 9))
     if rng.random() < 0.5:
         z = rng.uniform(-0.95, 0.95, size=2 * nsec) * np.exp(1j * rng.uniform(0, 0.5, size=2 * nsec))
         r = rng.uniform(0.2, 0.9995, size=nsec); th = rng.uniform(0, 3.1, size=nsec)

@@ -23,6 +23,7 @@
 // global loads/stores are 512-byte contiguous per instruction.  State is always double.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -356,12 +357,22 @@ struct wfk_iir_plan {
   double* lanep = nullptr;   // [64][D][D][2]  T^(l+1)
   double* pw2 = nullptr;     // the same for U = T^64
   double* lanep2 = nullptr;
+  // A cascade of more than 4 biquads has no register-resident kernel (its 10+ state values
+  // would go to scratch: 34 ms instead of 3.3 on 64 x 1e7).  It runs as consecutive passes of
+  // <= 4 biquads each, in place on `out`, every pass with its own slice of zi / zf.
+  std::vector<wfk_iir_plan*> parts;
+  std::vector<int> part_off;     // state offset of each part
+  double* zi_tmp = nullptr;      // [batch][D_part] repacked state slices
+  double* zf_tmp = nullptr;
 };
 
 extern "C" {
 
 int wfk_iir_plan_destroy(wfk_iir_plan* p) {
   if (!p) return WFK_OK;
+  for (wfk_iir_plan* q : p->parts) wfk_iir_plan_destroy(q);
+  (void)hipFree(p->zi_tmp);
+  (void)hipFree(p->zf_tmp);
   (void)hipFree(p->state);
   (void)hipFree(p->grp);
   (void)hipFree(p->pw);
@@ -416,6 +427,27 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     return iir_fail(WFK_EHIP, "no HIP device visible");
   }
   if (n == 0 || D == 0) { *out = p; return WFK_OK; }
+  {
+    bool biquads = n_sections > 4;
+    for (int s = 0; s < n_sections; ++s) biquads = biquads && orders[s] == 2;
+    if (biquads) {
+      for (int s0 = 0; s0 < n_sections; s0 += 4) {
+        const int cnt = std::min(4, n_sections - s0);
+        wfk_iir_plan* q = nullptr;
+        int rc = wfk_iir_plan_create(cnt, orders + s0, b + 3 * s0, a + 3 * s0, n, batch, kind, &q);
+        if (rc) { wfk_iir_plan_destroy(p); return rc; }
+        p->parts.push_back(q);
+        p->part_off.push_back(2 * s0);
+      }
+      if (hipMalloc(&p->zi_tmp, (size_t)batch * 8 * 8) != hipSuccess ||
+          hipMalloc(&p->zf_tmp, (size_t)batch * 8 * 8) != hipSuccess) {
+        wfk_iir_plan_destroy(p);
+        return iir_fail(WFK_ENOMEM, "IIR buffer allocation failed");
+      }
+      *out = p;
+      return WFK_OK;
+    }
+  }
   // LB-step transition matrix T: column i = homogeneous response to unit state e_i
   std::vector<quad> T((size_t)D * D);
   for (int i = 0; i < D; ++i) {
@@ -474,7 +506,7 @@ int wfk_iir_state_dim(const wfk_iir_plan* p) { return p ? p->c.D : WFK_EINVAL; }
 
 template <typename T, int NSEC, int ORD>
 static void iir_launch_t(wfk_iir_plan* p, const void* in, int64_t is, void* out, int64_t os,
-                         const double* zi, double* zf, double initial, hipStream_t s) {
+                         const double* zi, double* zf, double initial, double post, hipStream_t s) {
   const dim3 g((unsigned)p->ngrp, (unsigned)p->batch);
   hipLaunchKernelGGL((iir_pass<T, false, NSEC, ORD>), g, dim3(64), 0, s, p->c, (const T*)in, is,
                      (T*)nullptr, (int64_t)0, p->state, p->grp, p->pw, p->lanep, (double*)nullptr,
@@ -483,38 +515,70 @@ static void iir_launch_t(wfk_iir_plan* p, const void* in, int64_t is, void* out,
                      zi, p->ngrp, p->c.D);
   hipLaunchKernelGGL((iir_pass<T, true, NSEC, ORD>), g, dim3(64), 0, s, p->c, (const T*)in, is,
                      (T*)out, os, p->state, p->grp, p->pw, p->lanep, zf, p->n, p->nblk, initial,
-                     initial);
+                     post);
 }
 
 template <typename T>
 static void iir_launch(wfk_iir_plan* p, const void* in, int64_t is, void* out, int64_t os,
-                       const double* zi, double* zf, double initial, hipStream_t s) {
+                       const double* zi, double* zf, double initial, double post, hipStream_t s) {
   const IirCoef& c = p->c;
   bool uniform = true;
   for (int k = 1; k < c.nsec; ++k) uniform = uniform && c.ord[k] == c.ord[0];
   const int ns = c.nsec, od = c.ord[0];
-#define IIR_CASE(NS, OD) if (uniform && ns == NS && od == OD) return iir_launch_t<T, NS, OD>(p, in, is, out, os, zi, zf, initial, s)
+#define IIR_CASE(NS, OD) if (uniform && ns == NS && od == OD) return iir_launch_t<T, NS, OD>(p, in, is, out, os, zi, zf, initial, post, s)
   IIR_CASE(1, 2); IIR_CASE(2, 2); IIR_CASE(3, 2); IIR_CASE(4, 2);      // sosfilt cascades
   IIR_CASE(1, 1); IIR_CASE(1, 3); IIR_CASE(1, 4); IIR_CASE(1, 5); IIR_CASE(1, 6);  // lfilter
 #undef IIR_CASE
-  iir_launch_t<T, 0, 0>(p, in, is, out, os, zi, zf, initial, s);
+  iir_launch_t<T, 0, 0>(p, in, is, out, os, zi, zf, initial, post, s);
 }
 
 extern "C" {
 
-int wfk_iir_apply(wfk_iir_plan* p, const void* in_dev, int64_t in_stride, void* out_dev,
-                  int64_t out_stride, const double* zi_dev, double* zf_dev, double initial,
-                  void* hip_stream) {
+// y = F(x - pre) + post   (the public entry has pre == post == `initial`)
+static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride, void* out_dev,
+                          int64_t out_stride, const double* zi_dev, double* zf_dev, double initial,
+                          double post, void* hip_stream) {
   if (!p) return iir_fail(WFK_EINVAL, "null plan");
   if (p->n == 0) return WFK_OK;
   if (!in_dev || !out_dev) return iir_fail(WFK_EINVAL, "null buffer");
   if (in_stride < p->n || out_stride < p->n) return iir_fail(WFK_EINVAL, "stride smaller than n");
   hipStream_t s = (hipStream_t)hip_stream;
   if (p->c.D == 0) return iir_fail(WFK_EINVAL, "order-0 filter: use a scale instead");
-  if (p->kind == WFK_OUT_F32) iir_launch<float>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, s);
-  else iir_launch<double>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, s);
+  if (!p->parts.empty()) {
+    const size_t D = (size_t)p->c.D;
+    for (size_t i = 0; i < p->parts.size(); ++i) {
+      wfk_iir_plan* q = p->parts[i];
+      const size_t Di = (size_t)q->c.D, off = (size_t)p->part_off[i];
+      if (zi_dev &&
+          hipMemcpy2DAsync(p->zi_tmp, Di * 8, zi_dev + off, D * 8, Di * 8, (size_t)p->batch,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return iir_fail(WFK_EHIP, "IIR state repack failed");
+      // the DC offset comes off before the first pass and goes back on after the last one only:
+      // between passes the signal can be 1e-7 of the offset (a 16th-order Butterworth after its
+      // first four sections), which an fp32 buffer holding signal + offset would wipe out
+      const bool first = i == 0, last = i + 1 == p->parts.size();
+      int rc = iir_apply_impl(q, first ? in_dev : out_dev, first ? in_stride : out_stride, out_dev,
+                              out_stride, zi_dev ? p->zi_tmp : nullptr, zf_dev ? p->zf_tmp : nullptr,
+                              first ? initial : 0.0, last ? post : 0.0, hip_stream);
+      if (rc) return rc;
+      if (zf_dev &&
+          hipMemcpy2DAsync(zf_dev + off, D * 8, p->zf_tmp, Di * 8, Di * 8, (size_t)p->batch,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return iir_fail(WFK_EHIP, "IIR state repack failed");
+    }
+    return WFK_OK;
+  }
+  if (p->kind == WFK_OUT_F32) iir_launch<float>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, post, s);
+  else iir_launch<double>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, post, s);
   if (hipGetLastError() != hipSuccess) return iir_fail(WFK_EHIP, "IIR kernel launch failed");
   return WFK_OK;
+}
+
+extern "C" int wfk_iir_apply(wfk_iir_plan* p, const void* in_dev, int64_t in_stride, void* out_dev,
+                             int64_t out_stride, const double* zi_dev, double* zf_dev,
+                             double initial, void* hip_stream) {
+  return iir_apply_impl(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, initial,
+                        hip_stream);
 }
 
 }  // extern "C"
