@@ -125,7 +125,7 @@ def test_iir_batch_shapes_and_properties():
     import torch
     rng = np.random.default_rng(11)
     shapes = []
-    for order in (1, 2, 3, 4, 5, 6):
+    for order in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         b, a = butter(order, 0.05 + 0.02 * order)
         shapes.append([(b, a)])
     for order in (2, 4, 6, 8, 10, 12, 16):     # 5+ biquads: consecutive passes of <= 4 each

@@ -36,7 +36,7 @@ for it in range(count):
         got, gzf = distortion.iir_host(sig, secs, zi=zi0.reshape(-1))
         gzf = np.asarray(gzf).reshape(-1, 2)
     else:
-        order = int(rng.integers(1, 7))
+        order = int(rng.integers(1, 10))
         p = rng.uniform(0.1, 0.999, size=order) * rng.choice([-1, 1], size=order)
         a = np.poly(p); b = rng.normal(size=order + 1)
         zi0 = rng.normal(size=order) * 0.1

@@ -528,6 +528,7 @@ static void iir_launch(wfk_iir_plan* p, const void* in, int64_t is, void* out, i
 #define IIR_CASE(NS, OD) if (uniform && ns == NS && od == OD) return iir_launch_t<T, NS, OD>(p, in, is, out, os, zi, zf, initial, post, s)
   IIR_CASE(1, 2); IIR_CASE(2, 2); IIR_CASE(3, 2); IIR_CASE(4, 2);      // sosfilt cascades
   IIR_CASE(1, 1); IIR_CASE(1, 3); IIR_CASE(1, 4); IIR_CASE(1, 5); IIR_CASE(1, 6);  // lfilter
+  IIR_CASE(1, 7); IIR_CASE(1, 8);   // predistort(filters=) combines its sections into ONE polynomial
 #undef IIR_CASE
   iir_launch_t<T, 0, 0>(p, in, is, out, os, zi, zf, initial, post, s);
 }
