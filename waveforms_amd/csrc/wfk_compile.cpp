@@ -284,10 +284,37 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     }
     if (!fast) {
       switch (type) {
-        case WFK_INTERP:
+        case WFK_INTERP: {
           rec[3] = a[0]; rec[4] = a[1]; rec[5] = (double)(na - 2); rec[6] = (double)H.pool.size();
           H.pool.insert(H.pool.end(), a + 2, a + na);
+          // np.interp's per-sample slope (fp[j+1]-fp[j]) / (xp[j+1]-xp[j]) once per knot, in the
+          // same IEEE double operations (this file is built -ffp-contract=off), and 1/step for an
+          // O(1) knot index: the device then skips the binary search and the division
+          const int64_t m = na - 2;
+          const double start = a[0], stop = a[1];
+          rec[7] = -1.0;
+          if (m >= 2 && stop > start && std::isfinite(start) && std::isfinite(stop)) {
+            const double step = (stop - start) / (double)(m - 1);
+            auto X = [&](int64_t k) {
+              if (k == m - 1) return stop;
+              volatile double q = (double)k * step;
+              return q + start;
+            };
+            rec[7] = (double)H.pool.size();
+            rec[8] = 1.0 / step;
+            rec[9] = step;
+            const double* fp = a + 2;
+            for (int64_t j = 0; j + 1 < m; ++j) {
+              volatile double dy = fp[j + 1] - fp[j], dx = X(j + 1) - X(j);
+              H.pool.push_back(dy / dx);
+            }
+            H.pool.push_back(0.0);
+            // grid mode: same arithmetic, but the knot/slope loads (L2 latency) of four samples
+            // are in flight together instead of one dependent load pair per sample
+            if (!H.tlist && !nofast && pw == 1.0 && !std::getenv("WFK_NO_INTERP_GRID")) rec[0] = WFK_M_INTERP_GRID;
+          }
           break;
+        }
         case WFK_MOLLIFIER: {
           int d = (int)a[1];
           rec[3] = a[0]; rec[4] = d;

@@ -131,6 +131,16 @@ __device__ double np_linspace_at(double start, double stop, int64_t m, int64_t k
   return a + start;
 }
 
+// the same with the step (one IEEE division, done by the host) passed in: the division was most
+// of the cost of a knot lookup
+__device__ __forceinline__ double np_linspace_at_s(double start, double stop, int64_t m, int64_t k,
+                                                   double step) {
+#pragma clang fp contract(off)
+  if (k == m - 1) return stop;
+  double a = (double)k * step;
+  return a + start;
+}
+
 __device__ double prim_interp(double x, double start, double stop, const double* fp, int64_t m) {
 #pragma clang fp contract(off)
   if (isnan(x)) return x;
@@ -150,6 +160,31 @@ __device__ double prim_interp(double x, double start, double stop, const double*
   double r = slope * (x - xj) + fp[j];
   if (isnan(r)) {
     r = slope * (x - xj1) + fp[j + 1];
+    if (isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
+  }
+  return r;
+}
+
+// The same np.interp result with the knot found from an O(1) guess (corrected against the
+// exact knot abscissae, so the index is the one the binary search finds) and the slope read
+// from the host's table.  Requires stop > start, m >= 2 (the host checks).
+__device__ double prim_interp_fast(double x, double start, double stop, const double* fp,
+                                   const double* sl, int64_t m, double inv_step, double step) {
+#pragma clang fp contract(off)
+  if (isnan(x)) return x;
+  if (x > stop) return fp[m - 1];
+  if (x < start) return fp[0];
+  int64_t j = (int64_t)((x - start) * inv_step);
+  j = j < 0 ? 0 : (j > m - 1 ? m - 1 : j);
+  while (j > 0 && x < np_linspace_at_s(start, stop, m, j, step)) --j;
+  while (j < m - 1 && x >= np_linspace_at_s(start, stop, m, j + 1, step)) ++j;
+  if (j == m - 1) return fp[j];
+  const double xj = np_linspace_at_s(start, stop, m, j, step);
+  if (xj == x) return fp[j];
+  const double slope = sl[j];
+  double r = slope * (x - xj) + fp[j];
+  if (isnan(r)) {
+    r = slope * (x - np_linspace_at_s(start, stop, m, j + 1, step)) + fp[j + 1];
     if (isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
   }
   return r;
@@ -257,7 +292,10 @@ __device__ double prim_direct(int type, double u, const double* r, const double*
     case WFK_COS: return cos(r[3] * u);
     case WFK_SINC: { double x = r[3] * u; double y = PI * (x == 0 ? 1.0e-20 : x); return sin(y) / y; }
     case WFK_EXP: return exp(r[3] * u);
-    case WFK_INTERP: return prim_interp(u, r[3], r[4], pool + (int64_t)r[6], (int64_t)r[5]);
+    case WFK_INTERP:
+      if (r[7] >= 0.0)
+        return prim_interp_fast(u, r[3], r[4], pool + (int64_t)r[6], pool + (int64_t)r[7], (int64_t)r[5], r[8], r[9]);
+      return prim_interp(u, r[3], r[4], pool + (int64_t)r[6], (int64_t)r[5]);
     case WFK_LINEARCHIRP:
       return sin(r[6] + 2 * PI * ((r[4] - r[3]) / (2 * r[5]) * (u * u) + r[3] * u));
     case WFK_EXPONENTIALCHIRP: return sin(r[5] + 2 * PI * r[3] * (exp(r[4] * u) - 1) / r[4]);
@@ -284,7 +322,8 @@ __device__ double np_power(double v, double n) {
 // blk: LDS parameter block, r: this factor's record inside it, j0: lane's first sample.
 template <typename T, bool TLIST, bool DIRECT, int NS>
 __device__ __forceinline__ void apply_factor(const double* blk, const double* r, const KArgs& a,
-                                             double tshift, int64_t j0, T (&prod)[NS]) {
+                                             double tshift, int64_t j0, T (&prod)[NS],
+                                             double* s_val) {
   const int mode = uni((int)r[0]);
   const double shift = r[2];
   if (!TLIST && mode >= 100) {
@@ -343,6 +382,56 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
           e *= rho;
         }
       }
+    } else if (mode == WFK_M_INTERP_GRID) {
+      // np.interp (reference _waveform.pyx:309-311) at the exact per-sample grid times; same
+      // operations as prim_interp_fast, restructured so that a batch of four samples has its
+      // eight table loads in flight at once
+#pragma clang fp contract(off)
+      const double start = r[3], stop = r[4], inv_step = r[8], step = r[9];
+      const int64_t m = (int64_t)r[5];
+      const double* fp = a.pool + (int64_t)r[6];
+      const double* sl = a.pool + (int64_t)r[7];
+#pragma unroll
+      for (int k0 = 0; k0 < NS; k0 += 4) {
+        double xs[4], xj[4], f0[4], sv[4];
+        int64_t js[4];
+        bool flat[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (k0 + kk < NS) {
+            double x = grid_time(a, j0 + 64 * (int64_t)(k0 + kk));
+            if (tshift != 0.0) x = x - tshift;
+            x = x - shift;
+            int64_t j;
+            bool fl = true;
+            if (!(x <= stop)) j = m - 1;              // x > stop, or NaN (patched below)
+            else if (x < start) j = 0;
+            else {
+              j = (int64_t)((x - start) * inv_step);
+              j = j < 0 ? 0 : (j > m - 1 ? m - 1 : j);
+              while (j > 0 && x < np_linspace_at_s(start, stop, m, j, step)) --j;
+              while (j < m - 1 && x >= np_linspace_at_s(start, stop, m, j + 1, step)) ++j;
+              fl = j == m - 1;
+            }
+            xs[kk] = x; js[kk] = j;
+            xj[kk] = np_linspace_at_s(start, stop, m, j, step);
+            flat[kk] = fl || xj[kk] == x;
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          if (k0 + kk < NS) { f0[kk] = fp[js[kk]]; sv[kk] = sl[js[kk]]; }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (k0 + kk < NS) {
+            double v = flat[kk] ? f0[kk] : sv[kk] * (xs[kk] - xj[kk]) + f0[kk];
+            if (isnan(xs[kk])) v = xs[kk];
+            else if (isnan(v))   // non-finite table values: the scalar routine's fallbacks
+              v = prim_interp_fast(xs[kk], start, stop, fp, sl, m, inv_step, step);
+            prod[k0 + kk] *= (T)v;
+          }
+        }
+      }
     } else {  // WFK_M_LIN_REC
       const double D = r[3];
 #pragma unroll
@@ -351,21 +440,24 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
     return;
   }
   if (!DIRECT) return;  // fast-only build: the plan holds no direct factor
-  // direct evaluation: a rolled loop (small code) that rotates the register array so
-  // that every access keeps a compile-time index
+  // direct evaluation: a rolled loop (small code: prim_direct is one big switch over libm
+  // calls) that parks the NS values of this thread in LDS, then an unrolled pass multiplies
+  // them into the register array with compile-time indices.  (Rotating the register array
+  // through the rolled loop instead cost ~30 moves per sample and factor, more than most
+  // primitives.)  Every thread reads back only what it wrote itself: no barrier.
   const double pw = r[1];
   const bool has_pw = pw != 1.0;
+  double* mine = s_val + threadIdx.x;
 #pragma unroll 1
   for (int k = 0; k < NS; ++k) {
     double x = time_at<TLIST>(a, j0 + 64 * (int64_t)k);
     if (tshift != 0.0) x = x - tshift;
     double v = prim_direct(mode, x - shift, r, a.pool);
     if (has_pw) v = np_power(v, pw);
-    const T head = prod[0] * (T)v;
-#pragma unroll
-    for (int i = 0; i < NS - 1; ++i) prod[i] = prod[i + 1];
-    prod[NS - 1] = head;
+    mine[k * WFK_WG] = v;
   }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) prod[k] *= (T)mine[k * WFK_WG];
 }
 
 // ---- fused carrier-envelope op over the wave tile (see WFK_FCE_* ) --------------
@@ -727,6 +819,7 @@ wfk_sample_lean(const KArgs a) {
 template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
 __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
+  __shared__ double s_val[DIRECT ? NS * WFK_WG : 1];   // direct-factor values (apply_factor)
   constexpr int WT = 64 * NS;
   constexpr int TILE = WFK_WG * NS;
   using OutR = typename OutOps<T>::Real;
@@ -795,7 +888,7 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) prod[i] = (T)1;
             for (int f = 0; f < nf; ++f) {
-              apply_factor<T, TLIST, DIRECT, NS>(s_par, s_par + pos, a, C.tshift, j0, prod);
+              apply_factor<T, TLIST, DIRECT, NS>(s_par, s_par + pos, a, C.tshift, j0, prod, s_val);
               pos += WFK_FREC;
             }
 #pragma unroll
