@@ -311,7 +311,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
             H.pool.push_back(0.0);
             // grid mode: same arithmetic, but the knot/slope loads (L2 latency) of four samples
             // are in flight together instead of one dependent load pair per sample
-            if (!H.tlist && !nofast && pw == 1.0 && !std::getenv("WFK_NO_INTERP_GRID")) rec[0] = WFK_M_INTERP_GRID;
+            if (!H.tlist && !nofast && pw == 1.0 && m < (int64_t(1) << 31) && !std::getenv("WFK_NO_INTERP_GRID"))
+              rec[0] = WFK_M_INTERP_GRID;
           }
           break;
         }

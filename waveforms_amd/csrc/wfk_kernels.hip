@@ -86,7 +86,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // t[j] = fl(fl(j*step) + t0): NumPy's linspace/arange element formula, two roundings.
 __device__ __forceinline__ double grid_time(const KArgs& a, int64_t j) {
 #pragma clang fp contract(off)
-  double m = (double)j * a.step;
+  // (int64 -> double is a multi-instruction sequence on this ISA, uint32 -> double is one: the
+  //  per-sample callers of the direct tier feel it; both conversions are exact)
+  const double dj = a.n <= 0xffffffffLL ? (double)(uint32_t)j : (double)j;
+  double m = dj * a.step;
   double t = m + a.t0;
   if (a.has_last && j == a.n - 1) t = a.last;
   return t;
@@ -135,6 +138,13 @@ __device__ double np_linspace_at(double start, double stop, int64_t m, int64_t k
 // of the cost of a knot lookup
 __device__ __forceinline__ double np_linspace_at_s(double start, double stop, int64_t m, int64_t k,
                                                    double step) {
+#pragma clang fp contract(off)
+  if (k == m - 1) return stop;
+  double a = (double)k * step;
+  return a + start;
+}
+
+__device__ __forceinline__ double np_linspace_at_s(double start, double stop, int m, int k, double step) {
 #pragma clang fp contract(off)
   if (k == m - 1) return stop;
   double a = (double)k * step;
@@ -388,13 +398,13 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
       // eight table loads in flight at once
 #pragma clang fp contract(off)
       const double start = r[3], stop = r[4], inv_step = r[8], step = r[9];
-      const int64_t m = (int64_t)r[5];
+      const int m = (int)r[5];                       // knots: < 2^31 (host-checked)
       const double* fp = a.pool + (int64_t)r[6];
       const double* sl = a.pool + (int64_t)r[7];
 #pragma unroll
       for (int k0 = 0; k0 < NS; k0 += 4) {
         double xs[4], xj[4], f0[4], sv[4];
-        int64_t js[4];
+        int js[4];
         bool flat[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -402,12 +412,12 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
             double x = grid_time(a, j0 + 64 * (int64_t)(k0 + kk));
             if (tshift != 0.0) x = x - tshift;
             x = x - shift;
-            int64_t j;
+            int j;
             bool fl = true;
             if (!(x <= stop)) j = m - 1;              // x > stop, or NaN (patched below)
             else if (x < start) j = 0;
             else {
-              j = (int64_t)((x - start) * inv_step);
+              j = (int)((x - start) * inv_step);
               j = j < 0 ? 0 : (j > m - 1 ? m - 1 : j);
               while (j > 0 && x < np_linspace_at_s(start, stop, m, j, step)) --j;
               while (j < m - 1 && x >= np_linspace_at_s(start, stop, m, j + 1, step)) ++j;
