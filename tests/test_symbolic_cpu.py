@@ -132,3 +132,19 @@ def test_design_helpers_match_reference():
     assert got == [bool(x) for x in G['stable']]
     from waveforms_amd.waveform import convolve
     assert convolve(wf.one(), wf.one()) is None      # a stub in the reference too (not exported)
+
+
+def test_cli_argument_parsing():
+    """The reference's CLI surface (waveforms/__main__.py:10-31): sub-command `sample`, option
+    letters, defaults, and `--duration` taking effect only against the default stop."""
+    from waveforms_amd.__main__ import _build_parser
+    p = _build_parser()
+    a = p.parse_args(['sample', 'gaussian(10) >> 5', 'out.npy'])
+    assert (a.sample_rate, a.start, a.duration, a.stop, a.amplitude) == (44100, 0, -1, 1, 1)
+    a = p.parse_args(['sample', '-S', '10', '-a', '2', '-l', '5', '-A', '3', 'one()', 'o.npy'])
+    assert (a.sample_rate, a.start, a.duration, a.stop, a.amplitude) == (10, 2, 5, 1, 3)
+    assert all(isinstance(v, int) for v in (a.sample_rate, a.start, a.duration, a.stop, a.amplitude))
+    a = p.parse_args(['sample', '--sample-rate', '2e9', '--stop', '1e-6', 'one()', 'o.npy'])
+    assert a.sample_rate == 2e9 and a.stop == 1e-6
+    with pytest.raises(SystemExit):
+        p.parse_args(['play', 'one()'])
