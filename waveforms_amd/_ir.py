@@ -105,9 +105,19 @@ def _merge_into(keys: list, vals: list, key, val, lo: int, hi: int):
 def add(x, y):
     """x + y on (keys, values) pairs: used for expr+expr (terms/amps) and, by
     `mul`, for term*term (factors/powers) (reference: _waveform.pyx:82-88)."""
+    kx, ky = x[0], y[0]
+    if type(kx) is tuple and type(ky) is tuple:     # (malformed operands take the long way and
+        if not ky:                                  #  fail exactly where the reference fails)
+            return x                                # nothing to merge in
+        if not kx:
+            # merging into nothing reproduces y whenever y's keys already ascend (then every
+            # insertion lands at the end of the window): the case of "zero piece + pulse"
+            n = len(ky)
+            if n == 1 or all(ky[i] < ky[i + 1] for i in range(n - 1)):
+                return y
     keys, vals = list(x[0]), list(x[1])
     lo, hi = 0, len(keys)
-    for k, v in zip(y[0], y[1]):
+    for k, v in zip(ky, y[1]):
         lo, hi = _merge_into(keys, vals, k, v, lo, hi)
     return tuple(keys), tuple(vals)
 
@@ -115,6 +125,8 @@ def add(x, y):
 def mul(x, y):
     """Product of two expressions, distributing over terms
     (reference: _waveform.pyx:68-79)."""
+    if type(x[0]) is tuple and type(y[0]) is tuple and (not x[0] or not y[0]):
+        return ZERO                 # a zero operand: no term survives
     keys, vals = [], []
     lo = hi = 0
     for (tx, ty), (ax, ay) in zip(itertools.product(x[0], y[0]),
