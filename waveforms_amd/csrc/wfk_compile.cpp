@@ -92,6 +92,7 @@ struct FceGroup {
   double sigma = 0, sg = 0, slin = 0;
   long double A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
   int deg = 0, nterms = 0;
+  bool imag = false;            // the group adds to the IMAGINARY part of the output
 };
 
 struct BlockBuilder {
@@ -371,7 +372,9 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
 
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
                        int64_t s1) -> bool {
-    if (P->tm_amp_im[k] != 0.0) return false;
+    // a complex amplitude a + ib contributes a * (...) to the real part and b * (...) to the
+    // imaginary part of the output: two real-coefficient contributions, the second into groups
+    // marked `imag` (their op accumulates into the imaginary accumulators)
     const int32_t f0 = P->tm_factor_off[k], f1 = P->tm_factor_off[k + 1];
     int p = 0, ncos = 0;
     bool has_lin = false, has_env = false, env32 = false;
@@ -446,26 +449,32 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           return false;
       }
     }
-    if (p > 3 || !std::isfinite(P->tm_amp_re[k])) return false;
+    if (p > 3 || !std::isfinite(P->tm_amp_re[k]) || !std::isfinite(P->tm_amp_im[k])) return false;
     if (cars.empty()) cars.push_back({1.0L, 0.0L, 0.0L});
-    for (Car& q : cars) q.c *= (long double)P->tm_amp_re[k];
     const double cs[1] = {first_cos_shift};
     // stage the contributions; commit only if every carrier finds/creates a group
     std::vector<FceGroup> staged = groups;
     for (const Car& q : cars)
       if (!rate_safe((double)q.W, s0, s1)) return false;
+    for (int part = 0; part < 2; ++part) {
+    const long double amp_part = part == 0 ? (long double)P->tm_amp_re[k] : (long double)P->tm_amp_im[k];
+    if (amp_part == 0.0L) continue;                 // nothing in this part
+    const bool imag = part == 1;
     for (Car q : cars) {
+      q.c *= amp_part;
       if (q.W < 0) { q.W = -q.W; q.Psi = -q.Psi; }
       const double W = (double)q.W;
       // (a sum/difference frequency is rounded to double: relative error <= 2^-53, the
       //  same class as the reference's own rounding of w*t)
       FceGroup* G = nullptr;
       for (FceGroup& g : staged)
-        if (g.W == W && g.has_env == has_env && (!has_env || (g.sigma == sigma && g.sg == sg))) { G = &g; break; }
+        if (g.W == W && g.imag == imag && g.has_env == has_env &&
+            (!has_env || (g.sigma == sigma && g.sg == sg))) { G = &g; break; }
       if (!G) {
         staged.emplace_back();
         G = &staged.back();
         G->W = W; G->has_env = has_env; G->sigma = sigma; G->sg = sg; G->env32 = env32;
+        G->imag = imag;
         G->sref = W == 0.0 ? 0.0 : (ncos == 1 ? cs[0] : (double)(q.Psi / q.W));
         G->psi_ref = (long double)W * G->sref;
       }
@@ -500,6 +509,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       if (p > G->deg) G->deg = p;
       ++G->nterms;
     }
+    }
     groups.swap(staged);
     return true;
   };
@@ -530,7 +540,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
     }
     rec[WFK_FCE_D] = dstride;
-    rec[WFK_FCE_CARRIER] = G.W != 0.0 ? 1.0 : 0.0;
+    rec[WFK_FCE_CARRIER] = (G.W != 0.0 ? 1.0 : 0.0) + (G.imag ? 2.0 : 0.0);   // bit 0 carrier, bit 1 imaginary part
     size_t at = B.body.size();
     B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
     if (G.W != 0.0) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));

@@ -57,7 +57,7 @@
 #define WFK_FCE_F32OK 18
 #define WFK_FCE_TAB 19
 #define WFK_FCE_D 20
-#define WFK_FCE_CARRIER 21    // 0: W == 0 (no phasor needed)
+#define WFK_FCE_CARRIER 21    // bit 0: W != 0 (phasor needed); bit 1: the op adds to the IMAGINARY part
 
 // factor evaluation modes (record slot 0).  1..15 = direct evaluation of that
 // primitive with device libm; >=100 = uniform-grid fast paths (power == 1).

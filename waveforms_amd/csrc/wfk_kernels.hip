@@ -601,7 +601,7 @@ __device__ __forceinline__ void fce_env(const double2* tab, const double* r, Fce
 __device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x) {
   const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
   return fce_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), -(v * v), -Hh * (2.0 * v + Hh),
-                   uni((int)r[WFK_FCE_CARRIER]), uni((int)r[WFK_FCE_ENV]));
+                   uni((int)r[WFK_FCE_CARRIER]) & 1, uni((int)r[WFK_FCE_ENV]));
 }
 
 // run one fused op over the wave tile from the given state; `wide_env`: keep the
@@ -610,7 +610,7 @@ template <typename T, int NS>
 __device__ __forceinline__ void fce_eval(const double* blk, const double* r, FceSeeds& sd,
                                          double x, bool wide_env, T (&acc)[NS]) {
   const int deg = uni((int)r[WFK_FCE_DEG]);
-  const int carrier = uni((int)r[WFK_FCE_CARRIER]);
+  const int carrier = uni((int)r[WFK_FCE_CARRIER]) & 1;   // (bit 1: imaginary-part op, see the callers)
   int env = uni((int)r[WFK_FCE_ENV]);
   if (env && sizeof(T) == 4 && (wide_env || uni((int)r[WFK_FCE_F32OK]) == 0)) env = 2;
   const double2* tab = reinterpret_cast<const double2*>(blk + uni((int)r[WFK_FCE_TAB]));
@@ -734,7 +734,8 @@ template <typename T, bool CPLX, int NS>
 #ifndef WFK_LEAN_WAVES_F32
 #define WFK_LEAN_WAVES_F32 4   // fp32: 120 VGPRs, 10 KB LDS per wave -> 4 waves per SIMD (latency-bound kernel)
 #endif
-__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? WFK_LEAN_WAVES_F32 : WFK_LEAN_WAVES))
+// (complex outputs carry two accumulator sets: one wave per SIMD fewer, no spills)
+__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? WFK_LEAN_WAVES_F32 : WFK_LEAN_WAVES) - (CPLX ? 1 : 0))
 wfk_sample_lean(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LEAN_PAR];
   __shared__ double s_c[WFK_LEAN_OPS][64], s_s[WFK_LEAN_OPS][64], s_g[WFK_LEAN_OPS][64],
@@ -805,7 +806,14 @@ wfk_sample_lean(const KArgs a) {
           sd.s = s_s[op][lane];
           sd.g = s_g[op][lane];
           sd.r = s_r[op][lane];
-          fce_eval<T, NS>(s_par, s_par + WFK_BLK_HDR + op * WFK_FCE_REC, sd, x, true, acc);
+          const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
+          // an op of the imaginary part (complex amplitudes) adds into acci; a real-output
+          // launch of such a channel keeps the real part only, like WaveVStack's `.real`
+          if (uni((int)rec[WFK_FCE_CARRIER]) & 2) {
+            if constexpr (CPLX) fce_eval<T, NS>(s_par, rec, sd, x, true, acci);
+          } else {
+            fce_eval<T, NS>(s_par, rec, sd, x, true, acc);
+          }
           s_c[op][lane] = sd.c;
           s_s[op][lane] = sd.s;
           s_g[op][lane] = sd.g;
@@ -886,7 +894,11 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
           for (int k = 0; k < nops; ++k) {
             const int kind = uni((int)s_par[pos]);
             if (!TLIST && kind == WFK_OP_FCE) {
-              apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acc);
+              if (uni((int)s_par[pos + WFK_FCE_CARRIER]) & 2) {
+                if constexpr (CPLX) apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acci);
+              } else {
+                apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acc);
+              }
               pos += WFK_FCE_REC;
               continue;
             }
