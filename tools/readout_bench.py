@@ -1,0 +1,32 @@
+"""Frequency-multiplexed readout-style channels: 10 tones under one flat-top envelope with erf edges
+(square(width, edge) * sum of carriers), 50 pulses per channel: many carriers per piece, ERF on the
+edge pieces.  python tools/readout_bench.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import waveforms_amd as wf
+from waveforms_amd._sampling import BatchSampler
+nch, n, T = 64, 10**7, 3e-6
+rng = np.random.default_rng(0)
+chans = []
+for c in range(nch):
+    tones = None
+    for k in range(10):
+        tone = rng.uniform(0.05, 0.1) * wf.cos(2 * np.pi * rng.uniform(-300e6, 300e6), rng.uniform(0, 6))
+        tones = tone if tones is None else tones + tone
+    w = wf.zero()
+    for k in range(50):
+        w = w + ((wf.square(30e-9, edge=4e-9) >> ((k + 0.5) * 60e-9)) * tones)
+    chans.append(w)
+bs = BatchSampler(chans, ('linspace', 0.0, T, n, False))
+out = torch.empty((nch, n), dtype=torch.float64, device='cuda')
+for _ in range(3): bs.launch_torch(out)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(5): bs.launch_torch(out)
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 5
+i = bs.plan.info
+print(f'multiplexed readout {nch} x {n}: {ms:.2f} ms = {nch * n / ms * 1e-6:.0f} Gsamples/s ({nch * n * 8 / ms * 1e-9 / 8 * 100:.1f}% of 8 TB/s); '
+      f'pieces {i.n_pieces} fused {i.n_fused} generic {i.n_generic} fast {i.n_fast} direct {i.n_direct}')

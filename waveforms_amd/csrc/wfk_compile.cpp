@@ -244,6 +244,13 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   };
 
   // ---- factor record emission -------------------------------------------------
+  // The reference evaluates every distinct factor of a piece once (_calc's cache,
+  // _waveform.pyx:135-147); the generic tier evaluates term by term.  For the expensive case --
+  // a direct (libm) factor shared by consecutive terms, e.g. the erf edge of a flat-top pulse
+  // under ten multiplexed carriers -- the values the previous term left in the workgroup's LDS
+  // value buffer are reused: the repeated record is marked (type + WFK_M_REUSE) when its
+  // signature equals the last direct factor emitted into the same block.
+  std::vector<double> last_direct;      // record of the last direct factor of the current block
   auto emit_factor = [&](BlockBuilder& B, int32_t f, double tshift, int64_t s0, int64_t s1) {
     const int type = P->fc_type[f];
     const double pw = P->fc_power[f], shift = P->fc_shift[f];
@@ -340,6 +347,11 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           for (int64_t k = 0; k < na && k < 6; ++k) rec[3 + k] = a[k];
       }
       ++H.n_direct;
+      std::vector<double> sig(rec, rec + WFK_FREC);
+      const bool pooled = type == WFK_INTERP || type == WFK_MOLLIFIER || type == WFK_DRAG_SIN ||
+                          type == WFK_DRAG_SINX;             // records point into the pool: never equal
+      if (!pooled && rec[0] < 100.0 && sig == last_direct) rec[0] += WFK_M_REUSE;
+      else last_direct = pooled || rec[0] >= 100.0 ? std::vector<double>() : sig;
     } else {
       ++H.n_fast;
     }
@@ -349,6 +361,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   };
 
   auto flush_block = [&](BlockBuilder& B) -> int32_t {
+    last_direct.clear();   // the value buffer is only trusted within one block
     // [len, n_terms, body..., pad?, tables...]
     size_t tab_off = WFK_BLK_HDR + B.body.size();
     if (tab_off & 1) ++tab_off;  // 16-byte aligned tables

@@ -336,6 +336,13 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
                                              double* s_val) {
   const int mode = uni((int)r[0]);
   const double shift = r[2];
+  if (DIRECT && mode >= WFK_M_REUSE) {
+    // the previous term evaluated this very factor: its values are still in the value buffer
+    const double* mine = s_val + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) prod[k] *= (T)mine[k * WFK_WG];
+    return;
+  }
   if (!TLIST && mode >= 100) {
     // seed at the lane's first sample, evaluated exactly as the reference does
     double x = grid_time(a, j0);
