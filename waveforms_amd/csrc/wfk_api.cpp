@@ -290,6 +290,8 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   a.step = p->h.step;
   a.last = p->h.last;
   a.has_last = p->h.has_last;
+  a.lean_par = p->h.lean_par;
+  a.lean_ops = p->h.lean_ops;
   if (hip_stream) p->async_launch = true;
   std::string err;
   int rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.ns, p->h.lean,

@@ -616,6 +616,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
             else generic.push_back(k);
           }
         if (!generic.empty() || groups.size() > WFK_LEAN_OPS) lean_ok = false;
+        H.lean_ops = std::max<int32_t>(H.lean_ops, (int32_t)groups.size());
         for (FceGroup& G : groups) {
           if (room_for(WFK_FCE_REC + 2 * (NS + 1)) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
           emit_group(B, G);
@@ -642,6 +643,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         if (D.n_blk == 0) D.first_len = len;
         ++D.n_blk;
         if (D.n_blk != 1 || len > WFK_LEAN_PAR) lean_ok = false;
+        H.lean_par = std::max<int32_t>(H.lean_par, len);
       }
       // fuse adjacent zero pieces
       if (D.n_blk == 0 && (int32_t)H.pieces.size() > C.piece_begin &&
@@ -658,6 +660,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
   // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
   H.lean = lean_ok && !nolean && H.n_fused > 0;
+  H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
+  H.lean_ops = std::max(4, H.lean_ops);                          // likewise: 4 ops = 8 KB of state
   if (H.lean) H.tile = 64 * H.ns;
   int64_t tiles_per_ch = (ax.n + H.tile - 1) / H.tile;
   int64_t total_tiles = tiles_per_ch * P->n_channels;

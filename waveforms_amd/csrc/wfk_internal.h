@@ -73,12 +73,14 @@
 // "lean" plans: every piece is one block of <= WFK_LEAN_OPS fused ops and nothing else.
 // They run on the wave-per-workgroup kernel that carries per-lane op state across tiles.
 #ifndef WFK_LEAN_OPS
-#define WFK_LEAN_OPS 4
+#define WFK_LEAN_OPS 10       // upper limit (beyond it the occupancy the 2 KB of state per op costs outweighs
+                              // the state carry: 16 tones measured 7.9 ms lean vs 5.8 ms general); LDS is
+                              // reserved for what the plan actually has
 #endif
 // doubles of LDS parameter buffer per wave: header + 4 ops x (22 record + 34 table) = 232.
 // With the 8 KB of per-lane op state that makes 10 KB per wave = 16 waves per CU, which the
 // fp32 kernel (<= 128 VGPRs) uses: 2.11 -> 1.95 ms on 256 x 1e7 fp32 against 512 doubles.
-#define WFK_LEAN_PAR 256
+#define WFK_LEAN_PAR 640      // upper limit (10 ops x 56 doubles + header), reserved per plan as needed
 #define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles
 
 #define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)
@@ -114,6 +116,7 @@ struct KArgs {
   int32_t accumulate;
   double t0, step, last;
   int32_t has_last, pad;
+  int32_t lean_par, lean_ops;  // lean kernel: doubles of parameter block / ops of state to reserve in LDS
 };
 
 #ifdef __cplusplus
@@ -138,6 +141,7 @@ struct HostPlan {
   std::vector<uint8_t> channel_complex;
   int32_t n_fast = 0, n_direct = 0, n_fused = 0, n_generic = 0;
   bool lean = false;           // wave-per-workgroup fused kernel (see WFK_LEAN_*)
+  int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most ops of a piece
 };
 
 // host compiler: flattened program + time axis -> device tables.  Returns 0 or a

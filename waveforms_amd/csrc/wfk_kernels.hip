@@ -744,9 +744,13 @@ template <typename T, bool CPLX, int NS>
 // (complex outputs carry two accumulator sets: one wave per SIMD fewer, no spills)
 __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? WFK_LEAN_WAVES_F32 : WFK_LEAN_WAVES) - (CPLX ? 1 : 0))
 wfk_sample_lean(const KArgs a) {
-  __shared__ __attribute__((aligned(16))) double s_par[WFK_LEAN_PAR];
-  __shared__ double s_c[WFK_LEAN_OPS][64], s_s[WFK_LEAN_OPS][64], s_g[WFK_LEAN_OPS][64],
-      s_r[WFK_LEAN_OPS][64];
+  // LDS is sized per plan (dynamic): the parameter block (a.lean_par doubles) followed by the
+  // per-lane state of the plan's largest piece, (c, s, g, r) x 64 lanes per op.  Plans with up to
+  // four ops per piece (all BASELINE configs) take 10 KB per wave; a ten-tone multiplexed pulse
+  // takes 25 KB instead of falling back to the general kernel.
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double* const s_par = s_dyn;
+  double* const s_st = s_dyn + a.lean_par;      // [op][c | s | g | r][64]
   constexpr int WT = 64 * NS;
   using OutR = typename OutOps<T>::Real;
   using OutC = typename OutOps<T>::Cplx;
@@ -800,19 +804,21 @@ wfk_sample_lean(const KArgs a) {
           // seed phase: libm, nothing else live
           for (int op = 0; op < nops; ++op) {
             const FceSeeds sd = fce_make_seeds(s_par + WFK_BLK_HDR + op * WFK_FCE_REC, x);
-            s_c[op][lane] = sd.c;
-            s_s[op][lane] = sd.s;
-            s_g[op][lane] = sd.g;
-            s_r[op][lane] = sd.r;
+            double* st = s_st + op * 256 + lane;
+            st[0] = sd.c;
+            st[64] = sd.s;
+            st[128] = sd.g;
+            st[192] = sd.r;
           }
           since_seed = 0;
         }
         for (int op = 0; op < nops; ++op) {
           FceSeeds sd;
-          sd.c = s_c[op][lane];
-          sd.s = s_s[op][lane];
-          sd.g = s_g[op][lane];
-          sd.r = s_r[op][lane];
+          double* st = s_st + op * 256 + lane;
+          sd.c = st[0];
+          sd.s = st[64];
+          sd.g = st[128];
+          sd.r = st[192];
           const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
           // an op of the imaginary part (complex amplitudes) adds into acci; a real-output
           // launch of such a channel keeps the real part only, like WaveVStack's `.real`
@@ -821,10 +827,10 @@ wfk_sample_lean(const KArgs a) {
           } else {
             fce_eval<T, NS>(s_par, rec, sd, x, true, acc);
           }
-          s_c[op][lane] = sd.c;
-          s_s[op][lane] = sd.s;
-          s_g[op][lane] = sd.g;
-          s_r[op][lane] = sd.r;
+          st[0] = sd.c;
+          st[64] = sd.s;
+          st[128] = sd.g;
+          st[192] = sd.r;
         }
         state_piece = q;
         state_w0 = w0 + WT;
@@ -942,7 +948,8 @@ template <typename T, bool CPLX, bool TLIST, int NS>
 int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generic, bool direct) {
   const dim3 g((unsigned)blocks), b(WFK_WG);
   if (!TLIST && lean)
-    hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS>), g, dim3(64), 0, s, a);
+    hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS>), g, dim3(64),
+                       (size_t)(a.lean_par + 256 * a.lean_ops) * sizeof(double), s, a);
   else if (TLIST || direct)
     hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, true, true, NS>), g, b, 0, s, a);
   else if (generic)
