@@ -93,6 +93,7 @@ struct FceGroup {
   long double A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
   int deg = 0, nterms = 0;
   bool imag = false;            // the group adds to the IMAGINARY part of the output
+  bool envmul = false;          // pseudo-op: multiply the accumulators by the shared Gaussian envelope
 };
 
 struct BlockBuilder {
@@ -545,7 +546,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     rec[WFK_FCE_A] = (double)A0;
     rec[WFK_FCE_B] = (double)B0;
     for (int i = 1; i < 4; ++i) { rec[WFK_FCE_A + i] = (double)G.A[i]; rec[WFK_FCE_B + i] = (double)G.B[i]; }
-    rec[WFK_FCE_ENV] = G.has_env ? 1.0 : 0.0;
+    rec[WFK_FCE_ENV] = G.envmul ? 3.0 : (G.has_env ? 1.0 : 0.0);
     if (G.has_env) {
       double Hh = dstride / G.sigma;
       rec[WFK_FCE_SIGMA] = G.sigma; rec[WFK_FCE_SG] = G.sg;
@@ -615,6 +616,23 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
             if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
             else generic.push_back(k);
           }
+        // When every carrier of the piece sits under the SAME Gaussian (a frequency-multiplexed
+        // pulse), the envelope is factored out: the ops run without envelope and one closing
+        // pseudo-op multiplies the accumulators by it -- 2 instead of 5 FMAs per sample and tone.
+        // (From four carriers on: the extra op costs a pair of pieces what it saves them.)
+        if (groups.size() >= 4) {
+          bool shared = true, e32 = true;
+          for (const FceGroup& g : groups) {
+            shared = shared && g.has_env && g.sigma == groups[0].sigma && g.sg == groups[0].sg;
+            e32 = e32 && g.env32;
+          }
+          if (shared) {
+            FceGroup E;
+            E.envmul = true; E.has_env = true; E.sigma = groups[0].sigma; E.sg = groups[0].sg; E.env32 = e32;
+            for (FceGroup& g : groups) g.has_env = false;
+            groups.push_back(E);
+          }
+        }
         if (!generic.empty() || groups.size() > WFK_LEAN_OPS) lean_ok = false;
         H.lean_ops = std::max<int32_t>(H.lean_ops, (int32_t)groups.size());
         for (FceGroup& G : groups) {

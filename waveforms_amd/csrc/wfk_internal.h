@@ -49,7 +49,7 @@
 #define WFK_FCE_DEG 4
 #define WFK_FCE_A 5           // A0..A3
 #define WFK_FCE_B 9           // B0..B3
-#define WFK_FCE_ENV 13        // 0 none, 1 gaussian
+#define WFK_FCE_ENV 13        // 0 none, 1 gaussian, 3: pseudo-op, multiply the accumulators by the gaussian
 #define WFK_FCE_SIGMA 14
 #define WFK_FCE_SG 15
 #define WFK_FCE_H 16

@@ -632,6 +632,23 @@ __device__ __forceinline__ void fce_eval(const double* blk, const double* r, Fce
   }
 }
 
+// closing pseudo-op of a piece whose carriers share one Gaussian envelope (WFK_FCE_ENV == 3):
+// acc (and the imaginary accumulators) *= g_k; the state advances by the NS recurrence steps
+template <typename T, int NS, bool CPLX>
+__device__ __forceinline__ void fce_envmul(const double* r, FceSeeds& sd, T (&acc)[NS],
+                                           T (&acci)[CPLX ? NS : 1]) {
+  double g = sd.g, rr = sd.r;
+  const double q = r[WFK_FCE_Q];
+  WFK_EACH(NS, k)
+    acc[k] *= (T)g;
+    if constexpr (CPLX) acci[k] *= (T)g;
+    g *= rr;
+    rr *= q;
+  WFK_END
+  sd.g = g;
+  sd.r = rr;
+}
+
 template <typename T, int NS>
 __device__ __forceinline__ void apply_fce(const double* blk, const double* r, const KArgs& a,
                                           double tshift, int64_t j0, T (&acc)[NS]) {
@@ -822,7 +839,9 @@ wfk_sample_lean(const KArgs a) {
           const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
           // an op of the imaginary part (complex amplitudes) adds into acci; a real-output
           // launch of such a channel keeps the real part only, like WaveVStack's `.real`
-          if (uni((int)rec[WFK_FCE_CARRIER]) & 2) {
+          if (uni((int)rec[WFK_FCE_ENV]) == 3) {
+            fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
+          } else if (uni((int)rec[WFK_FCE_CARRIER]) & 2) {
             if constexpr (CPLX) fce_eval<T, NS>(s_par, rec, sd, x, true, acci);
           } else {
             fce_eval<T, NS>(s_par, rec, sd, x, true, acc);
@@ -907,7 +926,12 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
           for (int k = 0; k < nops; ++k) {
             const int kind = uni((int)s_par[pos]);
             if (!TLIST && kind == WFK_OP_FCE) {
-              if (uni((int)s_par[pos + WFK_FCE_CARRIER]) & 2) {
+              if (uni((int)s_par[pos + WFK_FCE_ENV]) == 3) {
+                double x = grid_time(a, j0);
+                if (C.tshift != 0.0) x = x - C.tshift;
+                FceSeeds sd = fce_make_seeds(s_par + pos, x);
+                fce_envmul<T, NS, CPLX>(s_par + pos, sd, acc, acci);
+              } else if (uni((int)s_par[pos + WFK_FCE_CARRIER]) & 2) {
                 if constexpr (CPLX) apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acci);
               } else {
                 apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acc);
