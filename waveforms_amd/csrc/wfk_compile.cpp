@@ -100,6 +100,7 @@ struct BlockBuilder {
   std::vector<double> body;     // after the 2-double header
   std::vector<double> tables;   // appended behind the records
   std::vector<std::pair<size_t, int>> table_refs;  // (index of aux slot in body, table id)
+  std::vector<size_t> fce_ats;                      // body index of every fused-op record (packed word fix-up)
   std::map<double, int> table_of_w;               // dedupe COS tables by dphase
   int n_terms = 0;                                // ops in this block
   size_t size() const { return WFK_BLK_HDR + body.size() + tables.size() + 1; }
@@ -367,6 +368,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     size_t tab_off = WFK_BLK_HDR + B.body.size();
     if (tab_off & 1) ++tab_off;  // 16-byte aligned tables
     for (auto& r : B.table_refs) B.body[r.first] = (double)(tab_off + (size_t)r.second * 2 * (NS + 1));
+    for (size_t at : B.fce_ats)   // the table offset also travels in the packed op word
+      B.body[at + WFK_FCE_DEG] += 256.0 * B.body[at + WFK_FCE_TAB];
     size_t len = tab_off + B.tables.size();
     H.params.push_back((double)len);
     H.params.push_back((double)B.n_terms);
@@ -542,7 +545,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     rec[WFK_FCE_W] = G.W;
     rec[WFK_FCE_SREF] = sref;
     rec[WFK_FCE_SLIN] = G.has_lin ? G.slin : 0.0;
-    rec[WFK_FCE_DEG] = G.deg;
+    rec[WFK_FCE_DEG] = (double)WFK_FCE_PACK(G.deg, G.W != 0.0 ? 1 : 0, G.imag ? 1 : 0,
+                                            G.envmul ? 3 : (G.has_env ? 1 : 0), G.env32 ? 1 : 0);
     rec[WFK_FCE_A] = (double)A0;
     rec[WFK_FCE_B] = (double)B0;
     for (int i = 1; i < 4; ++i) { rec[WFK_FCE_A + i] = (double)G.A[i]; rec[WFK_FCE_B + i] = (double)G.B[i]; }
@@ -557,6 +561,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     rec[WFK_FCE_CARRIER] = (G.W != 0.0 ? 1.0 : 0.0) + (G.imag ? 2.0 : 0.0);   // bit 0 carrier, bit 1 imaginary part
     size_t at = B.body.size();
     B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
+    B.fce_ats.push_back(at);
     if (G.W != 0.0) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
   };
 

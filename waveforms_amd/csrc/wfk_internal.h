@@ -46,7 +46,9 @@
 #define WFK_FCE_W 1
 #define WFK_FCE_SREF 2
 #define WFK_FCE_SLIN 3
-#define WFK_FCE_DEG 4
+#define WFK_FCE_DEG 4         // PACKED op word (one LDS read instead of five dependent ones per op and tile):
+                              // deg (bits 0-1) | carrier << 2 | imag << 3 | env << 4 (2 bits) | f32ok << 6 | table offset << 8
+#define WFK_FCE_PACK(deg, carrier, imag, env, f32ok) ((deg) | ((carrier) << 2) | ((imag) << 3) | ((env) << 4) | ((f32ok) << 6))
 #define WFK_FCE_A 5           // A0..A3
 #define WFK_FCE_B 9           // B0..B3
 #define WFK_FCE_ENV 13        // 0 none, 1 gaussian, 3: pseudo-op, multiply the accumulators by the gaussian

@@ -605,22 +605,23 @@ __device__ __forceinline__ void fce_env(const double2* tab, const double* r, Fce
 }
 
 // exact per-lane seeds of one fused op at sample time x (already minus tshift)
-__device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x) {
+// `fl`: the op's packed word (WFK_FCE_DEG), read once by the caller
+__device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x, int fl) {
   const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
   return fce_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), -(v * v), -Hh * (2.0 * v + Hh),
-                   uni((int)r[WFK_FCE_CARRIER]) & 1, uni((int)r[WFK_FCE_ENV]));
+                   (fl >> 2) & 1, (fl >> 4) & 3);
 }
 
 // run one fused op over the wave tile from the given state; `wide_env`: keep the
 // Gaussian state in double even for float output
 template <typename T, int NS>
 __device__ __forceinline__ void fce_eval(const double* blk, const double* r, FceSeeds& sd,
-                                         double x, bool wide_env, T (&acc)[NS]) {
-  const int deg = uni((int)r[WFK_FCE_DEG]);
-  const int carrier = uni((int)r[WFK_FCE_CARRIER]) & 1;   // (bit 1: imaginary-part op, see the callers)
-  int env = uni((int)r[WFK_FCE_ENV]);
-  if (env && sizeof(T) == 4 && (wide_env || uni((int)r[WFK_FCE_F32OK]) == 0)) env = 2;
-  const double2* tab = reinterpret_cast<const double2*>(blk + uni((int)r[WFK_FCE_TAB]));
+                                         double x, bool wide_env, T (&acc)[NS], int fl) {
+  const int deg = fl & 3;
+  const int carrier = (fl >> 2) & 1;
+  int env = (fl >> 4) & 3;
+  if (env && sizeof(T) == 4 && (wide_env || ((fl >> 6) & 1) == 0)) env = 2;
+  const double2* tab = reinterpret_cast<const double2*>(blk + (fl >> 8));
   const double u0 = x - r[WFK_FCE_SLIN];
   if (carrier) {
     if (deg == 0) fce_env<T, NS, 0, true>(tab, r, sd, u0, env, acc);
@@ -654,8 +655,9 @@ __device__ __forceinline__ void apply_fce(const double* blk, const double* r, co
                                           double tshift, int64_t j0, T (&acc)[NS]) {
   double x = grid_time(a, j0);
   if (tshift != 0.0) x = x - tshift;
-  FceSeeds sd = fce_make_seeds(r, x);
-  fce_eval<T, NS>(blk, r, sd, x, false, acc);
+  const int fl = uni((int)r[WFK_FCE_DEG]);
+  FceSeeds sd = fce_make_seeds(r, x, fl);
+  fce_eval<T, NS>(blk, r, sd, x, false, acc, fl);
 }
 
 template <typename T> struct OutOps;
@@ -820,7 +822,8 @@ wfk_sample_lean(const KArgs a) {
         if (!carried) {
           // seed phase: libm, nothing else live
           for (int op = 0; op < nops; ++op) {
-            const FceSeeds sd = fce_make_seeds(s_par + WFK_BLK_HDR + op * WFK_FCE_REC, x);
+            const double* srec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
+            const FceSeeds sd = fce_make_seeds(srec, x, uni((int)srec[WFK_FCE_DEG]));
             double* st = s_st + op * 256 + lane;
             st[0] = sd.c;
             st[64] = sd.s;
@@ -839,12 +842,13 @@ wfk_sample_lean(const KArgs a) {
           const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
           // an op of the imaginary part (complex amplitudes) adds into acci; a real-output
           // launch of such a channel keeps the real part only, like WaveVStack's `.real`
-          if (uni((int)rec[WFK_FCE_ENV]) == 3) {
+          const int fl = uni((int)rec[WFK_FCE_DEG]);     // packed op word: one read for all flags
+          if (((fl >> 4) & 3) == 3) {
             fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
-          } else if (uni((int)rec[WFK_FCE_CARRIER]) & 2) {
-            if constexpr (CPLX) fce_eval<T, NS>(s_par, rec, sd, x, true, acci);
+          } else if (fl & 8) {
+            if constexpr (CPLX) fce_eval<T, NS>(s_par, rec, sd, x, true, acci, fl);
           } else {
-            fce_eval<T, NS>(s_par, rec, sd, x, true, acc);
+            fce_eval<T, NS>(s_par, rec, sd, x, true, acc, fl);
           }
           st[0] = sd.c;
           st[64] = sd.s;
@@ -926,12 +930,13 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
           for (int k = 0; k < nops; ++k) {
             const int kind = uni((int)s_par[pos]);
             if (!TLIST && kind == WFK_OP_FCE) {
-              if (uni((int)s_par[pos + WFK_FCE_ENV]) == 3) {
+              const int fl = uni((int)s_par[pos + WFK_FCE_DEG]);
+              if (((fl >> 4) & 3) == 3) {
                 double x = grid_time(a, j0);
                 if (C.tshift != 0.0) x = x - C.tshift;
-                FceSeeds sd = fce_make_seeds(s_par + pos, x);
+                FceSeeds sd = fce_make_seeds(s_par + pos, x, fl);
                 fce_envmul<T, NS, CPLX>(s_par + pos, sd, acc, acci);
-              } else if (uni((int)s_par[pos + WFK_FCE_CARRIER]) & 2) {
+              } else if (fl & 8) {
                 if constexpr (CPLX) apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acci);
               } else {
                 apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acc);
