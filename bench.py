@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A "step" = one pass of the sampler over one batch of synthetic channels with the
+A "step" = one pass of the hot path over one batch of synthetic channels with the
 output left resident in HBM (that is where the API leaves it: BatchSampler.launch).
 Workloads (SURVEY.md §8(d) / BASELINE.json configs):
   sampler256 (default)  256 channels x 1e7 points, 100 gaussian+DRAG pulses per
@@ -12,19 +12,32 @@ Workloads (SURVEY.md §8(d) / BASELINE.json configs):
   c2_duty30 / c2_drag   C2 variants: 30 % duty cycle / built from the DRAG primitive
   c3                    256 WaveVStack channels x 20 pulses x 1e6 points, fp32
   c4                    sampler256 followed by the 1024-tap FIR stage
+  c5                    C5 per-rank shape: 512 channels x 1e7 points per GPU (seeds 1000+c
+                        over the GLOBAL channel index; 4096 channels at --gpus 8), fp64
+  far                   256 channels x 2e6 points at 2 GS/s = a 1 ms sequence, 300 MHz
+                        carriers (phases of ~2e6 rad: the grid-rounding regime)
+
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); channels are
-independent, so each rank samples its own block of 256 channels with no data-path
-collective (weak scaling); time = max over ranks between two barriers.
+independent, so each rank samples its own block of channels with no data-path
+collective (weak scaling); time = max over ranks between two barriers.  Started either
+by a launcher that sets RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun, the driver), or by
+`python bench.py --gpus N` itself: the parent then starts N rank processes BEFORE anything
+touches the GPU (it never imports torch), waits for them and relays rank 0's JSON line.
+
+Rehearsal switches (no effect on the default line):
+  --backend gloo   rendezvous/reductions over gloo instead of RCCL
+  --share-gpu      all ranks use device 0 (one-GPU box; needs --backend gloo)
+  --plan-only      no GPU at all: every rank flattens + compiles its channel block
+                   (host-only plans) and the line reports the sharding (CPU tests)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,14 +45,98 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='sampler256')
+    ap.add_argument('--channels', type=int, default=None, help='channels per GPU')
+    ap.add_argument('--points', type=float, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true',
+                    help='skip the secondary workloads (c2, c3, c4) of the default line')
+    ap.add_argument('--gather-rows', type=int, default=0,
+                    help='N > 1 only: after the timed steps, also time an RCCL all_gather of this '
+                         'many rows per rank (result placement, SURVEY 8(e); reported under '
+                         '"gather", never part of `value`: results stay sharded by default)')
+    ap.add_argument('--dtype', choices=['f64', 'f32'], default=None,
+                    help='override the output dtype of the workload')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
+    ap.add_argument('--share-gpu', action='store_true')
+    ap.add_argument('--plan-only', action='store_true')
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a rendezvous in the environment
+# ---------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Start one rank process per GPU and relay rank 0's line.  Runs before any GPU call
+    and never imports torch: a process that has initialised the GPU must neither fork
+    workers that use it nor be replaced by exec."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL needs it here)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                                   # the exact child we started
+            rcs.append(p.wait())
+    sys.stdout.write(out0.decode('utf-8', 'replace'))
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    return bad[0] if bad else 0
+
+
+# ---------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------
+def far_channel(ns, c, nseg=100, spacing=10e-6, width=200e-9):
+    """One channel of a 1 ms sequence: `nseg` gaussian+DRAG pulses 10 us apart, carriers of
+    +-(250..350) MHz: phases up to 2 pi * 350e6 * 1e-3 = 2.2e6 rad (routine T1/echo shapes)."""
+    import numpy as np
+    rng = np.random.default_rng(5000 + c)
+    ws = []
+    for k in range(nseg):
+        A = rng.uniform(0.1, 1)
+        f = rng.uniform(250e6, 350e6) * (1 if rng.uniform() < 0.5 else -1)
+        phi = rng.uniform(0, 2 * np.pi)
+        I, _ = ns.mixing(A * ns.gaussian(width) >> ((k + 0.5) * spacing), freq=f, phase=phi,
+                         DRAGScaling=1e-10)
+        ws.append(I)
+    while len(ws) > 1:
+        nxt = [ws[i] + ws[i + 1] for i in range(0, len(ws) - 1, 2)]
+        if len(ws) % 2:
+            nxt.append(ws[-1])
+        ws = nxt
+    return ws[0]
+
+
 def workload(name, channels, points):
     """-> (make_channel(c), grid, dtype, description); channel c is global (all ranks)."""
+    import numpy as np
     import waveforms_amd as wf
     from waveforms_amd import workloads as wl
-    if name in ('sampler256', 'c4'):
+    if name in ('sampler256', 'c4', 'c5'):
+        tag = {'sampler256': 'sampler256', 'c4': 'C4 sampler + 1024-tap FIR',
+               'c5': 'C5 per-rank shape'}[name]
         return (lambda c: wl.sum_channel(wf, 100, 1000 + c)), wl.c2_grid(points), np.float64, (
-            f'{channels} ch/GPU x {points:.0e} pts, 100 gaussian+DRAG pulses/ch '
-            f'(SURVEY 8(d) C4/C5 channel spec), grid mode')
+            f'{tag}: {channels} ch/GPU x {points:.0e} pts, 100 gaussian+DRAG pulses/ch, seeds '
+            f'1000+c (SURVEY 8(d) C4/C5 channel spec), grid mode')
     if name == 'c2':
         return (lambda c: wl.c2_channel(wf)), wl.c2_grid(points), np.float64, (
             f'C2: 1 ch x 100 gaussian+DRAG pulses x {points:.0e} pts')
@@ -52,7 +149,17 @@ def workload(name, channels, points):
     if name == 'c3':
         return (lambda c: wl.vstack_channel(wf, 20, 100 + c)), wl.c3_grid(points), np.float32, (
             f'C3: {channels} WaveVStack ch/GPU x 20 pulses x {points:.0e} pts')
+    if name == 'far':
+        return (lambda c: far_channel(wf, c)), ('linspace', 0.0, points / 2e9, points, False), \
+            np.float64, (f'far: {channels} ch/GPU x {points:.0e} pts at 2 GS/s, 100 pulses/ch with '
+                         f'250-350 MHz carriers out to t = {points / 2e9 * 1e3:.1f} ms')
     raise SystemExit(f'unknown workload {name}')
+
+
+def default_shape(name):
+    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512}.get(name, 256)
+    points = {'c3': 10**6, 'far': 2 * 10**6}.get(name, 10**7)
+    return channels, points
 
 
 def _c_oracle_worker(job):
@@ -120,42 +227,97 @@ def cpu_baseline(chans, grid_desc, budget_s=12.0):
     return base, outs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='sampler256')
-    ap.add_argument('--channels', type=int, default=None)
-    ap.add_argument('--points', type=float, default=None)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather-rows', type=int, default=0,
-                    help='N > 1 only: after the timed steps, also time an RCCL all_gather of this '
-                         'many rows per rank (result placement, SURVEY 8(e); reported under '
-                         '"gather", never part of `value`: results stay sharded by default)')
-    ap.add_argument('--dtype', choices=['f64', 'f32'], default=None,
-                    help='override the output dtype of the workload')
-    args = ap.parse_args()
+def profile_traffic(key):
+    """HBM bytes per launch of this workload's dominant kernel from the committed PMC passes
+    (profiles/traffic.json: rocprofv3 --pmc of this same command; counters cannot be read
+    from inside the run) -> (bytes | None, source label)."""
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(tfile):
+        return None, None
+    t = json.load(open(tfile))
+    v = t.get(key)
+    if isinstance(v, dict):
+        return v.get('bytes'), 'profiles/' + v.get('source', 'traffic.json') + ' (separate rocprofv3 --pmc pass, not this run)'
+    return v, 'profiles/traffic.json (separate rocprofv3 --pmc pass, not this run)'
 
+
+# ---------------------------------------------------------------------------------------
+# plan-only rehearsal (CPU): sharding, rendezvous, reductions -- no kernels
+# ---------------------------------------------------------------------------------------
+def run_plan_only(args, rank, world):
+    import numpy as np
     import torch
+    import torch.distributed as dist
+    from waveforms_amd import _engine, _flatten
+    from waveforms_amd._dist import channel_block
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    name = args.workload
+    dch, dpts = default_shape(name)
+    channels, points = args.channels or dch, int(args.points or dpts)
+    make_channel, grid, dtype, desc = workload(name, channels, points)
+    a, b = channel_block(channels * world, rank, world)
+    t0 = time.perf_counter()
+    prog = _flatten.flatten([make_channel(c) for c in range(a, b)])
+    plan = _engine.Plan(prog, grid=_flatten.grid_from_desc(grid))
+    dt = time.perf_counter() - t0
+    info = [float(a), float(b), float(plan.info.n_pieces), float(plan.info.n_fused), dt]
+    if world > 1:
+        t = torch.tensor(info, dtype=torch.float64)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        infos = [p.tolist() for p in parts]
+    else:
+        infos = [info]
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'plan-only rehearsal (no kernels run)', 'value': None, 'unit': 'Msamples/s',
+            'n_gpus': world, 'plan_only': True, 'backend': 'gloo' if world > 1 else None,
+            'config': {'workload': f'{name}: {desc}', 'channels_per_gpu': channels,
+                       'points_per_channel': points},
+            'kernel': plan.kernel_name(dtype),
+            'ranks': [{'rank': r, 'channels': [int(i[0]), int(i[1])], 'pieces': int(i[2]),
+                       'fused_terms': int(i[3]), 'plan_s': i[4]} for r, i in enumerate(infos)]}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------
+def run_rank(args):
+    import numpy as np
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.plan_only:
+        return run_plan_only(args, rank, world)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the sampler has no CPU path)')
+    if args.share_gpu:
+        if args.backend != 'gloo' and world > 1:
+            raise SystemExit('--share-gpu needs --backend gloo (RCCL wants one device per rank)')
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
 
-    from waveforms_amd import _engine
+    from waveforms_amd import _engine, workloads as wl
     from waveforms_amd._dist import ShardedSampler
+    from waveforms_amd._sampling import BatchSampler
     _engine.set_device(local_rank)
 
     name = args.workload
-    channels = args.channels or (1 if name.startswith('c2') else 256)
-    points = int(args.points or (10**6 if name == 'c3' else 10**7))
+    dch, dpts = default_shape(name)
+    channels = args.channels or dch
+    points = int(args.points or dpts)
     make_channel, grid, dtype, desc = workload(name, channels, points)
     if args.dtype:
         dtype = np.float64 if args.dtype == 'f64' else np.float32
@@ -168,7 +330,6 @@ def main():
     fir = None
     if name == 'c4':
         from waveforms_amd.distortion import FirStage
-        from waveforms_amd import workloads as wl
         fir = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
         out2 = torch.empty_like(out)
 
@@ -177,22 +338,32 @@ def main():
         if fir is not None:
             fir.apply_torch(out, out2)
 
+    def allreduce_max(x):
+        if dist is None:
+            return x
+        dev = 'cuda' if args.backend == 'nccl' else 'cpu'
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Untimed device pre-warm, before the W warm-up steps: the first ~40 ms of launches after
-    # idle run ~10% slower (memory/fabric clocks still ramping; measured per launch in
-    # tools/placement_probe2.py), and W = 3 steps of a 3 ms kernel end well inside that ramp.
-    t_pre = time.perf_counter()
-    n_pre = 0
-    while n_pre < 10 or time.perf_counter() - t_pre < 0.25:
-        step()
-        n_pre += 1
-        if n_pre % 10 == 0:
-            torch.cuda.synchronize()
+    def prewarm(fn, min_s=0.25):
+        # Untimed device pre-warm, before the W warm-up steps: the first ~40 ms of launches
+        # after idle run ~10% slower (memory/fabric clocks still ramping; measured per launch in
+        # tools/placement_probe2.py), and W = 3 steps of a 3 ms kernel end well inside that ramp.
+        t_pre, n_pre = time.perf_counter(), 0
+        while n_pre < 10 or time.perf_counter() - t_pre < min_s:
+            fn()
+            n_pre += 1
+            if n_pre % 10 == 0:
+                torch.cuda.synchronize()
+
+    prewarm(step)
     for _ in range(args.warmup):
         step()
     fence()
@@ -210,21 +381,46 @@ def main():
             c.record()
             ev_fir.append((b, c))
     fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = allreduce_max(time.perf_counter() - t0)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     samples_per_step = bs.n_channels * bs.n * world
     elem = np.dtype(dtype).itemsize
     algo_bytes = bs.n_channels * bs.n * elem            # per launch, per GPU
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(name)
+    traffic, traffic_src = profile_traffic(name)
+
+    roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': traffic, 'traffic_source': traffic_src,
+            'kernel': bs.plan.kernel_name(dtype),
+            'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': algo_bytes,
+            'timing': 'HIP events around every launch on the launch stream, mean over the timed steps'}
+    if fir is not None:
+        # the FIR stage dominates this workload: report ITS roofline (16 B/sample: read+write)
+        fir_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_fir]))
+        fb = 2 * algo_bytes
+        roof = {'bound': 'hbm', 'achieved': fb / (fir_ms * 1e-3) / 1e9,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': fb / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'traffic': traffic, 'traffic_source': traffic_src,
+                'kernel': 'fir_fused<%s>' % ('double' if dtype == np.float64 else 'float'),
+                'kernel_ms': fir_ms, 'algorithmic_bytes_per_launch': fb,
+                'sampler_kernel_ms': kern_ms, 'sampler_kernel': bs.plan.kernel_name(dtype)}
+    if dist is not None:
+        # per-rank roofline of the dominant kernel (every rank times its own launches)
+        mine = torch.tensor([roof['kernel_ms']], dtype=torch.float64,
+                            device='cuda' if args.backend == 'nccl' else 'cpu')
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        per = [float(p.item()) for p in parts]
+        ab = roof['algorithmic_bytes_per_launch']
+        roof['per_rank'] = [{'rank': r, 'kernel_ms': ms, 'frac': ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                            for r, ms in enumerate(per)]
+        worst = max(per)                      # the line's frac is the slowest rank's
+        roof['kernel_ms'] = worst
+        roof['achieved'] = ab / (worst * 1e-3) / 1e9
+        roof['frac'] = roof['achieved'] / HBM_PEAK_GBS
 
     line = {
         'metric': 'Msamples/s (all channels)',
@@ -234,48 +430,65 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64' if dtype == np.float64 else 'f32', 'data': 'synthetic',
         'config': {'workload': f'{name}: {desc}', 'channels_per_gpu': bs.n_channels,
+                   'channels_total': bs.n_channels * world,
                    'points_per_channel': bs.n, 'output': 'device (HBM) buffer',
-                   'parallelism': f'channel-block-per-rank x{world}, no collective'},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': traffic, 'kernel': 'wfk_sample',
-                     'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': algo_bytes},
+                   'parallelism': f'channel-block-per-rank x{world}, no data-path collective',
+                   'backend': None if dist is None else
+                   ('nccl (RCCL) world_size=%d' % dist.get_world_size() if args.backend == 'nccl'
+                    else 'gloo world_size=%d' % dist.get_world_size())},
+        'roofline': roof,
     }
-    if fir is not None:
-        # the FIR stage dominates this workload: report ITS roofline (16 B/sample: read+write)
-        fir_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_fir]))
-        fb = 2 * algo_bytes
-        line['roofline'] = {'bound': 'hbm', 'achieved': fb / (fir_ms * 1e-3) / 1e9,
-                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                            'frac': fb / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            'traffic': traffic, 'kernel': 'fir_fused', 'kernel_ms': fir_ms,
-                            'algorithmic_bytes_per_launch': fb,
-                            'sampler_kernel_ms': kern_ms}
-    if name == 'sampler256' and world == 1 and not args.no_cpu_baseline:
+
+    def timed(fn, steps, warm=3):
+        """mean ms per call of fn, HIP events on the launch stream"""
+        prewarm(fn, 0.05)
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    if name == 'sampler256' and world == 1 and not args.no_also:
+        also = {}
         # C4 = this workload followed by the 1024-tap FIR stage: time the FIR kernel on the
         # buffer just sampled so that the one default line carries both stages
         from waveforms_amd.distortion import FirStage
-        from waveforms_amd import workloads as wl
         fst = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
         out2 = torch.empty_like(out)
-        for _ in range(2):
-            fst.apply_torch(out, out2)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            fst.apply_torch(out, out2)
-        e1.record()
-        torch.cuda.synchronize()
-        fir_ms = e0.elapsed_time(e1) / 5
-        line['also'] = {
-            'c4_fir_kernel_ms': fir_ms,
-            'c4_fir_frac_of_hbm_peak': 2 * algo_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            'c4_step_ms': kern_ms + fir_ms,
-            'c4_msamples_per_s': bs.n_channels * bs.n / ((kern_ms + fir_ms) * 1e-3) / 1e6,
-            'note': 'C4 (BASELINE configs[3]) = sampler256 + 1024-tap FIR (fused LDS-FFT kernel)'}
+        fir_ms = timed(lambda: fst.apply_torch(out, out2), 5, 2)
+        also['c4'] = {
+            'fir_kernel': 'fir_fused<double>', 'fir_kernel_ms': fir_ms,
+            'fir_frac': 2 * algo_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'step_ms': kern_ms + fir_ms,
+            'msamples_per_s': bs.n_channels * bs.n / ((kern_ms + fir_ms) * 1e-3) / 1e6,
+            'note': 'C4 (BASELINE configs[3]) = sampler256 + 1024-tap FIR (LDS-FFT kernel); '
+                    'frac = 16 B/sample (read + write) / FIR kernel time / 8 TB/s'}
         del out2
         fst.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # BASELINE configs[1] and [2] in the same line (kernel time by HIP events, frac of 8 TB/s)
+        for wname in ('c2', 'c3'):
+            wch, wpts = default_shape(wname)
+            mk, g, dt_, d_ = workload(wname, wch, wpts)
+            b2 = BatchSampler([mk(c) for c in range(wch)], g)
+            o2 = torch.empty((b2.n_channels, b2.n), device='cuda',
+                             dtype=torch.float64 if dt_ == np.float64 else torch.float32)
+            ms = timed(lambda: b2.launch_torch(o2), 200 if wname == 'c2' else 50, 10)
+            nbytes = b2.n_channels * b2.n * np.dtype(dt_).itemsize
+            also[wname] = {'workload': d_, 'kernel': b2.plan.kernel_name(dt_), 'kernel_ms': ms,
+                           'msamples_per_s': b2.n_channels * b2.n / (ms * 1e-3) / 1e6,
+                           'algorithmic_bytes_per_launch': nbytes,
+                           'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           'dtype': 'f64' if dt_ == np.float64 else 'f32'}
+            del o2
+            b2.close()
+        line['also'] = also
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and name in (
+            'sampler256', 'c4', 'c5', 'c2', 'far'):
         base, outs = cpu_baseline(chans, grid)
         line['cpu_baseline'] = base
         line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
@@ -288,7 +501,9 @@ def main():
         try:
             rows = min(args.gather_rows, bs.n_channels)
             src = out[:rows].contiguous()
-            dst = torch.empty((world * rows, bs.n), dtype=out.dtype, device='cuda')
+            if args.backend != 'nccl':
+                src = src.cpu()
+            dst = torch.empty((world * rows, bs.n), dtype=out.dtype, device=src.device)
             dist.all_gather_into_tensor(dst, src)
             fence()
             g0 = time.perf_counter()
@@ -309,7 +524,18 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -153,6 +153,9 @@ int wfk_plan_member_index(const wfk_plan* plan, int32_t member, int64_t* idx,
 /* 1 if a live piece of `channel` has a complex amplitude (dtype detection of
  * calc_parts, _waveform.pyx:164-166)                                          */
 int wfk_plan_channel_is_complex(const wfk_plan* plan, int32_t channel);
+/* Name of the device kernel a launch of this plan with `out_kind` selects (the symbol
+ * rocprofv3 --kernel-trace shows, template arguments included), for reports.           */
+const char* wfk_plan_kernel_name(const wfk_plan* plan, int out_kind);
 /* Evaluate every channel into out_dev[ch*ch_stride + i] (elements of out_kind).
  * Asynchronous on `hip_stream` (a hipStream_t, or NULL for the null stream).   */
 int wfk_plan_launch(wfk_plan* plan, void* out_dev, int64_t ch_stride,

@@ -66,6 +66,8 @@ def lib():
         l.wfk_plan_get_info.argtypes = [VP, P(wfk_plan_info)]
         l.wfk_plan_member_index.argtypes = [VP, I32, VP, I32]
         l.wfk_plan_channel_is_complex.argtypes = [VP, I32]
+        l.wfk_plan_kernel_name.argtypes = [VP, C.c_int]
+        l.wfk_plan_kernel_name.restype = C.c_char_p
         l.wfk_plan_launch.argtypes = [VP, VP, I64, C.c_int, C.c_uint32, VP]
         l.wfk_plan_run_host.argtypes = [VP, VP, I64, C.c_int]
         l.wfk_fir_plan_create.argtypes = [VP, I32, I64, I32, C.c_int, P(VP)]
@@ -144,6 +146,10 @@ class Plan:
         idx = np.empty(nb, dtype=np.int64)
         check(lib().wfk_plan_member_index(self._h, member, idx.ctypes.data, nb))
         return idx
+
+    def kernel_name(self, dtype=np.float64) -> str:
+        """Symbol of the kernel a launch with this output dtype runs (as rocprofv3 shows it)."""
+        return lib().wfk_plan_kernel_name(self._h, _KIND_OF[np.dtype(dtype)]).decode()
 
     def launch(self, out_ptr: int, ch_stride: int, kind: int, accumulate=False,
                stream: int = 0):

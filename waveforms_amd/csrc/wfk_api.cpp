@@ -106,6 +106,19 @@ DevBlockCache& dev_cache() {
 
 }  // namespace
 
+// Makes `dev` the current HIP device for a scope (plans and blocks stay on the device they
+// were created on, whatever the caller's current device is when it comes back to them).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 struct wfk_plan {
   HostPlan h;
   bool on_device = false;
@@ -229,6 +242,7 @@ int wfk_plan_destroy(wfk_plan* p) {
   if (p->d_tables || p->d_scratch) {
     // blocks go back to the cache and may be handed to the next plan at once: work launched
     // on a caller stream must have drained first (hipFree used to imply that)
+    DeviceGuard guard(p->dev);                       // synchronise the OWNING device
     if (p->async_launch) (void)hipDeviceSynchronize();
     dev_cache().put(p->d_tables, p->tables_cap, p->dev);
     dev_cache().put(p->d_scratch, p->scratch_cap, p->dev);
@@ -263,6 +277,23 @@ int wfk_plan_member_index(const wfk_plan* p, int32_t member, int64_t* idx, int32
 int wfk_plan_channel_is_complex(const wfk_plan* p, int32_t channel) {
   if (!p || channel < 0 || channel >= p->h.n_channels) return fail(WFK_EINVAL, "bad channel");
   return p->h.channel_complex[channel];
+}
+
+const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
+  if (!p || out_kind < 0 || out_kind > 3) return "";
+  static thread_local std::string name;
+  const char* T = (out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64) ? "float" : "double";
+  const char* cplx = (out_kind == WFK_OUT_C128 || out_kind == WFK_OUT_C64) ? "true" : "false";
+  const HostPlan& h = p->h;
+  if (!h.tlist && h.lean) {
+    name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) + ">";
+  } else {
+    const bool direct = h.tlist || h.n_direct > 0, generic = direct || h.n_generic > 0;
+    name = std::string("wfk_sample<") + T + "," + cplx + "," + (h.tlist ? "true" : "false") + "," +
+           (generic ? "true" : "false") + "," + (direct ? "true" : "false") + "," +
+           std::to_string(h.ns) + ">";
+  }
+  return name.c_str();
 }
 
 int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind, uint32_t flags,
@@ -319,6 +350,7 @@ int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_ki
   if (!p->on_device)
     return fail(WFK_EHIP, "plan has no device tables (no HIP device was visible at plan creation)");
   size_t bytes = (size_t)p->h.n_channels * (size_t)p->h.n * es;
+  DeviceGuard guard(p->dev);   // scratch, launch and copy all happen on the plan's own device
   if (bytes > p->scratch_bytes) {
     dev_cache().put(p->d_scratch, p->scratch_cap, p->dev);
     p->d_scratch = nullptr;
@@ -360,8 +392,11 @@ int wfk_free(void* dev_ptr) {
     dev = it->second.second;
     dev_cache().handed_.erase(it);
   }
-  // like hipFree, freeing waits for the device: the block may be reused at once
-  HIP_TRY(hipDeviceSynchronize());
+  // like hipFree, freeing waits for the block's OWN device: the block may be reused at once
+  {
+    DeviceGuard guard(dev);
+    HIP_TRY(hipDeviceSynchronize());
+  }
   dev_cache().put(dev_ptr, cap, dev);
   return WFK_OK;
 }

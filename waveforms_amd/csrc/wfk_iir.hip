@@ -313,6 +313,16 @@ __global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const
   }
 }
 
+// state dimension 0 (every section is a bare gain): y = g (x - pre) + post
+template <typename T>
+__global__ void __launch_bounds__(256) iir_scale(const T* __restrict__ in, int64_t in_stride,
+                                                 T* __restrict__ out, int64_t out_stride, int64_t n,
+                                                 double g, double pre, double post) {
+  const int64_t row = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256)
+    out[row * out_stride + j] = (T)(g * ((double)in[row * in_stride + j] - pre) + post);
+}
+
 int iir_fail(int code, const std::string& m) {
   wfk_internal_set_error(m.c_str());
   return code;
@@ -364,6 +374,7 @@ struct wfk_iir_plan {
   std::vector<int> part_off;     // state offset of each part
   double* zi_tmp = nullptr;      // [batch][D_part] repacked state slices
   double* zf_tmp = nullptr;
+  double gain = 1.0;             // D == 0: y = gain * (x - pre) + post
 };
 
 extern "C" {
@@ -387,13 +398,69 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
                         int64_t n, int32_t batch, int kind, wfk_iir_plan** out) {
   if (!out) return iir_fail(WFK_EINVAL, "null out");
   *out = nullptr;
-  if (n_sections < 1 || n_sections > IIR_MAXSEC || !orders || !b || !a || n < 0 || batch < 1 ||
+  if (n_sections < 1 || n_sections > 4096 || !orders || !b || !a || n < 0 || batch < 1 ||
       batch > 65535)
     return iir_fail(WFK_EINVAL, "bad IIR arguments");
   if (kind != WFK_OUT_F64 && kind != WFK_OUT_F32) return iir_fail(WFK_EINVAL, "IIR kind must be F64 or F32");
   wfk_iir_plan* p = new wfk_iir_plan();
   IirCoef& c = p->c;
   std::memset(&c, 0, sizeof c);
+  {
+    // A cascade is a composition of sections, so any cut of the section list into consecutive
+    // runs is the same filter (scipy's sosfilt/lfilter state layout is section by section, so
+    // zi/zf slice the same way).  One kernel pass takes <= IIR_MAXSEC sections with a total
+    // state dimension <= IIR_MAXD; longer cascades run as consecutive passes.  Only a SINGLE
+    // section of order > IIR_MAXD has no device form.
+    int Dtot = 0;
+    bool single_too_big = false;
+    for (int s = 0; s < n_sections; ++s) {
+      if (orders[s] < 0) { delete p; return iir_fail(WFK_EINVAL, "negative section order"); }
+      single_too_big = single_too_big || orders[s] > IIR_MAXD;
+      Dtot += orders[s];
+    }
+    if (single_too_big) {
+      delete p;
+      return iir_fail(WFK_EUNSUP, "a single IIR section of order > 16 (factor it into a cascade)");
+    }
+    bool all_biquads = true;
+    for (int s = 0; s < n_sections; ++s) all_biquads = all_biquads && orders[s] == 2;
+    const bool split = n_sections > IIR_MAXSEC || Dtot > IIR_MAXD || (all_biquads && n_sections > 4);
+    if (split) {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        delete p;
+        return iir_fail(WFK_EHIP, "no HIP device visible");
+      }
+      c.nsec = 0; c.D = Dtot;
+      p->n = n; p->batch = batch; p->kind = kind;
+      if (n == 0) { *out = p; return WFK_OK; }
+      int s0 = 0, pos0 = 0, doff = 0;
+      while (s0 < n_sections) {
+        // greedy run: <= 4 biquads (register-resident kernels), else <= IIR_MAXSEC sections / IIR_MAXD states
+        int cnt = 0, dd = 0, pp = 0;
+        while (s0 + cnt < n_sections) {
+          const int o = orders[s0 + cnt];
+          const int cap_sec = all_biquads ? 4 : IIR_MAXSEC;
+          if (cnt >= cap_sec || dd + o > IIR_MAXD) break;
+          dd += o; pp += o + 1; ++cnt;
+        }
+        wfk_iir_plan* q = nullptr;
+        int rc = wfk_iir_plan_create(cnt, orders + s0, b + pos0, a + pos0, n, batch, kind, &q);
+        if (rc) { wfk_iir_plan_destroy(p); return rc; }
+        p->parts.push_back(q);
+        p->part_off.push_back(doff);
+        s0 += cnt; pos0 += pp; doff += dd;
+      }
+      if (hipMalloc(&p->zi_tmp, (size_t)batch * IIR_MAXD * 8) != hipSuccess ||
+          hipMalloc(&p->zf_tmp, (size_t)batch * IIR_MAXD * 8) != hipSuccess) {
+        wfk_iir_plan_destroy(p);
+        return iir_fail(WFK_ENOMEM, "IIR buffer allocation failed");
+      }
+      *out = p;
+      return WFK_OK;
+    }
+  }
   c.nsec = n_sections;
   int D = 0, pos = 0;
   for (int s = 0; s < n_sections; ++s) {
@@ -426,27 +493,12 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     delete p;
     return iir_fail(WFK_EHIP, "no HIP device visible");
   }
-  if (n == 0 || D == 0) { *out = p; return WFK_OK; }
-  {
-    bool biquads = n_sections > 4;
-    for (int s = 0; s < n_sections; ++s) biquads = biquads && orders[s] == 2;
-    if (biquads) {
-      for (int s0 = 0; s0 < n_sections; s0 += 4) {
-        const int cnt = std::min(4, n_sections - s0);
-        wfk_iir_plan* q = nullptr;
-        int rc = wfk_iir_plan_create(cnt, orders + s0, b + 3 * s0, a + 3 * s0, n, batch, kind, &q);
-        if (rc) { wfk_iir_plan_destroy(p); return rc; }
-        p->parts.push_back(q);
-        p->part_off.push_back(2 * s0);
-      }
-      if (hipMalloc(&p->zi_tmp, (size_t)batch * 8 * 8) != hipSuccess ||
-          hipMalloc(&p->zf_tmp, (size_t)batch * 8 * 8) != hipSuccess) {
-        wfk_iir_plan_destroy(p);
-        return iir_fail(WFK_ENOMEM, "IIR buffer allocation failed");
-      }
-      *out = p;
-      return WFK_OK;
-    }
+  if (n == 0 || D == 0) {
+    // order-0 sections only: a pure gain (lfilter with len(a) == len(b) == 1 per section)
+    p->gain = 1.0;
+    for (int s = 0; s < n_sections; ++s) p->gain *= c.b[s][0];
+    *out = p;
+    return WFK_OK;
   }
   // LB-step transition matrix T: column i = homogeneous response to unit state e_i
   std::vector<quad> T((size_t)D * D);
@@ -544,13 +596,23 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
   if (!in_dev || !out_dev) return iir_fail(WFK_EINVAL, "null buffer");
   if (in_stride < p->n || out_stride < p->n) return iir_fail(WFK_EINVAL, "stride smaller than n");
   hipStream_t s = (hipStream_t)hip_stream;
-  if (p->c.D == 0) return iir_fail(WFK_EINVAL, "order-0 filter: use a scale instead");
+  if (p->c.D == 0) {
+    const dim3 g((unsigned)std::min<int64_t>((p->n + 255) / 256, 4096), (unsigned)p->batch);
+    if (p->kind == WFK_OUT_F32)
+      hipLaunchKernelGGL(iir_scale<float>, g, dim3(256), 0, s, (const float*)in_dev, in_stride,
+                         (float*)out_dev, out_stride, p->n, p->gain, initial, post);
+    else
+      hipLaunchKernelGGL(iir_scale<double>, g, dim3(256), 0, s, (const double*)in_dev, in_stride,
+                         (double*)out_dev, out_stride, p->n, p->gain, initial, post);
+    if (hipGetLastError() != hipSuccess) return iir_fail(WFK_EHIP, "IIR kernel launch failed");
+    return WFK_OK;
+  }
   if (!p->parts.empty()) {
     const size_t D = (size_t)p->c.D;
     for (size_t i = 0; i < p->parts.size(); ++i) {
       wfk_iir_plan* q = p->parts[i];
       const size_t Di = (size_t)q->c.D, off = (size_t)p->part_off[i];
-      if (zi_dev &&
+      if (zi_dev && Di > 0 &&
           hipMemcpy2DAsync(p->zi_tmp, Di * 8, zi_dev + off, D * 8, Di * 8, (size_t)p->batch,
                            hipMemcpyDeviceToDevice, s) != hipSuccess)
         return iir_fail(WFK_EHIP, "IIR state repack failed");
@@ -562,7 +624,7 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
                               out_stride, zi_dev ? p->zi_tmp : nullptr, zf_dev ? p->zf_tmp : nullptr,
                               first ? initial : 0.0, last ? post : 0.0, hip_stream);
       if (rc) return rc;
-      if (zf_dev &&
+      if (zf_dev && Di > 0 &&
           hipMemcpy2DAsync(zf_dev + off, D * 8, p->zf_tmp, Di * 8, Di * 8, (size_t)p->batch,
                            hipMemcpyDeviceToDevice, s) != hipSuccess)
         return iir_fail(WFK_EHIP, "IIR state repack failed");

@@ -168,7 +168,18 @@ def predistort(sig, filters=None, ker=None, initial=0.0, initial_x=None,
             iy = (np.full((len(a) - 1, ), initial) if initial_y is None else
                   np.asarray(initial_y)[:len(a) - 1])
             zi = lfiltic(b, a, iy, ix)
-        sig, zf = iir_host(sig, [(b, a)], zi=zi, ker=ker)
+        sections = [(b, a)]
+        if max(len(b), len(a)) - 1 > 16:
+            # One direct-form section of order > 16 has no device form.  With a zero initial
+            # state the cascade of the caller's own sections is the same LTI system (the
+            # reference multiplies them into one polynomial first, distortion.py:298-300); a
+            # non-zero lfilter state of the combined form does not map onto cascade states.
+            if np.any(np.asarray(zi) != 0) or return_zf:
+                raise NotImplementedError(
+                    'predistort: combined filter order > 16 with a non-zero initial state '
+                    '(or return_zf) -- pass fewer sections per call')
+            sections, zi = [(np.atleast_1d(b_), np.atleast_1d(a_)) for b_, a_ in filters], None
+        sig, zf = iir_host(sig, sections, zi=zi, ker=ker)
         return (sig, zf) if return_zf else sig
     if ker is None:
         return (sig, zf) if return_zf else sig
