@@ -132,10 +132,8 @@ def workload(name, channels, points):
     import waveforms_amd as wf
     from waveforms_amd import workloads as wl
     if name in ('sampler256', 'c4', 'c5'):
-        tag = {'sampler256': 'sampler256', 'c4': 'C4 sampler + 1024-tap FIR',
-               'c5': 'C5 per-rank shape'}[name]
         return (lambda c: wl.sum_channel(wf, 100, 1000 + c)), wl.c2_grid(points), np.float64, (
-            f'{tag}: {channels} ch/GPU x {points:.0e} pts, 100 gaussian+DRAG pulses/ch, seeds '
+            f'{channels} ch/GPU x {points:.0e} pts, 100 gaussian+DRAG pulses/ch, seeds '
             f'1000+c (SURVEY 8(d) C4/C5 channel spec), grid mode')
     if name == 'c2':
         return (lambda c: wl.c2_channel(wf)), wl.c2_grid(points), np.float64, (
@@ -151,7 +149,7 @@ def workload(name, channels, points):
             f'C3: {channels} WaveVStack ch/GPU x 20 pulses x {points:.0e} pts')
     if name == 'far':
         return (lambda c: far_channel(wf, c)), ('linspace', 0.0, points / 2e9, points, False), \
-            np.float64, (f'far: {channels} ch/GPU x {points:.0e} pts at 2 GS/s, 100 pulses/ch with '
+            np.float64, (f'{channels} ch/GPU x {points:.0e} pts at 2 GS/s, 100 pulses/ch with '
                          f'250-350 MHz carriers out to t = {points / 2e9 * 1e3:.1f} ms')
     raise SystemExit(f'unknown workload {name}')
 

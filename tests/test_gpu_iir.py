@@ -185,3 +185,61 @@ def test_long_cascade_fp32_initial_in_place():
     plan.apply(xd.data_ptr(), n, xd.data_ptr(), n, None, None, 0.3)
     torch.cuda.synchronize()
     assert np.max(np.abs(xd.cpu().numpy().astype(np.float64) - want)) <= 2e-5
+
+
+def test_order_zero_and_empty_filter_lists():
+    # scipy.signal.lfilter accepts a bare gain and predistort(filters=[]) combines to b = a = [1]
+    # (reference distortion.py:298-321): the device runs them as a scale
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=5000)
+    assert np.allclose(distortion.predistort(x, filters=[]), lfilter([1.0], [1.0], x), atol=0, rtol=0)
+    got = distortion.predistort(x, filters=[([0.5], [2.0])])
+    assert np.max(np.abs(got - lfilter([0.5], [2.0], x))) <= 1e-15
+    assert np.array_equal(distortion.distort(x, [], 1e9), x)
+
+
+def test_long_cascades_split_into_passes():
+    # 12 biquads (order-24 Butterworth as SOS) and a mixed-order cascade of total order 21:
+    # scipy has no limit on the number of sections; the device runs consecutive passes
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=30000)
+    sos = butter(24, 0.2, output='sos')
+    zi = rng.normal(size=(len(sos), 2)) * 1e-3
+    n = len(x)
+    plan = _engine.IirPlan([(r[:3], r[3:]) for r in sos], n, 1, np.float64)
+    dx, dy = _engine.DeviceBuffer(n * 8), _engine.DeviceBuffer(n * 8)
+    dzi, dzf = _engine.DeviceBuffer(zi.nbytes), _engine.DeviceBuffer(zi.nbytes)
+    dx.upload(x)
+    dzi.upload(zi)
+    plan.apply(dx.ptr, n, dy.ptr, n, dzi.ptr, dzf.ptr)
+    _engine.sync()
+    want, zf = sosfilt(sos, x, zi=zi[:, None, :].reshape(len(sos), 2))
+    got = dy.download((n, ), np.float64)
+    assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, np.abs(want).max())
+    assert np.max(np.abs(dzf.download(zi.shape, np.float64) - zf)) <= 1e-10 * max(1.0, np.abs(zf).max())
+    for b_ in (dx, dy, dzi, dzf):
+        b_.close()
+    plan.close()
+    # mixed orders 5 + 0 + 7 + 2 + 7 = 21 states, through predistort-like sections
+    secs = [butter(5, 0.3), ([0.7], [1.0]), butter(7, 0.25), butter(2, 0.4), butter(7, 0.35)]
+    got, _ = distortion.iir_host(x, secs)
+    want = x
+    for b, a in secs:
+        want = lfilter(b, a, want)
+    assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, np.abs(want).max())
+
+
+def test_predistort_combined_order_above_16():
+    # 20 first-order exp-decay sections: the reference multiplies them into one order-20
+    # polynomial pair and calls lfilter; zero initial state -> the cascade is the same system
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.zeros(100), np.ones(4000)])
+    filters = [distortion.exp_decay_filter(a_, t_, 1e9)
+               for a_, t_ in zip(rng.uniform(-0.02, 0.02, 20), rng.uniform(20e-9, 900e-9, 20))]
+    got = distortion.predistort(x, filters)
+    want = x
+    for b, a in filters:
+        want = lfilter(b, a, want)
+    assert np.max(np.abs(got - want)) <= 1e-9
+    with pytest.raises(NotImplementedError):
+        distortion.predistort(x, filters, initial=0.3)
