@@ -57,12 +57,21 @@ extern "C" {
  *     waveforms_amd/multy_drag.py:device_args):
  *       (t0, freq, width, delta, phase, plateau, tab_half_width, m, dq,
  *        Px[0..m], Py[0..m], Cx, Cy [, QLx, QLy, QRx, QRy (dq+1 each, highest power first)])
- * Any other id -> WFK_EUNSUP (Python callables cannot run on the device).      */
+ * 1000 SAMPLED (i0, v[0..m-1]): the factor's value at sample index j is v[j - i0] (j - i0
+ *     clamped into [0, m)); `shift` is ignored.  This is how a primitive that only the CALLER
+ *     can evaluate reaches the device: the caller evaluates it once per distinct factor on the
+ *     plan's own time axis, over the samples of the piece (i0 = first sample of the piece), exactly
+ *     where the reference calls function_lib[id](x[start:stop] - shift, *args)
+ *     (_apply, waveforms/_waveform.pyx:130-131) -- Python callables registered with function() /
+ *     registerBaseFunc (waveform.py:1470-1478, _waveform.pyx:264-271) and function_lib= overrides
+ *     (waveform.py:178,535,679).
+ * Any other id -> WFK_EUNSUP.                                                     */
 enum {
   WFK_LINEAR = 1, WFK_GAUSSIAN = 2, WFK_ERF = 3, WFK_COS = 4, WFK_SINC = 5,
   WFK_EXP = 6, WFK_INTERP = 7, WFK_LINEARCHIRP = 8, WFK_EXPONENTIALCHIRP = 9,
   WFK_HYPERBOLICCHIRP = 10, WFK_COSH = 11, WFK_SINH = 12, WFK_DRAG = 13,
-  WFK_MOLLIFIER = 14, WFK_D_GAUSSIAN = 15, WFK_DRAG_SIN = 16, WFK_DRAG_SINX = 17
+  WFK_MOLLIFIER = 14, WFK_D_GAUSSIAN = 15, WFK_DRAG_SIN = 16, WFK_DRAG_SINX = 17,
+  WFK_SAMPLED = 1000
 };
 
 /*

@@ -21,6 +21,7 @@ Outputs
   tests/golden/design.npz         extractKernel / exp_decay_filter_old / factor_filter / stable_filter
   tests/golden/fuzz.npz           reference wav(t) for random scripts (+ fuzz_frontend.json: tolist())
   tests/golden/edges.npz          wav(x) on empty / single / off-support / non-uniform x
+  tests/golden/user.npz           scripts with Python-callable primitives (function(), function_lib=)
 """
 import json
 import os
@@ -105,6 +106,23 @@ def main():
     design['stable'] = np.array([rdist.stable_filter(f, fs) for f, fs in cases.stable_cases()])
     np.savez_compressed(os.path.join(gold, 'design.npz'), **design)
     if sys.argv[1:] == ['design']:         # regenerate this fixture only
+        return
+
+    # ---- Python-callable primitives: function() / registerBaseFunc / function_lib= -------
+    user = {}
+    for name, build in cases.USER_CASES.items():
+        w, lib, x = build(ref)
+        y = w(x) if lib is None else w(x, function_lib=lib)
+        user[name + '.y'] = np.asarray(y)
+        if not isinstance(w, WaveVStack):
+            parts = w(x, frag=True) if lib is None else w(x, frag=True, function_lib=lib)
+            user[name + '.frag_idx'] = np.array([[a, b] for a, b, _ in parts], dtype=np.int64).reshape(-1, 2)
+            user[name + '.frag_sum'] = np.array([np.sum(np.asarray(p_) * np.ones(b - a)) for a, b, p_ in parts])
+    w, lib = cases.user_sample_case(ref)
+    user['sample.full'] = w.sample(function_lib=lib)
+    user['sample.chunked'] = np.concatenate(list(w.sample(chunk_size=257, function_lib=lib)))
+    np.savez_compressed(os.path.join(gold, 'user.npz'), **user)
+    if sys.argv[1:] == ['user']:           # regenerate this fixture only
         return
 
     # ---- random scripts (tests/cases.py: random_channel), evaluated by the reference ----

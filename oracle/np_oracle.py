@@ -65,7 +65,9 @@ PRIMITIVES = {
 }
 
 
-def eval_expr(expr, x):
+def eval_expr(expr, x, lib=None):
+    # lib: function_lib of the reference (_apply, _waveform.pyx:130-131): id -> callable(t, *args)
+    lib = PRIMITIVES if lib is None else lib
     cache = {}
     total = 0
     for (factors, powers), amp in zip(*expr):
@@ -73,18 +75,18 @@ def eval_expr(expr, x):
         for f, n in zip(factors, powers):
             if f not in cache:
                 type_id, *args, shift = f
-                cache[f] = PRIMITIVES[type_id](x - shift, *args)
+                cache[f] = lib[type_id](x - shift, *args)
             prod = prod * (cache[f] if n == 1 else cache[f]**n)
         total = total + amp * prod
     return total
 
 
-def pieces(bounds, seq, x, lo=-np.inf, hi=np.inf):
+def pieces(bounds, seq, x, lo=-np.inf, hi=np.inf, lib=None):
     edges = np.searchsorted(x, bounds)
     parts, dtype, a = [], float, 0
     for i, b in enumerate(edges):
         if a < b and seq[i] != _ZERO:
-            part = np.clip(eval_expr(seq[i], x[a:b]), lo, hi)
+            part = np.clip(eval_expr(seq[i], x[a:b], lib), lo, hi)
             if isinstance(part, complex) or (isinstance(part, np.ndarray) and
                                              isinstance(part[0], complex)):
                 dtype = complex
@@ -93,26 +95,26 @@ def pieces(bounds, seq, x, lo=-np.inf, hi=np.inf):
     return parts, dtype
 
 
-def call_waveform(w, x):
-    parts, dtype = pieces(w.bounds, w.seq, x, w.min, w.max)
+def call_waveform(w, x, lib=None):
+    parts, dtype = pieces(w.bounds, w.seq, x, w.min, w.max, lib)
     out = np.zeros_like(x, dtype=dtype)
     for a, b, part in parts:
         out[a:b] += part
     return out
 
 
-def call_vstack(w, x):
+def call_vstack(w, x, lib=None):
     out = np.full_like(x, w.offset, dtype=np.complex128)
     if w.shift != 0:
         x = x - w.shift
     for bounds, seq in w.wlist:
-        for a, b, part in pieces(bounds, seq, x)[0]:
+        for a, b, part in pieces(bounds, seq, x, lib=lib)[0]:
             out[a:b] += part
     return out.real
 
 
-def call(w, x):
-    return call_vstack(w, x) if hasattr(w, 'wlist') else call_waveform(w, x)
+def call(w, x, lib=None):
+    return call_vstack(w, x, lib) if hasattr(w, 'wlist') else call_waveform(w, x, lib)
 
 
 def sample(w):

@@ -264,9 +264,20 @@ static int eval(const wfk_program* P, const tsrc* ts, double* re, double* im,
               double prod = 1.0;
               for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f) {
                 double v;
-                int rc = prim(P->fc_type[f], x - P->fc_shift[f],
-                              P->pool + P->fc_arg_off[f],
-                              P->fc_arg_off[f + 1] - P->fc_arg_off[f], &v);
+                int rc = 0;
+                if (P->fc_type[f] == WFK_SAMPLED) {
+                  /* caller-evaluated factor: args = (i0, values...), value of sample i is values[i - i0]
+                     (include/wfk.h; the reference evaluates function_lib[id] on x[start:stop], pyx:130-131) */
+                  const double* a = P->pool + P->fc_arg_off[f];
+                  int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 1, j = i - (int64_t)a[0];
+                  if (m < 1) return WFK_EINVAL;
+                  j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+                  v = a[1 + j];
+                } else {
+                  rc = prim(P->fc_type[f], x - P->fc_shift[f],
+                            P->pool + P->fc_arg_off[f],
+                            P->fc_arg_off[f + 1] - P->fc_arg_off[f], &v);
+                }
                 if (rc) return rc;
                 double n = P->fc_power[f];
                 prod = prod * (n == 1.0 ? v : np_power(v, n));

@@ -427,3 +427,119 @@ FAR_GOLD = 40        # far-from-origin scripts evaluated by the real reference (
 def far_golden_case(wf, seed):
     chans, grid = far_from_origin_case(wf, seed)
     return chans, (grid[0], grid[1], grid[2], min(grid[3], 1500), grid[4])
+
+
+# ---------------------------------------------------------------------------------------
+# Python-callable primitives: function(), registerBaseFunc, function_lib= (reference
+# waveform.py:1470-1478, 178/535/679; _waveform.pyx:130-131, 264-271).  Module-level
+# callables (picklable).  Each case: name -> builder(ns) -> (waveform, function_lib | None, x)
+# ---------------------------------------------------------------------------------------
+def uf_tanh(t, k, a):
+    return a * np.tanh(k * t)
+
+
+def uf_const(t):
+    return 0.75                      # a scalar: broadcast by the reference's arithmetic
+
+
+def uf_bump(t, w):
+    return 1.0 / (1.0 + (t / w)**2)  # Lorentzian
+
+
+def uf_triangle(t, w):
+    return 2.0 / np.pi * np.arcsin(np.sin(w * t + np.pi / 2))   # triangle wave in place of cos
+
+
+def uf_table(t, pts):
+    return np.interp(t, np.linspace(-40e-9, 40e-9, len(pts)), pts)   # tuple argument
+
+
+def _base_lib(ns):
+    return dict(ns._waveform._baseFunc)
+
+
+def _user_x(n=4001, a=-120e-9, b=160e-9):
+    return np.linspace(a, b, n)
+
+
+def _u_tanh(ns):
+    w = ns.function(uf_tanh, 3e7, 0.8, start=-50e-9, stop=50e-9) * ns.cos(2 * pi * 50e6)
+    return w, None, _user_x()
+
+
+def _u_power_const(ns):
+    w = ns.function(uf_tanh, 5e7, 1.0, start=-60e-9, stop=60e-9)**2 + \
+        (ns.function(uf_const, start=10e-9, stop=90e-9) >> 20e-9) * 0.5
+    return w, None, _user_x()
+
+
+def _u_shared_factor(ns):
+    f = ns.function(uf_bump, 15e-9, start=-70e-9, stop=70e-9) >> 12e-9
+    I, Q = ns.mixing(f, freq=80e6, phase=0.3, DRAGScaling=2e-10 * 0)     # f in two terms of one piece
+    return I + 0.25 * (ns.gaussian(30e-9) >> 60e-9) * ns.function(uf_tanh, 1e8, 1.0), None, _user_x()
+
+
+def _u_vstack(ns):
+    ws = [ns.function(uf_bump, 10e-9, start=-40e-9, stop=40e-9) * ns.cos(2 * pi * 30e6),
+          ns.gaussian(40e-9) >> 30e-9,
+          ns.function(uf_table, tuple(np.sin(np.arange(17) * 0.7)), start=-40e-9, stop=40e-9) >> 50e-9]
+    w = (ns.WaveVStack(ws) + 0.125) >> 7e-9
+    return w, None, _user_x()
+
+
+def _u_lib_override(ns):
+    lib = _base_lib(ns)
+    lib[2] = uf_bump                 # GAUSSIAN(t, std_sq2) -> Lorentzian of the same argument
+    w = (ns.gaussian(40e-9) >> 10e-9) * ns.cos(2 * pi * 40e6) + 0.2 * ns.sin(2 * pi * 10e6)
+    return w, lib, _user_x()
+
+
+def _u_lib_vstack_attr(ns):
+    lib = _base_lib(ns)
+    lib[4] = uf_triangle             # COS(t, w) -> triangle wave
+    w = ns.WaveVStack([ns.gaussian(50e-9) * ns.cos(2 * pi * 25e6), ns.square(60e-9) >> 70e-9])
+    w.function_lib = lib
+    return w, None, _user_x()
+
+
+def _u_lib_remap_builtin(ns):
+    lib = _base_lib(ns)
+    lib[11] = lib[12]                # COSH evaluated as SINH (a built-in under another id)
+    w = ns.cosh(2e7) * (ns.square(100e-9) >> 20e-9)
+    return w, lib, _user_x()
+
+
+def _u_complex_amp(ns):
+    w = (1 + 2j) * ns.function(uf_tanh, 4e7, 1.0, start=-30e-9, stop=80e-9) + \
+        0.5j * (ns.gaussian(20e-9) >> 100e-9)
+    return w, None, _user_x()
+
+
+def _u_registered_id(ns):
+    tid = ns.registerBaseFunc(uf_bump)
+    expr = ns._waveform.basic_wave(tid, 8e-9, shift=25e-9)
+    w = ns.Waveform(bounds=(round(-20e-9, 15), round(90e-9, 15), np.inf),
+                    seq=(ns._waveform._zero, expr, ns._waveform._zero)) * 1.5
+    return w, None, _user_x()
+
+
+USER_CASES = {
+    'u_tanh': _u_tanh, 'u_power_const': _u_power_const, 'u_shared_factor': _u_shared_factor,
+    'u_vstack': _u_vstack, 'u_lib_override': _u_lib_override,
+    'u_lib_vstack_attr': _u_lib_vstack_attr, 'u_lib_remap_builtin': _u_lib_remap_builtin,
+    'u_complex_amp': _u_complex_amp, 'u_registered_id': _u_registered_id,
+}
+
+
+def user_sample_case(ns):
+    """Waveform.sample(function_lib=...) on its own arange grid, plain and chunked."""
+    w = ns.square(200e-9, edge=40e-9, type='erf') * ns.cos(2 * pi * 15e6) + \
+        ns.function(uf_bump, 30e-9, start=-150e-9, stop=150e-9)
+    lib = _base_lib(ns)              # (after function(): an explicit library REPLACES the registry)
+    lib[3] = uf_tanh_edge            # ERF(t, std_sq2) -> tanh edge
+    w.start, w.stop, w.sample_rate = -300e-9, 300e-9, 2e9
+    return w, lib
+
+
+def uf_tanh_edge(t, s):
+    return np.tanh(t / s)

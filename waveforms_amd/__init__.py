@@ -13,6 +13,7 @@ from .waveform import (D, Waveform, WaveVStack, chirp, const, cos, cosh,
                        registerBaseFunc, registerDerivative, samplingPoints,
                        sign, sin, sinc, sinh, slepian, square, step, t, zero)
 
+from . import _waveform
 from .multy_drag import drag_sin, drag_sinx
 from .waveform_parser import wave_eval
 

@@ -72,13 +72,13 @@ class Program:
 _SIMPLE_ARGC = {k: v for k, v in _ARGC.items() if v is not None and k != _ir.DRAG}
 
 
+SAMPLED = 1000   # include/wfk.h WFK_SAMPLED: a factor evaluated by the caller, (i0, values...)
+
+
 def _factor_args(factor):
     type_id, *args, _shift = factor
     if type_id not in _ARGC:
-        raise NotImplementedError(
-            f'primitive id {type_id} has no device implementation '
-            f'(only the built-in ids 1..17 run on the GPU; Python callables '
-            f'registered with registerBaseFunc/function() cannot)')
+        raise KeyError(type_id)       # as function_lib[func_id] of the reference (_waveform.pyx:131)
     want = _ARGC[type_id]
     if type_id in (_ir.DRAG_SIN, _ir.DRAG_SINX):
         if len(args) != (7 if type_id == _ir.DRAG_SIN else 8):
@@ -112,14 +112,70 @@ def channel_members(w):
     return [(w.bounds, w.seq)], 0.0, 0.0, float(w.min), float(w.max)
 
 
-def flatten(channels) -> Program:
+def grid_values(grid: 'wfk_grid') -> np.ndarray:
+    """The NumPy array a `wfk_grid` stands for: t[i] = fl(fl(i*step) + t0), last element
+    overridden when has_last (the linspace / arange element formulas)."""
+    t = np.arange(int(grid.n), dtype=np.float64) * grid.step + grid.t0
+    if grid.has_last and grid.n > 0:
+        t[-1] = grid.last
+    return t
+
+
+class _HostFactors:
+    """Python-callable primitives (function(), registerBaseFunc, function_lib= overrides).
+
+    A callable cannot run on the device, so the HOST side of the product calls it where the
+    reference does -- `function_lib[id](x[start:stop] - shift, *args)` once per distinct factor
+    of a piece (_apply / _calc's cache, _waveform.pyx:130-147), with start/stop from
+    np.searchsorted on the (channel-shifted) time axis (:156) -- and hands the values to the
+    device as a WFK_SAMPLED table factor.  Built-in ids never come through here."""
+
+    def __init__(self, axis):
+        self._axis = axis
+        self._x = None
+
+    def x(self):
+        if self._x is None:
+            if self._axis is None:
+                raise ValueError('a Python-callable primitive needs the time axis to be evaluated on')
+            self._x = (grid_values(self._axis) if isinstance(self._axis, wfk_grid)
+                       else np.ascontiguousarray(self._axis, dtype=np.float64))
+        return self._x
+
+    def member_axis(self, tshift, bounds):
+        """(x - tshift, piece edges) of one member: what calc_parts sees (waveform.py:683-691)."""
+        x = self.x()
+        xs = x - tshift if tshift != 0 else x
+        return xs, np.searchsorted(xs, bounds)
+
+    @staticmethod
+    def evaluate(fn, factor, xs, start, stop):
+        _tid, *args, shift = factor
+        if stop <= start:
+            return np.zeros(0)
+        v = np.asarray(fn(xs[start:stop] - shift, *args))
+        if np.iscomplexobj(v):
+            if np.any(v.imag != 0):
+                raise NotImplementedError('complex-valued Python-callable primitive')
+            v = v.real
+        return np.ascontiguousarray(np.broadcast_to(v.astype(np.float64, copy=False),
+                                                    (stop - start, )))
+
+
+def flatten(channels, axis=None, function_lib=None) -> Program:
+    """channels -> wfk_program.  `axis` (a wfk_grid or the sorted time array) and
+    `function_lib` matter only for primitives that are Python callables: those are evaluated
+    here, on the exact sample times (see _HostFactors)."""
+    from .waveform import BuiltinPrimitive, _baseFunc
     ch_member_off = [0]
     ch_offset, ch_tshift, ch_lo, ch_hi = [], [], [], []
     mb_piece_off = [0]
     pc_bound, pc_term_off = [], [0]
     amp_re, amp_im, tm_factor_off = [], [], [0]
-    fc_type, fc_power, fc_shift, fc_arg_off, pool = [], [], [], [0], []
+    fc_type, fc_power, fc_shift, fc_arg_off = [], [], [], [0]
+    pool, pool_parts, pool_len = [], [], 0     # scalars collect in `pool`; big tables go in as arrays
     any_complex = False
+    host = None
 
     for w in channels:
         members, offset, tshift, lo, hi = channel_members(w)
@@ -127,11 +183,21 @@ def flatten(channels) -> Program:
         ch_tshift.append(tshift)
         ch_lo.append(lo)
         ch_hi.append(hi)
+        # the library of this channel: explicit argument, else the WaveVStack's own, else the
+        # registry (reference: waveform.py:539-540, 685-689).  `native`: ids whose entry is the
+        # device primitive of that very id -- the hot case, no lookup per factor.
+        lib = function_lib if function_lib is not None else getattr(w, 'function_lib', None)
+        if lib is None:
+            lib = _baseFunc
+        native = {tid for tid, fn in lib.items()
+                  if isinstance(fn, BuiltinPrimitive) and fn.type_id == tid}
         for bounds, seq in members:
             if len(bounds) != len(seq) or not bounds or bounds[-1] != math.inf:
                 raise ValueError('bounds/seq mismatch or last bound is not +inf')
-            for b, (terms, amps) in zip(bounds, seq):
+            xs = edges = None
+            for ip, (b, (terms, amps)) in enumerate(zip(bounds, seq)):
                 pc_bound.append(float(b))
+                cache = {}            # distinct factor -> values, per piece (_calc's lru_cache)
                 for (factors, powers), amp in zip(terms, amps):
                     if isinstance(amp, complex):
                         any_complex = True
@@ -143,20 +209,48 @@ def flatten(channels) -> Program:
                     for f, n in zip(factors, powers):
                         if isinstance(n, complex):
                             raise NotImplementedError('complex power')
-                        fc_type.append(f[0])
+                        tid = f[0]
                         fc_power.append(n)
                         fc_shift.append(f[-1])
-                        argc = _SIMPLE_ARGC.get(f[0])
-                        if argc is not None and len(f) == argc + 2:
-                            if argc:
-                                pool.extend(f[1:-1])    # converted to float64 in one go below
+                        if tid in native:
+                            fc_type.append(tid)
+                            argc = _SIMPLE_ARGC.get(tid)
+                            if argc is not None and len(f) == argc + 2:
+                                if argc:
+                                    pool.extend(f[1:-1])    # converted to float64 in one go below
+                            else:
+                                pool.extend(_factor_args(f))
                         else:
-                            pool.extend(_factor_args(f))
-                        fc_arg_off.append(len(pool))
+                            fn = lib[tid]     # KeyError for an unknown id, like the reference
+                            if isinstance(fn, BuiltinPrimitive):
+                                # the id is mapped onto ANOTHER device primitive
+                                fc_type.append(fn.type_id)
+                                pool.extend(_factor_args((fn.type_id, ) + tuple(f[1:])))
+                            else:
+                                if host is None:
+                                    host = _HostFactors(axis)
+                                if xs is None:
+                                    xs, edges = host.member_axis(tshift, bounds)
+                                start = int(edges[ip - 1]) if ip > 0 else 0
+                                stop = int(edges[ip])
+                                if f not in cache:
+                                    cache[f] = host.evaluate(fn, f, xs, start, stop)
+                                vals = cache[f]
+                                fc_type.append(SAMPLED)
+                                pool.append(float(start))
+                                if len(vals):
+                                    pool_parts.append(np.asarray(pool, dtype=np.float64))
+                                    pool_parts.append(vals)
+                                    pool_len += len(pool) + len(vals)
+                                    pool = []
+                        fc_arg_off.append(pool_len + len(pool))
                     tm_factor_off.append(len(fc_type))
                 pc_term_off.append(len(amp_re))
             mb_piece_off.append(len(pc_bound))
         ch_member_off.append(len(mb_piece_off) - 1)
+    if pool_parts:
+        pool_parts.append(np.asarray(pool, dtype=np.float64))
+        pool = np.concatenate(pool_parts)
 
     def i32(x):
         return np.ascontiguousarray(x, dtype=np.int32)

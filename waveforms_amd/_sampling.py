@@ -15,13 +15,6 @@ from . import _engine, _flatten
 from ._ir import ZERO
 
 
-def _check_function_lib(function_lib):
-    if function_lib is not None:
-        raise NotImplementedError(
-            'function_lib overrides are Python callables and cannot run on the '
-            'device; only the built-in primitive ids 1..17 are implemented')
-
-
 def _as_time_array(x):
     x = np.asarray(x)
     if x.ndim != 1:
@@ -78,11 +71,10 @@ def _finish(w, plan, frag, out, accumulate):
 
 
 def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=None):
-    _check_function_lib(function_lib)
     if isinstance(x, (int, float, complex)):
-        return call_waveform(w, np.array([x]))[0]
+        return call_waveform(w, np.array([x]), function_lib=function_lib)[0]
     t = _as_time_array(x)
-    plan = _engine.Plan(_flatten.flatten([w]), t=t)
+    plan = _engine.Plan(_flatten.flatten([w], t, function_lib), t=t)
     try:
         return _finish(w, plan, frag, out, accumulate)
     finally:
@@ -92,10 +84,10 @@ def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=Non
 def call_vstack(w, x, function_lib=None):
     if function_lib is None and w.function_lib is not None:
         function_lib = w.function_lib
-    _check_function_lib(function_lib)
     if isinstance(x, (int, float, complex)):
-        return call_vstack(w, np.array([x]))[0]
-    plan = _engine.Plan(_flatten.flatten([w]), t=_as_time_array(x))
+        return call_vstack(w, np.array([x]), function_lib)[0]
+    t = _as_time_array(x)
+    plan = _engine.Plan(_flatten.flatten([w], t, function_lib), t=t)
     try:
         return plan.run_host(np.float64)[0]
     finally:
@@ -138,8 +130,7 @@ def _sample_filtered(w, plan, sos, initial, zi):
 
 def _sample_on_grid(w, grid, out, function_lib, filters=None, zi=None):
     from .waveform import WaveVStack
-    _check_function_lib(function_lib)
-    plan = _engine.Plan(_flatten.flatten([w]), grid=grid)
+    plan = _engine.Plan(_flatten.flatten([w], grid, function_lib), grid=grid)
     try:
         if filters is not None:
             sos, initial = filters
@@ -213,11 +204,11 @@ class BatchSampler:
         arr = bs.to_host(np.float32)                # or: run + copy back
     """
 
-    def __init__(self, channels, grid):
+    def __init__(self, channels, grid, function_lib=None):
         if not isinstance(grid, _flatten.wfk_grid):
             grid = _flatten.grid_from_desc(grid)
         self.grid = grid
-        self.prog = _flatten.flatten(list(channels))
+        self.prog = _flatten.flatten(list(channels), grid, function_lib)
         self.plan = _engine.Plan(self.prog, grid=grid)
         self.n = self.plan.n
         self.n_channels = self.plan.n_channels

@@ -59,6 +59,7 @@ int argc_of(int type) {
     case WFK_DRAG: return 6;
     case WFK_INTERP: return -1;
     case WFK_DRAG_SIN: case WFK_DRAG_SINX: return -3;
+    case WFK_SAMPLED: return -4;
     default: return -2;
   }
 }
@@ -176,6 +177,13 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       if (!ok) { err = "malformed compiled DRAG_SIN/DRAG_SINX argument block"; return WFK_EINVAL; }
       continue;
     }
+    if (want == -4) {   // caller-evaluated factor: (i0, values...)
+      const double i0 = have >= 1 ? P->pool[P->fc_arg_off[f]] : NAN;
+      if (!(have >= 1) || !(i0 >= 0) || i0 != std::floor(i0) || i0 > 9.0e15) {
+        err = "malformed SAMPLED factor: needs (i0 >= 0, values...)"; return WFK_EINVAL;
+      }
+      continue;
+    }
     if ((want >= 0 && have != want) || (want == -1 && have < 3)) {
       err = "wrong argument count for primitive id " + std::to_string(P->fc_type[f]);
       return WFK_EINVAL;
@@ -252,6 +260,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   // under ten multiplexed carriers -- the values the previous term left in the workgroup's LDS
   // value buffer are reused: the repeated record is marked (type + WFK_M_REUSE) when its
   // signature equals the last direct factor emitted into the same block.
+  std::map<int64_t, int64_t> sampled_at; // SAMPLED tables already copied: program pool offset -> H.pool offset
   std::vector<double> last_direct;      // record of the last direct factor of the current block
   auto emit_factor = [&](BlockBuilder& B, int32_t f, double tshift, int64_t s0, int64_t s1) {
     const int type = P->fc_type[f];
@@ -345,13 +354,24 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           rec[3] = (double)H.pool.size();
           H.pool.insert(H.pool.end(), a, a + na);
           break;
+        case WFK_SAMPLED: {
+          // one copy per table, however many device pieces the member piece was cut into
+          auto it = sampled_at.find(P->fc_arg_off[f]);
+          if (it == sampled_at.end()) {
+            it = sampled_at.emplace(P->fc_arg_off[f], (int64_t)H.pool.size()).first;
+            H.pool.insert(H.pool.end(), a + 1, a + na);
+            if (na == 1) H.pool.push_back(NAN);    // empty table: never indexed, keep the offset valid
+          }
+          rec[0] = WFK_M_SAMPLED; rec[3] = (double)it->second; rec[4] = a[0]; rec[5] = (double)(na - 1);
+          break;
+        }
         default:
           for (int64_t k = 0; k < na && k < 6; ++k) rec[3 + k] = a[k];
       }
       ++H.n_direct;
       std::vector<double> sig(rec, rec + WFK_FREC);
       const bool pooled = type == WFK_INTERP || type == WFK_MOLLIFIER || type == WFK_DRAG_SIN ||
-                          type == WFK_DRAG_SINX;             // records point into the pool: never equal
+                          type == WFK_DRAG_SINX || type == WFK_SAMPLED;             // records point into the pool: never equal
       if (!pooled && rec[0] < 100.0 && sig == last_direct) rec[0] += WFK_M_REUSE;
       else last_direct = pooled || rec[0] >= 100.0 ? std::vector<double>() : sig;
     } else {

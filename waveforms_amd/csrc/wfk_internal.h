@@ -67,6 +67,7 @@
 #define WFK_M_GAUSS_REC 102   // g_{n+1}=g_n r_n, r_{n+1}=r_n q        a0 = sigma, a1 = H, a2 = q
 #define WFK_M_COS_TAB 104     // cos(th0 + n*dth) = c0*C[n] - s0*S[n]  a0 = w, aux = table
 #define WFK_M_EXP_REC 106     // e_{n+1} = e_n * rho                   a0 = alpha, a1 = rho
+#define WFK_M_SAMPLED 20      // caller-evaluated factor (WFK_SAMPLED): a0 = pool offset of the values, a1 = i0, a2 = m
 #define WFK_M_REUSE 1000      // added to a direct factor's type: same record as the previous direct factor of
                               // the block -> its values are still in the LDS value buffer
 #define WFK_M_INTERP_GRID 108 // np.interp on linspace knots, exact per-sample times, knot/slope loads

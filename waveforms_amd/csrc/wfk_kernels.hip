@@ -465,13 +465,29 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
   const double pw = r[1];
   const bool has_pw = pw != 1.0;
   double* mine = s_val + threadIdx.x;
+  if (mode == WFK_M_SAMPLED) {
+    // caller-evaluated factor (WFK_SAMPLED; Python callables of function()/function_lib=): the
+    // value of sample j is table[j - i0]; the index is clamped, so a lane beyond the piece (or
+    // beyond n) reads a valid entry that the store phase then drops
+    const double* tab = a.pool + (int64_t)r[3];
+    const int64_t i0 = (int64_t)r[4], m = (int64_t)r[5];
 #pragma unroll 1
-  for (int k = 0; k < NS; ++k) {
-    double x = time_at<TLIST>(a, j0 + 64 * (int64_t)k);
-    if (tshift != 0.0) x = x - tshift;
-    double v = prim_direct(mode, x - shift, r, a.pool);
-    if (has_pw) v = np_power(v, pw);
-    mine[k * WFK_WG] = v;
+    for (int k = 0; k < NS; ++k) {
+      int64_t i = j0 + 64 * (int64_t)k - i0;
+      i = i < 0 ? 0 : (i >= m ? m - 1 : i);
+      double v = m > 0 ? tab[i] : __builtin_nan("");
+      if (has_pw) v = np_power(v, pw);
+      mine[k * WFK_WG] = v;
+    }
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < NS; ++k) {
+      double x = time_at<TLIST>(a, j0 + 64 * (int64_t)k);
+      if (tshift != 0.0) x = x - tshift;
+      double v = prim_direct(mode, x - shift, r, a.pool);
+      if (has_pw) v = np_power(v, pw);
+      mine[k * WFK_WG] = v;
+    }
   }
 #pragma unroll
   for (int k = 0; k < NS; ++k) prod[k] *= (T)mine[k * WFK_WG];

@@ -23,23 +23,63 @@ from ._ir import (COS, COSH, D_GAUSSIAN, DRAG, ERF, EXP, EXPONENTIALCHIRP,
                   primitive)
 
 # --------------------------------------------------------------------------
-# primitive registry (API surface only: ids >= FIRST_USER_TYPE are Python
-# callables, which the device sampler cannot run and rejects loudly)
+# primitive registry (reference: _waveform.pyx:10-13, 264-287, 374-388)
 # --------------------------------------------------------------------------
-_user_functions: dict[int, object] = {}
+class BuiltinPrimitive:
+    """Registry entry of a primitive that has a device implementation (ids 1..17).
+
+    It marks the id as "evaluated by the HIP kernels"; calling it evaluates the primitive
+    on the device too (`_baseFunc[GAUSSIAN](t, sigma)` inside a user's own callable works),
+    so there is no NumPy evaluation of built-ins anywhere in this package."""
+
+    __slots__ = ('type_id', )
+
+    def __init__(self, type_id):
+        self.type_id = type_id
+
+    def __call__(self, t, *args):
+        scalar = np.ndim(t) == 0
+        x = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        # one piece up to +inf: np.searchsorted(x, [inf]) == len(x) whatever the order of x
+        y = Waveform(seq=(primitive(self.type_id, *args), ))(x.ravel()).reshape(x.shape)
+        return y[0] if scalar else y
+
+    def __repr__(self):
+        return f'<device primitive {_ir.PRIMITIVE_NAMES.get(self.type_id, self.type_id)}>'
+
+    def __reduce__(self):
+        return (BuiltinPrimitive, (self.type_id, ))
+
+
+#: id -> evaluator, the default `function_lib` (reference: `_baseFunc`).  Built-in ids map to
+#: BuiltinPrimitive markers; ids from registerBaseFunc()/function() map to the user's callable,
+#: which the HOST calls once per distinct factor and piece on the exact sample times
+#: (`function_lib[id](x[start:stop] - shift, *args)`, reference _waveform.pyx:130-131); the
+#: device then reads the values as a per-sample table factor (_flatten.py, WFK_SAMPLED).
+_baseFunc: dict[int, object] = {i: BuiltinPrimitive(i) for i in range(1, _ir.FIRST_USER_TYPE)}
 _next_type_id = _ir.FIRST_USER_TYPE
 
 
 def registerBaseFunc(func) -> int:
-    """Reserve a primitive id for a Python callable
-    (reference: _waveform.pyx:264-271).  The id can be used to build trees and
-    flat lists; sampling a tree that contains it raises NotImplementedError
-    because a Python callable has no device implementation."""
+    """Register a Python callable `func(t_shifted_array, *args) -> array` as a primitive and
+    return its id (reference: _waveform.pyx:264-271)."""
     global _next_type_id
     type_id = _next_type_id
     _next_type_id += 1
-    _user_functions[type_id] = func
+    _baseFunc[type_id] = func
     return type_id
+
+
+def packBaseFunc():
+    """reference: _waveform.pyx:274-275"""
+    import pickle
+    return pickle.dumps(_baseFunc)
+
+
+def updateBaseFunc(buf):
+    """reference: _waveform.pyx:278-279"""
+    import pickle
+    _baseFunc.update(pickle.loads(buf))
 
 
 def registerDerivative(type_id, rule):
@@ -464,13 +504,28 @@ class WaveVStack(Waveform):
     __hash__ = None
 
     def __getstate__(self):
+        # the function library travels pickled, when it can be (reference: waveform.py:823-833
+        # uses dill; plain pickle here -- dill is not a dependency of this package)
+        function_lib = self.function_lib
+        if function_lib:
+            try:
+                import pickle
+                function_lib = pickle.dumps(function_lib)
+            except Exception:
+                function_lib = None
         return (self.wlist, self.start, self.stop, self.sample_rate,
-                self.offset, self.shift, self.filters, self.label, None)
+                self.offset, self.shift, self.filters, self.label, function_lib or None)
 
     def __setstate__(self, state):
         (self.wlist, self.start, self.stop, self.sample_rate, self.offset,
-         self.shift, self.filters, self.label, _) = state
-        self.function_lib = None
+         self.shift, self.filters, self.label, function_lib) = state
+        if function_lib:
+            try:
+                import pickle
+                function_lib = pickle.loads(function_lib)
+            except Exception:
+                function_lib = None
+        self.function_lib = function_lib or None
 
 
 # --------------------------------------------------------------------------
