@@ -59,12 +59,16 @@ def test_big_grid_indices():
     assert plan.info.n_direct == 0 and plan.info.n_generic == 0 and plan.info.n_fused > 0
 
 
-def test_unsupported_primitive_raises():
+def test_callable_primitives_need_an_axis_and_unknown_ids_are_refused():
+    # a Python callable is evaluated by the host on the plan's time axis: no axis, no program
     w = wf.function(lambda t: t * 0 + 1.0)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         _flatten.flatten([w])
-    with pytest.raises(NotImplementedError):
-        wf.cos(1)(np.linspace(0, 1, 5), function_lib={1: lambda t: t})
+    prog = _flatten.flatten([w], np.linspace(0, 1, 5))
+    assert list(prog.arrays['fc_type']) == [_flatten.SAMPLED]
+    # an explicit library replaces the registry (reference _apply: function_lib[func_id])
+    with pytest.raises(KeyError):
+        _flatten.flatten([wf.cos(1)], np.linspace(0, 1, 5), function_lib={1: lambda t: t})
 
 
 def test_sample_needs_init():
