@@ -153,6 +153,10 @@ int wfk_plan_create_grid(const wfk_program* prog, const wfk_grid* grid,
  * uploaded); replaces Waveform.__call__(x) for arbitrary x                     */
 int wfk_plan_create_tlist(const wfk_program* prog, const double* t_host,
                           int64_t n, wfk_plan** out);
+/* 1 and *grid filled if the sorted host array t_host[0..n) is BIT-IDENTICAL to a uniform NumPy
+ * grid (np.linspace with or without endpoint, np.arange: every element is compared), else 0.
+ * Lets Waveform.__call__(x) (waveform.py:529-563) compile grid mode for the usual x.     */
+int wfk_grid_detect(const double* t_host, int64_t n, wfk_grid* grid);
 int wfk_plan_destroy(wfk_plan* plan);
 int wfk_plan_get_info(const wfk_plan* plan, wfk_plan_info* info);
 /* np.searchsorted(x - tshift, bounds) of one member (integer parity probe);

@@ -62,6 +62,7 @@ def lib():
         P, I64, I32, VP = C.POINTER, C.c_int64, C.c_int32, C.c_void_p
         l.wfk_plan_create_grid.argtypes = [P(wfk_program), P(wfk_grid), P(VP)]
         l.wfk_plan_create_tlist.argtypes = [P(wfk_program), VP, I64, P(VP)]
+        l.wfk_grid_detect.argtypes = [VP, I64, P(wfk_grid)]
         l.wfk_plan_destroy.argtypes = [VP]
         l.wfk_plan_get_info.argtypes = [VP, P(wfk_plan_info)]
         l.wfk_plan_member_index.argtypes = [VP, I32, VP, I32]
@@ -111,6 +112,15 @@ def device_count() -> int:
 
 def set_device(ordinal: int):
     check(lib().wfk_set_device(ordinal))
+
+
+def detect_grid(t: np.ndarray):
+    """-> wfk_grid if the float64 array `t` is bit-identical to a np.linspace / np.arange grid
+    (exact element-wise check inside the library), else None."""
+    if os.environ.get('WFK_NO_GRID_DETECT') == '1' or t.dtype != np.float64 or not t.flags.c_contiguous:
+        return None
+    g = wfk_grid()
+    return g if lib().wfk_grid_detect(t.ctypes.data, len(t), C.byref(g)) == 1 else None
 
 
 class Plan:

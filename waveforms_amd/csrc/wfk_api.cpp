@@ -286,7 +286,8 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   const char* cplx = (out_kind == WFK_OUT_C128 || out_kind == WFK_OUT_C64) ? "true" : "false";
   const HostPlan& h = p->h;
   if (!h.tlist && h.lean) {
-    name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) + ">";
+    name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +
+           (h.n_corr > 0 && out_kind != WFK_OUT_F32 && out_kind != WFK_OUT_C64 ? ",true>" : ",false>");
   } else {
     const bool direct = h.tlist || h.n_direct > 0, generic = direct || h.n_generic > 0;
     name = std::string("wfk_sample<") + T + "," + cplx + "," + (h.tlist ? "true" : "false") + "," +
@@ -323,6 +324,7 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   a.has_last = p->h.has_last;
   a.lean_par = p->h.lean_par;
   a.lean_ops = p->h.lean_ops;
+  a.corr = p->h.n_corr > 0 ? 1 : 0;
   if (hip_stream) p->async_launch = true;
   std::string err;
   int rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.ns, p->h.lean,

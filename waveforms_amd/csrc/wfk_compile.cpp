@@ -16,8 +16,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "wfk.h"
@@ -95,6 +97,8 @@ struct FceGroup {
   int deg = 0, nterms = 0;
   bool imag = false;            // the group adds to the IMAGINARY part of the output
   bool envmul = false;          // pseudo-op: multiply the accumulators by the shared Gaussian envelope
+  bool corr = false;            // carrier needs the per-sample rounding correction (WFK_FCE_PACK bit 7)
+  double wm = 0, sm = 0;        // corr: the reference COS factor (w, shift) whose rounded phase fl(w*fl(x-shift)) is mimicked
 };
 
 struct BlockBuilder {
@@ -109,8 +113,21 @@ struct BlockBuilder {
 
 }  // namespace
 
+static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
+                        int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr);
+
 int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
                 int64_t n_tlist, HostPlan& H, std::string& err) {
+  // Carriers whose phase is sensitive to NumPy's grid rounding (far from t = 0) stay fused with a
+  // first-order per-sample correction, which only the lean kernel implements.  A plan that turns
+  // out not to be lean is compiled again with such carriers on the exact (libm) path.
+  int rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
+  if (rc == WFK_OK && H.n_corr > 0 && !H.lean) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
+  return rc;
+}
+
+static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
+                        int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr) {
   if (!P || (!grid && !tlist && n_tlist != 0)) { err = "null program or time axis"; return WFK_EINVAL; }
   if (P->n_channels < 0 || P->n_members < 0) { err = "negative counts"; return WFK_EINVAL; }
   TimeAxis ax{grid, tlist, grid ? grid->n : n_tlist};
@@ -251,6 +268,23 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   };
   auto rate_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {   // |d value / dt| <= rate
     return std::fabs(rate) * grid_jitter(s0, s1) <= WFK_JITTER_TOL;
+  };
+
+  // A carrier beyond that bound can still run fused.  Two things separate the reference from the
+  // ideal phasor there: (i) it evaluates AT NumPy's rounded grid time x_k, e_k = x_k - ideal_k
+  // (about an ulp of |t|), and (ii) its phase is the ROUNDED product fl(w * fl(x_k - shift)),
+  // rho_k = that minus the exact product (up to half an ulp of the phase: 2e-9 rad at 3e7 rad).
+  // Both are reproduced per sample, to first order: cos(th + d) = cos th - d sin th with
+  // d_k = W e_k + rho_k, rho_k recomputed for ONE reference COS factor per group (w_m, s_m): the
+  // factor of the group's heaviest term with the largest phase.  Terms whose own factor differs
+  // may join only if their weight times the phase noise stays inside the budget; what is left
+  // after the correction is d^2 / 2.  (fl(x - s_m) is not exact when the carrier is referenced to
+  // t = 0, as mixing()'s is: what the subtraction rounds away is recovered with a TwoSum.)
+  const char* nocorr_env = std::getenv("WFK_DISABLE_CORR");
+  const bool corr_enabled = allow_corr && !(nocorr_env && nocorr_env[0] == '1');
+  auto corr_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {
+    const double x = std::fabs(rate) * grid_jitter(s0, s1);
+    return corr_enabled && std::isfinite(x) && 2.0 * x * x <= 1e-11;   // (d <= ~2 W e)
   };
 
   // ---- factor record emission -------------------------------------------------
@@ -418,6 +452,9 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     double slin = 0, sigma = 0, sg = 0;
     double first_cos_shift = 0;
     struct Car { long double c, W, Psi; };   // c * cos(W t' - Psi),  t' = t - tshift
+    struct CosF { double w, sh, thmax; };    // reference COS factors of the term (|w|, shift, largest |phase|)
+    std::vector<CosF> cosf;
+    bool has_drag = false;
     const long double PI = 3.141592653589793238462643383279502884L;
     std::vector<Car> cars;                   // empty: no carrier factor seen yet
     // multiply the running carrier sum by another sum of carriers:
@@ -455,12 +492,15 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           has_env = true; sigma = a[0]; sg = sh;
           break;
         }
-        case WFK_COS:
+        case WFK_COS: {
           if (pw != 1.0 || !std::isfinite(a[0]) || !std::isfinite(sh)) return false;
           if (ncos == 0) first_cos_shift = sh;
           ++ncos;
           if (!times({{1.0L, (long double)a[0], (long double)a[0] * sh}})) return false;
+          const double ua = (ax.at(s0) - tshift) - sh, ub = (ax.at(s1 - 1) - tshift) - sh;
+          cosf.push_back({std::fabs(a[0]), sh, std::fabs(a[0]) * std::max(std::fabs(ua), std::fabs(ub))});
           break;
+        }
         case WFK_DRAG: {
           // sin^2(o tau) cos(wt) + Oy sin(wt),  tau = u - t0,  Oy = -b o sin(2 o tau)
           //   = cos(wt)/2 + (-1/4 + b o/2) cos(wt + 2 o tau) + (-1/4 - b o/2) cos(wt - 2 o tau)
@@ -476,6 +516,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
           long double bo = 0.0L;
           if (!std::isnan(bf) && bf - delta != 0.0) bo = o / (2 * PI * ((long double)bf - delta));
           ncos += 2;   // reference shift is derived from Psi/W
+          has_drag = true;
           if (!times({{0.5L, W, Psi0},
                       {-0.25L + bo / 2, W + Om, Psi0 + Psi1},
                       {-0.25L - bo / 2, W - Om, Psi0 - Psi1}}))
@@ -491,8 +532,28 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     const double cs[1] = {first_cos_shift};
     // stage the contributions; commit only if every carrier finds/creates a group
     std::vector<FceGroup> staged = groups;
+    bool any_corr = false;
     for (const Car& q : cars)
-      if (!rate_safe((double)q.W, s0, s1)) return false;
+      if (!rate_safe((double)q.W, s0, s1)) {
+        if (!corr_safe((double)q.W, s0, s1)) return false;
+        any_corr = true;
+      }
+    // the term's weight and the reference factor whose rounding it mimics (see corr_safe)
+    double wm = 0, sm = 0, weight = 0;
+    if (any_corr) {
+      if (has_drag || cosf.empty()) return false;      // (the DRAG primitive rounds its phase differently)
+      size_t im = 0;
+      for (size_t i = 1; i < cosf.size(); ++i)
+        if (cosf[i].thmax > cosf[im].thmax) im = i;
+      wm = cosf[im].w; sm = cosf[im].sh;
+      weight = std::fabs(P->tm_amp_re[k]) + std::fabs(P->tm_amp_im[k]);
+      if (has_lin) {
+        const double ua = (ax.at(s0) - tshift) - slin, ub = (ax.at(s1 - 1) - tshift) - slin;
+        weight *= std::pow(std::max(std::fabs(ua), std::fabs(ub)), p);
+      }
+      for (size_t i = 0; i < cosf.size(); ++i)         // the other factors' own phase noise must not matter
+        if (i != im && 2.3e-16 * cosf[i].thmax * weight > WFK_JITTER_TOL) return false;
+    }
     for (int part = 0; part < 2; ++part) {
     const long double amp_part = part == 0 ? (long double)P->tm_amp_re[k] : (long double)P->tm_amp_im[k];
     if (amp_part == 0.0L) continue;                 // nothing in this part
@@ -504,16 +565,37 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       // (a sum/difference frequency is rounded to double: relative error <= 2^-53, the
       //  same class as the reference's own rounding of w*t)
       FceGroup* G = nullptr;
+      double thm = 0;
+      for (const CosF& cf : cosf) thm = std::max(thm, cf.thmax);
+      const bool heavy = 2.3e-16 * thm * weight > WFK_JITTER_TOL;   // its own phase rounding must be mimicked
       for (FceGroup& g : staged)
         if (g.W == W && g.imag == imag && g.has_env == has_env &&
-            (!has_env || (g.sigma == sigma && g.sg == sg))) { G = &g; break; }
+            (!has_env || (g.sigma == sigma && g.sg == sg))) {
+          // a corrected group mimics ONE reference factor: a heavy term with another factor founds
+          // its own group (same carrier, own op) instead of joining
+          if (any_corr && heavy && (g.wm != wm || g.sm != sm)) continue;
+          G = &g;
+          break;
+        }
       if (!G) {
         staged.emplace_back();
         G = &staged.back();
         G->W = W; G->has_env = has_env; G->sigma = sigma; G->sg = sg; G->env32 = env32;
         G->imag = imag;
+        G->corr = W != 0.0 && !rate_safe(W, s0, s1);
+        G->wm = wm; G->sm = sm;
         G->sref = W == 0.0 ? 0.0 : (ncos == 1 ? cs[0] : (double)(q.Psi / q.W));
         G->psi_ref = (long double)W * G->sref;
+        if (G->corr && ncos != 1) {
+          // A sum / difference frequency is rounded to double: (W_exact - W) * (x - s_ref) must stay
+          // small, so a corrected carrier takes its reference time INSIDE the piece (with s_ref =
+          // Psi / W next to t = 0 the rounding of W is multiplied by |x|: 5e-9 rad at 100 s)
+          const double mid = 0.5 * (ax.at(s0) + ax.at(s1 - 1)) - tshift;
+          if (std::isfinite(mid)) {
+            G->sref = mid;
+            G->psi_ref = q.W * (long double)mid;       // q.W: the exact sum (long double)
+          }
+        }
       }
       if (has_env && !env32) G->env32 = false;
       long double ca, cb;
@@ -555,7 +637,13 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     double rec[WFK_FCE_REC] = {0};
     long double A0 = G.A[0], B0 = G.B[0];
     double sref = G.sref;
-    if (G.deg == 0 && G.W != 0.0) {
+    int deg = G.deg;
+    if (G.deg == 0 && G.W != 0.0 && G.corr) {
+      // (corrected carriers keep A and B: the folded shift s_ref + phi/W would be ROUNDED to a
+      //  double next to |s_ref| -- half an ulp of a time 100 s from the origin is 7e-15 s, 3e-9 rad
+      //  under a 60 kHz carrier.  The degree-0 loop has no B term: such an op runs as degree 1.)
+      if (B0 != 0.0L) deg = 1;
+    } else if (G.deg == 0 && G.W != 0.0) {
       // A cos(th) + B sin(th) = R cos(th - phi): fold B into the reference shift
       long double R = hypotl(A0, B0), phi = atan2l(B0, A0);
       sref = (double)((long double)G.sref + phi / (long double)G.W);
@@ -565,12 +653,15 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     rec[WFK_FCE_W] = G.W;
     rec[WFK_FCE_SREF] = sref;
     rec[WFK_FCE_SLIN] = G.has_lin ? G.slin : 0.0;
-    rec[WFK_FCE_DEG] = (double)WFK_FCE_PACK(G.deg, G.W != 0.0 ? 1 : 0, G.imag ? 1 : 0,
-                                            G.envmul ? 3 : (G.has_env ? 1 : 0), G.env32 ? 1 : 0);
+    rec[WFK_FCE_DEG] = (double)(WFK_FCE_PACK(deg, G.W != 0.0 ? 1 : 0, G.imag ? 1 : 0,
+                                             G.envmul ? 3 : (G.has_env ? 1 : 0), G.env32 ? 1 : 0) |
+                                (G.corr ? 128 : 0));
+    if (G.corr) ++H.n_corr;
     rec[WFK_FCE_A] = (double)A0;
     rec[WFK_FCE_B] = (double)B0;
     for (int i = 1; i < 4; ++i) { rec[WFK_FCE_A + i] = (double)G.A[i]; rec[WFK_FCE_B + i] = (double)G.B[i]; }
-    rec[WFK_FCE_ENV] = G.envmul ? 3.0 : (G.has_env ? 1.0 : 0.0);
+    rec[WFK_FCE_WM] = G.wm;     // (slots 13 / 21 carried redundant copies of the packed word before)
+    rec[WFK_FCE_SM] = G.sm;
     if (G.has_env) {
       double Hh = dstride / G.sigma;
       rec[WFK_FCE_SIGMA] = G.sigma; rec[WFK_FCE_SG] = G.sg;
@@ -578,7 +669,6 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
       rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
     }
     rec[WFK_FCE_D] = dstride;
-    rec[WFK_FCE_CARRIER] = (G.W != 0.0 ? 1.0 : 0.0) + (G.imag ? 2.0 : 0.0);   // bit 0 carrier, bit 1 imaginary part
     size_t at = B.body.size();
     B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
     B.fce_ats.push_back(at);
@@ -635,12 +725,35 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
         // pass 1: fuse eligible terms into carrier-envelope groups
         std::vector<FceGroup> groups;
         std::vector<int32_t> generic;
+        std::vector<int32_t> order;
         for (int32_t p : live)
-          for (int32_t k = P->pc_term_off[p]; k < P->pc_term_off[p + 1]; ++k) {
-            if (P->tm_amp_im[k] != 0.0) H.channel_complex[c] = 1;
-            if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
-            else generic.push_back(k);
+          for (int32_t k = P->pc_term_off[p]; k < P->pc_term_off[p + 1]; ++k) order.push_back(k);
+        if (can_fuse && corr_enabled) {
+          // where a carrier needs the rounding correction the HEAVIEST term must found the group
+          // (its COS factor is the one mimicked): visit the terms by descending amplitude there
+          bool any = false;
+          for (int32_t k : order)
+            for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1] && !any; ++f)
+              any = P->fc_type[f] == WFK_COS && !rate_safe(P->pool[P->fc_arg_off[f]], s0, s1);
+          if (any) {
+            auto weight_of = [&](int32_t k) {   // |amp| * max |LINEAR factors| over the piece
+              double wgt = std::hypot(P->tm_amp_re[k], P->tm_amp_im[k]);
+              for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
+                if (P->fc_type[f] == WFK_LINEAR) {
+                  const double ua = (ax.at(s0) - C.tshift) - P->fc_shift[f], ub = (ax.at(s1 - 1) - C.tshift) - P->fc_shift[f];
+                  wgt *= std::pow(std::max(std::fabs(ua), std::fabs(ub)), P->fc_power[f]);
+                }
+              return wgt;
+            };
+            std::stable_sort(order.begin(), order.end(),
+                             [&](int32_t x, int32_t y) { return weight_of(x) > weight_of(y); });
           }
+        }
+        for (int32_t k : order) {
+          if (P->tm_amp_im[k] != 0.0) H.channel_complex[c] = 1;
+          if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
+          else generic.push_back(k);
+        }
         // When every carrier of the piece sits under the SAME Gaussian (a frequency-multiplexed
         // pulse), the envelope is factored out: the ops run without envelope and one closing
         // pseudo-op multiplies the accumulators by it -- 2 instead of 5 FMAs per sample and tone.
@@ -732,4 +845,126 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   if (H.pool.empty()) H.pool.push_back(0.0);
   if (H.params.empty()) H.params.push_back(0.0);
   return WFK_OK;
+}
+
+
+// ---- uniform-grid detection -----------------------------------------------------------------
+// Waveform.__call__(x) takes any sorted array (reference waveform.py:529-563), but scripts
+// almost always pass np.linspace / np.arange output.  If x is BIT-IDENTICAL to the grid formula
+// t[i] = fl(fl(i*step) + t0) (optionally with the last element overridden, np.linspace
+// endpoint=True) the plan can be compiled in grid mode -- fused ops instead of one libm call per
+// factor and sample, no upload of x -- and the device regenerates exactly the caller's times.
+// The check is exact (every element is compared); anything else stays in tlist mode.
+namespace {
+
+struct GridProbe {
+  const double* t;
+  int64_t n;
+  double t0;
+  // (this file is built with -ffp-contract=off: the product rounds before the sum, as NumPy's does)
+  double at(int64_t i, double step) const { return (double)i * step + t0; }
+  // first index in [a, b) where the formula differs from t, or -1; *sign = formula - t there
+  int64_t first_mismatch(double step, int64_t a, int64_t b, int* sign) const {
+    for (int64_t c = a; c < b; c += 1024) {       // branch-free blocks (vectorisable), then locate
+      const int64_t e = std::min(b, c + 1024);
+      int bad = 0;
+      const double dc = (double)c;                // c + k is exact in double (indices < 2^53)
+      const double* tc = t + c;
+      const int len = (int)(e - c);
+      for (int k = 0; k < len; ++k) bad |= ((dc + (double)k) * step + t0) != tc[k];
+      if (!bad) continue;
+      for (int64_t i = c; i < e; ++i) {
+        const double g = at(i, step);
+        if (g != t[i]) {
+          if (sign) *sign = g < t[i] ? -1 : 1;   // (a NaN in t lands in +1: never bracketed)
+          return i;
+        }
+      }
+    }
+    return -1;
+  }
+  int64_t verify(double step, int64_t count, int* sign) const {
+    if (count < (int64_t(1) << 20)) return first_mismatch(step, 0, count, sign);
+    constexpr int nt = 8;
+    std::atomic<int64_t> worst(INT64_MAX);
+    int signs[nt] = {0};
+    int64_t at_[nt];
+    for (int k = 0; k < nt; ++k) at_[k] = -1;
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; ++k)
+      th.emplace_back([&, k] {
+        const int64_t a = count * k / nt, b = count * (k + 1) / nt;
+        // blocks of 64k so that a thread stops early once an earlier mismatch is known
+        for (int64_t s0 = a; s0 < b && s0 < worst.load(std::memory_order_relaxed); s0 += 65536) {
+          const int64_t m = first_mismatch(step, s0, std::min(b, s0 + 65536), &signs[k]);
+          if (m >= 0) {
+            at_[k] = m;
+            int64_t w = worst.load();
+            while (m < w && !worst.compare_exchange_weak(w, m)) {}
+            break;
+          }
+        }
+      });
+    for (auto& x : th) x.join();
+    for (int k = 0; k < nt; ++k)
+      if (at_[k] >= 0) { if (sign) *sign = signs[k]; return at_[k]; }   // lowest thread = lowest index
+    return -1;
+  }
+};
+
+}  // namespace
+
+extern "C" int wfk_grid_detect(const double* t, int64_t n, wfk_grid* out) {
+  if (!t || !out || n < 16) return 0;
+  GridProbe P{t, n, t[0]};
+  if (!(t[n - 1] > t[0]) || !std::isfinite(t[0]) || !std::isfinite(t[n - 1])) return 0;
+  auto accept = [&](double step, int has_last) {
+    out->t0 = t[0]; out->step = step; out->n = n; out->has_last = has_last;
+    out->last = has_last ? t[n - 1] : 0.0;
+    return 1;
+  };
+  // np.linspace(a, b, n) (endpoint=True): step = (b - a) / (n - 1), last element := b
+  {
+    const double step = (t[n - 1] - t[0]) / (double)(n - 1);
+    if (step > 0 && P.first_mismatch(step, 1, 16, nullptr) < 0 && P.verify(step, n - 1, nullptr) < 0)
+      return accept(step, 0 + 1);
+  }
+  // np.arange(start, stop, d): t[1] - t[0] is the element step itself
+  {
+    const double step = t[1] - t[0];
+    if (step > 0 && P.first_mismatch(step, 1, 16, nullptr) < 0 && P.verify(step, n, nullptr) < 0)
+      return accept(step, 0);
+  }
+  // np.linspace(..., endpoint=False) and anything else of the same form: the step is not one of
+  // the two above, but fl(fl(i*s) + t0) is monotone in s, so it is found by bisection over the
+  // doubles between two brackets, on a subset of indices that grows with every counter-example.
+  std::vector<int64_t> probe;
+  for (int64_t i = n - 1; i >= 1; i = i * 7 / 8 - (i < 8 ? 1 : 0)) probe.push_back(i);
+  auto classify = [&](double s) {   // -1: too small, +1: too big, 0: fits the subset, 2: contradiction
+    bool lo = false, hi = false;
+    for (int64_t i : probe) {
+      const double g = P.at(i, s);
+      lo = lo || g < t[i];
+      hi = hi || g > t[i];
+    }
+    return lo && hi ? 2 : (lo ? -1 : (hi ? 1 : 0));
+  };
+  const double est = (t[n - 1] - t[0]) / (double)(n - 1);
+  const double slack = 8.0 * (std::fabs(t[0]) + std::fabs(t[n - 1])) * 2.3e-16 / (double)(n - 1) + est * 1e-15;
+  double lo = est - slack, hi = est + slack;
+  if (!(lo > 0) || classify(lo) != -1 || classify(hi) != 1) return 0;
+  for (int iter = 0; iter < 400; ++iter) {
+    const double mid = lo + (hi - lo) / 2;
+    if (!(mid > lo && mid < hi)) return 0;            // adjacent doubles: no step reproduces x
+    const int c = classify(mid);
+    if (c == 2) return 0;
+    if (c < 0) { lo = mid; continue; }
+    if (c > 0) { hi = mid; continue; }
+    int sign = 0;
+    const int64_t bad = P.verify(mid, n, &sign);
+    if (bad < 0) return accept(mid, 0);
+    probe.push_back(bad);                             // the counter-example narrows the bracket
+    if (sign < 0) lo = mid; else hi = mid;
+  }
+  return 0;
 }

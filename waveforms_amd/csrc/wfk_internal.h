@@ -47,11 +47,12 @@
 #define WFK_FCE_SREF 2
 #define WFK_FCE_SLIN 3
 #define WFK_FCE_DEG 4         // PACKED op word (one LDS read instead of five dependent ones per op and tile):
-                              // deg (bits 0-1) | carrier << 2 | imag << 3 | env << 4 (2 bits) | f32ok << 6 | table offset << 8
+                              // deg (bits 0-1) | carrier << 2 | imag << 3 | env << 4 (2 bits) | f32ok << 6 |
+                              // corr << 7 (per-sample grid-rounding correction of the carrier) | table offset << 8
 #define WFK_FCE_PACK(deg, carrier, imag, env, f32ok) ((deg) | ((carrier) << 2) | ((imag) << 3) | ((env) << 4) | ((f32ok) << 6))
 #define WFK_FCE_A 5           // A0..A3
 #define WFK_FCE_B 9           // B0..B3
-#define WFK_FCE_ENV 13        // 0 none, 1 gaussian, 3: pseudo-op, multiply the accumulators by the gaussian
+#define WFK_FCE_WM 13         // corr ops: |w| of the reference COS factor whose rounded phase is mimicked
 #define WFK_FCE_SIGMA 14
 #define WFK_FCE_SG 15
 #define WFK_FCE_H 16
@@ -59,7 +60,7 @@
 #define WFK_FCE_F32OK 18
 #define WFK_FCE_TAB 19
 #define WFK_FCE_D 20
-#define WFK_FCE_CARRIER 21    // bit 0: W != 0 (phasor needed); bit 1: the op adds to the IMAGINARY part
+#define WFK_FCE_SM 21         // corr ops: shift of that factor
 
 // factor evaluation modes (record slot 0).  1..15 = direct evaluation of that
 // primitive with device libm; >=100 = uniform-grid fast paths (power == 1).
@@ -120,6 +121,7 @@ struct KArgs {
   double t0, step, last;
   int32_t has_last, pad;
   int32_t lean_par, lean_ops;  // lean kernel: doubles of parameter block / ops of state to reserve in LDS
+  int32_t corr, pad2;          // plan holds carriers that need the grid-rounding correction (lean kernel variant)
 };
 
 #ifdef __cplusplus
@@ -143,6 +145,7 @@ struct HostPlan {
   std::vector<std::vector<int64_t>> member_idx;
   std::vector<uint8_t> channel_complex;
   int32_t n_fast = 0, n_direct = 0, n_fused = 0, n_generic = 0;
+  int32_t n_corr = 0;          // fused ops carrying the grid-rounding correction
   bool lean = false;           // wave-per-workgroup fused kernel (see WFK_LEAN_*)
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most ops of a piece
 };
@@ -155,4 +158,5 @@ int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tli
 // kernels (wfk_kernels.hip)
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns,
                        bool lean, bool generic, bool direct, void* stream, std::string& err);
+// (a.corr selects the lean kernel variant with the per-sample grid-rounding correction)
 #endif

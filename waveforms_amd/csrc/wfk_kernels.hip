@@ -99,6 +99,10 @@ __device__ __forceinline__ double grid_time(const KArgs& a, int64_t j) {
 // theta/pi as an exact two-term product (1/pi split hi+lo), reduced with rint, then
 // sincospi on |r| <= 1/2.  Phase error ~1 ulp of r, i.e. as accurate as libm.
 __device__ __attribute__((noinline)) double2 sincos_phase(double theta) {
+  // contraction OFF: under -ffp-contract=fast `xh - n` below becomes fma(theta, IPI_HI, -n), which
+  // already contains the low half of the product that `xl` adds again -- a phase error of up to
+  // half an ulp of theta/pi (3e-9 rad at theta = 3e7)
+#pragma clang fp contract(off)
   const double IPI_HI = 0.31830988618379069, IPI_LO = -1.9678676675182486e-17;
   const double xh = theta * IPI_HI;
   const double xl = fma(theta, IPI_HI, -xh) + theta * IPI_LO;
@@ -503,14 +507,17 @@ struct FceSeeds { double c, s, g, r; };
 // All libm work of one fused op in ONE out-of-line routine: the three polynomial chains
 // (sincospi, exp, exp) are independent, so the scheduler interleaves them, and their
 // constants are not live across the sampling loops.
-__device__ __attribute__((noinline)) FceSeeds fce_seeds(double theta, double ea, double eb,
-                                                        int carrier, int env) {
+__device__ __attribute__((noinline)) FceSeeds fce_seeds(double theta, double theta_lo, double ea,
+                                                        double eb, int carrier, int env) {
+#pragma clang fp contract(off)   // see sincos_phase(): the explicit fma()s below must stay the only ones
   FceSeeds o;
   o.c = 1.0; o.s = 0.0; o.g = 1.0; o.r = 1.0;
   if (carrier) {
+    // phase = theta + theta_lo (the low word is the rounding error of the product W * (x - s_ref),
+    // passed by the kernels that correct per sample and therefore need the EXACT seed phase)
     const double IPI_HI = 0.31830988618379069, IPI_LO = -1.9678676675182486e-17;
     const double xh = theta * IPI_HI;
-    const double xl = fma(theta, IPI_HI, -xh) + theta * IPI_LO;
+    const double xl = fma(theta, IPI_HI, -xh) + fma(theta, IPI_LO, theta_lo * IPI_HI);
     const double n = rint(xh);
     double ss, cc;
     sincospi((xh - n) + xl, &ss, &cc);
@@ -525,17 +532,57 @@ __device__ __attribute__((noinline)) FceSeeds fce_seeds(double theta, double ea,
   return o;
 }
 
+// Rounding correction (CORR): the phasor of sample k stands for the IDEAL uniform time
+// x_ref + (kbase + k) * D and the exact phase there; the reference evaluates at NumPy's rounded
+// grid value x_k (e_k = x_k - ideal_k, about one ulp of |t|) and rounds its phase,
+// fl(w * fl(x_k - shift)) (rho_k, up to half an ulp of the phase).  Far from t = 0 a fast carrier
+// makes both visible, so the carrier is corrected per sample to first order:
+// cos(th + d) = cos th - d sin th, d = W e_k + rho_k (wfk_compile.cpp: corr_safe).
+struct CorrCtx {
+  double dj0;      // this lane's first sample index of the tile, as a double (exact)
+  double xref;     // time (minus tshift) at which the op state was seeded exactly
+  double step, t0, tshift, last, dlast;   // grid (dlast = n - 1 when the last sample is overridden, else -1)
+  int kbase;       // lane-strides (of 64 samples) between the seed sample and this tile's first
+};
+
+// phase deviation of sample K from the ideal phasor: W * e_K + rho_K (see CorrCtx)
+template <int K>
+__device__ __forceinline__ double corr_delta(const CorrCtx& cc, double dj0, double D, double W,
+                                             double wm, double sm) {
+#pragma clang fp contract(off)
+  const double dj = dj0 + (double)(64 * K);      // exact integer arithmetic in double
+  const double m = dj * cc.step;                 // t[j] = fl(fl(j*step) + t0): two roundings
+  double t = m + cc.t0;
+  if (cc.dlast >= 0.0 && dj == cc.dlast) t = cc.last;
+  if (cc.tshift != 0.0) t = t - cc.tshift;
+  const double eps = (t - cc.xref) - (double)(cc.kbase + K) * D;
+  const double um = t - sm;                      // the reference's fl(x - shift) ...
+  const double bb = um - t;
+  const double eu = (t - (um - bb)) + (-sm - bb);   // ... and what it rounded away (TwoSum: x - shift = um + eu)
+  const double pm = wm * um;                     // the reference's rounded phase fl(w * fl(x - shift))
+  const double rho = -__builtin_fma(wm, um, -pm);   // pm - wm*um, exactly
+  return __builtin_fma(W, eps, __builtin_fma(-wm, eu, rho));
+}
+
 // ENV: 0 none, 1 Gaussian with state in T, 2 Gaussian with state in double (float
 // output whose state would leave float's exponent range).  DEG: 0, 1, or 3 (= 2..3).
-template <typename T, int NS, int DEG, bool CARRIER, int ENV>
+template <typename T, int NS, int DEG, bool CARRIER, int ENV, bool CORR = false>
 __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, FceSeeds& sd,
-                                         double u0, T (&acc)[NS]) {  // u0 by value: made opaque below
+                                         double u0, T (&acc)[NS],   // u0 by value: made opaque below
+                                         const CorrCtx* cc = nullptr) {
   using S = typename std::conditional<ENV == 2, double, T>::type;
   constexpr int SB = 4;  // sub-batch: bounds the live LDS-table / temporary registers
   // The specialised loops share sub-expressions (u_k, the table loads); without this
   // opaque barrier GVN hoists all of them above the variant dispatch and every variant
   // pays ~100 live VGPRs for it.
   asm volatile("" : "+v"(u0) : : "memory");
+  double dj0 = 0.0, wm = 0.0, sm = 0.0;
+  if constexpr (CORR) {
+    wm = r[WFK_FCE_WM];
+    sm = r[WFK_FCE_SM];
+    dj0 = cc->dj0;    // opaque per variant as well: the per-sample times are the same in every CORR
+    asm volatile("" : "+v"(dj0));   // variant, and hoisted above the dispatch they would stay live (32 VGPRs)
+  }
   const T c0 = (T)sd.c, s0 = (T)sd.s;
   const T A0 = (T)r[WFK_FCE_A], A1 = (T)r[WFK_FCE_A + 1], B0 = (T)r[WFK_FCE_B],
           B1 = (T)r[WFK_FCE_B + 1];
@@ -564,7 +611,14 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
       if (DEG == 0) {
         if (CARRIER) {
           const double2 cs = tb[kb & 1][kk];
-          val = ac * (T)cs.x - as * (T)cs.y;
+          if constexpr (CORR) {
+            const T we = (T)corr_delta<k>(*cc, dj0, D, r[WFK_FCE_W], wm, sm);
+            const T ck = c0 * (T)cs.x - s0 * (T)cs.y;
+            const T sk = s0 * (T)cs.x + c0 * (T)cs.y;
+            val = A0 * (ck - we * sk);
+          } else {
+            val = ac * (T)cs.x - as * (T)cs.y;
+          }
         } else {
           val = A0;
         }
@@ -580,8 +634,14 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
         u += Dt;
         if (CARRIER) {
           const double2 cs = tb[kb & 1][kk];
-          const T ck = c0 * (T)cs.x - s0 * (T)cs.y;
-          const T sk = s0 * (T)cs.x + c0 * (T)cs.y;
+          T ck = c0 * (T)cs.x - s0 * (T)cs.y;
+          T sk = s0 * (T)cs.x + c0 * (T)cs.y;
+          if constexpr (CORR) {
+            const T we = (T)corr_delta<k>(*cc, dj0, D, r[WFK_FCE_W], wm, sm);
+            const T c1 = ck - we * sk;
+            sk = sk + we * ck;
+            ck = c1;
+          }
           val = pa * ck + pb * sk;
         } else {
           val = pa;
@@ -612,33 +672,51 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
   }
 }
 
-template <typename T, int NS, int DEG, bool CARRIER>
+template <typename T, int NS, int DEG, bool CARRIER, bool CORR = false>
 __device__ __forceinline__ void fce_env(const double2* tab, const double* r, FceSeeds& sd,
-                                        double u0, int env, T (&acc)[NS]) {
-  if (env == 0) fce_loop<T, NS, DEG, CARRIER, 0>(tab, r, sd, u0, acc);
-  else if (sizeof(T) == 8 || env == 1) fce_loop<T, NS, DEG, CARRIER, 1>(tab, r, sd, u0, acc);
-  else fce_loop<T, NS, DEG, CARRIER, 2>(tab, r, sd, u0, acc);
+                                        double u0, int env, T (&acc)[NS], const CorrCtx* cc = nullptr) {
+  if (env == 0) fce_loop<T, NS, DEG, CARRIER, 0, CORR>(tab, r, sd, u0, acc, cc);
+  else if (sizeof(T) == 8 || env == 1) fce_loop<T, NS, DEG, CARRIER, 1, CORR>(tab, r, sd, u0, acc, cc);
+  else fce_loop<T, NS, DEG, CARRIER, 2>(tab, r, sd, u0, acc);   // (float output: CORR never set)
 }
 
 // exact per-lane seeds of one fused op at sample time x (already minus tshift)
 // `fl`: the op's packed word (WFK_FCE_DEG), read once by the caller
+template <bool EXACT = false>
 __device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x, int fl) {
   const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
-  return fce_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), -(v * v), -Hh * (2.0 * v + Hh),
-                   (fl >> 2) & 1, (fl >> 4) & 3);
+  const double sref = r[WFK_FCE_SREF], W = r[WFK_FCE_W];
+  const double d = x - sref;
+  const double th = W * d;
+  double lo = 0.0;
+  if (EXACT) {   // W * (x - s_ref) to twice the working precision: TwoSum of the difference, TwoProd
+    const double bb = d - x;
+    const double ed = (x - (d - bb)) + (-sref - bb);
+    lo = fma(W, ed, fma(W, d, -th));
+  }
+  return fce_seeds(th, lo, -(v * v), -Hh * (2.0 * v + Hh), (fl >> 2) & 1, (fl >> 4) & 3);
 }
 
 // run one fused op over the wave tile from the given state; `wide_env`: keep the
 // Gaussian state in double even for float output
-template <typename T, int NS>
+template <typename T, int NS, bool CORR = false>
 __device__ __forceinline__ void fce_eval(const double* blk, const double* r, FceSeeds& sd,
-                                         double x, bool wide_env, T (&acc)[NS], int fl) {
+                                         double x, bool wide_env, T (&acc)[NS], int fl,
+                                         const CorrCtx* cc = nullptr) {
   const int deg = fl & 3;
   const int carrier = (fl >> 2) & 1;
   int env = (fl >> 4) & 3;
   if (env && sizeof(T) == 4 && (wide_env || ((fl >> 6) & 1) == 0)) env = 2;
   const double2* tab = reinterpret_cast<const double2*>(blk + (fl >> 8));
   const double u0 = x - r[WFK_FCE_SLIN];
+  if constexpr (CORR && sizeof(T) == 8) {
+    if (carrier && ((fl >> 7) & 1)) {   // this carrier's phase feels the grid rounding
+      if (deg == 0) fce_env<T, NS, 0, true, true>(tab, r, sd, u0, env, acc, cc);
+      else if (deg == 1) fce_env<T, NS, 1, true, true>(tab, r, sd, u0, env, acc, cc);
+      else fce_env<T, NS, 3, true, true>(tab, r, sd, u0, env, acc, cc);
+      return;
+    }
+  }
   if (carrier) {
     if (deg == 0) fce_env<T, NS, 0, true>(tab, r, sd, u0, env, acc);
     else if (deg == 1) fce_env<T, NS, 1, true>(tab, r, sd, u0, env, acc);
@@ -769,7 +847,7 @@ __device__ __forceinline__ int64_t xcd_chunk(const KArgs& a) {
 // costs 4 FMAs per op per tile; exact libm seeds are taken when a piece is entered and
 // every WFK_LEAN_RESEED tiles, in a phase where no accumulator is live (so the libm call
 // does not inflate the kernel's register allocation).  No barriers between waves at all.
-template <typename T, bool CPLX, int NS>
+template <typename T, bool CPLX, int NS, bool CORR>
 #ifndef WFK_LEAN_WAVES
 #define WFK_LEAN_WAVES 3   // occupancy target (waves per SIMD) for the register allocator
 #endif
@@ -777,7 +855,9 @@ template <typename T, bool CPLX, int NS>
 #define WFK_LEAN_WAVES_F32 4   // fp32: 120 VGPRs, 10 KB LDS per wave -> 4 waves per SIMD (latency-bound kernel)
 #endif
 // (complex outputs carry two accumulator sets: one wave per SIMD fewer, no spills)
-__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? WFK_LEAN_WAVES_F32 : WFK_LEAN_WAVES) - (CPLX ? 1 : 0))
+// (the CORR variant recomputes every sample's exact grid time next to the op: one wave fewer too)
+__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? WFK_LEAN_WAVES_F32 : WFK_LEAN_WAVES) - (CPLX ? 1 : 0) -
+                                          (CORR && sizeof(T) == 8 && !CPLX ? 1 : 0))
 wfk_sample_lean(const KArgs a) {
   // LDS is sized per plan (dynamic): the parameter block (a.lean_par doubles) followed by the
   // per-lane state of the plan's largest piece, (c, s, g, r) x 64 lanes per op.  Plans with up to
@@ -839,7 +919,7 @@ wfk_sample_lean(const KArgs a) {
           // seed phase: libm, nothing else live
           for (int op = 0; op < nops; ++op) {
             const double* srec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
-            const FceSeeds sd = fce_make_seeds(srec, x, uni((int)srec[WFK_FCE_DEG]));
+            const FceSeeds sd = fce_make_seeds<CORR>(srec, x, uni((int)srec[WFK_FCE_DEG]));
             double* st = s_st + op * 256 + lane;
             st[0] = sd.c;
             st[64] = sd.s;
@@ -847,6 +927,18 @@ wfk_sample_lean(const KArgs a) {
             st[192] = sd.r;
           }
           since_seed = 0;
+        }
+        CorrCtx cc;
+        if constexpr (CORR) {
+          // the op state was seeded exactly `since_seed` tiles ago, at this lane's sample there
+          const int64_t js = j0 - (int64_t)since_seed * WT;
+          double xs = grid_time(a, js);
+          if (C.tshift != 0.0) xs = xs - C.tshift;
+          cc.dj0 = (double)j0;
+          cc.xref = xs;
+          cc.step = a.step; cc.t0 = a.t0; cc.tshift = C.tshift; cc.last = a.last;
+          cc.dlast = a.has_last ? (double)(a.n - 1) : -1.0;
+          cc.kbase = since_seed * NS;
         }
         for (int op = 0; op < nops; ++op) {
           FceSeeds sd;
@@ -862,9 +954,9 @@ wfk_sample_lean(const KArgs a) {
           if (((fl >> 4) & 3) == 3) {
             fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
           } else if (fl & 8) {
-            if constexpr (CPLX) fce_eval<T, NS>(s_par, rec, sd, x, true, acci, fl);
+            if constexpr (CPLX) fce_eval<T, NS, CORR>(s_par, rec, sd, x, true, acci, fl, &cc);
           } else {
-            fce_eval<T, NS>(s_par, rec, sd, x, true, acc, fl);
+            fce_eval<T, NS, CORR>(s_par, rec, sd, x, true, acc, fl, &cc);
           }
           st[0] = sd.c;
           st[64] = sd.s;
@@ -992,10 +1084,20 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
 template <typename T, bool CPLX, bool TLIST, int NS>
 int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generic, bool direct) {
   const dim3 g((unsigned)blocks), b(WFK_WG);
-  if (!TLIST && lean)
-    hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS>), g, dim3(64),
-                       (size_t)(a.lean_par + 256 * a.lean_ops) * sizeof(double), s, a);
-  else if (TLIST || direct)
+  if constexpr (!TLIST) {   // (the lean kernel exists for grid plans only)
+    if (lean) {
+      const size_t lds = (size_t)(a.lean_par + 256 * a.lean_ops) * sizeof(double);
+      if constexpr (sizeof(T) == 8) {
+        if (a.corr) {
+          hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, true>), g, dim3(64), lds, s, a);
+          return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+      }
+      hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false>), g, dim3(64), lds, s, a);
+      return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+  }
+  if (TLIST || direct)
     hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, true, true, NS>), g, b, 0, s, a);
   else if (generic)
     hipLaunchKernelGGL((wfk_sample<T, CPLX, false, true, false, NS>), g, b, 0, s, a);
