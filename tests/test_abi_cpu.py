@@ -155,3 +155,33 @@ def test_plain_c_consumer(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert 'abi_smoke' in r.stdout
+
+
+def test_grid_detection_is_exact():
+    """wfk_grid_detect: a host x is taken for a grid only if EVERY element equals the NumPy
+    formula fl(fl(i*step) + t0) (linspace with/without endpoint, arange); one ulp off anywhere,
+    NaN, unsorted or concatenated grids stay in tlist mode."""
+    rng = np.random.default_rng(8)
+    grids = [np.linspace(-1e-6, 9e-6, 10001), np.linspace(0, 3e-6, 250000, endpoint=False),
+             np.arange(-1e-6, 2e-6, 1e-9), np.arange(100000) * 0.5e-9,
+             np.linspace(1e-3, 1e-3 + 1e-5, 100000, endpoint=False),
+             np.linspace(-7.3e-3, -7.3e-3 + 1e-5, 300000, endpoint=False),
+             np.linspace(-121.88426793235047, -121.88402308516527, 1500, endpoint=False),
+             np.arange(3e5, dtype=np.float64)]
+    for _ in range(30):
+        a = rng.uniform(-1, 1) * 10.0**rng.uniform(-9, 2)
+        span = 10.0**rng.uniform(-9, 0)
+        grids.append(np.linspace(a, a + span, int(rng.integers(16, 50000)), endpoint=bool(rng.random() < 0.5)))
+        grids.append(np.arange(a, a + span, span / int(rng.integers(16, 50000))))
+    for t in grids:
+        g = _engine.detect_grid(t)
+        assert g is not None, (t[0], t[-1], len(t))
+        assert np.array_equal(_flatten.grid_values(g), t)
+        bad = t.copy()
+        k = int(rng.integers(1, len(t) - 1))
+        bad[k] = np.nextafter(bad[k], np.inf)
+        assert _engine.detect_grid(bad) is None
+    t = np.linspace(0, 1, 1000)
+    for bad in (np.sort(rng.uniform(0, 1, 1000)), np.concatenate([t[:500], t[500:] + 0.5]),
+                np.where(np.arange(1000) == 7, np.nan, t), t[::-1].copy(), t[:8], np.zeros(100)):
+        assert _engine.detect_grid(np.ascontiguousarray(bad)) is None
