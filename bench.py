@@ -325,13 +325,21 @@ def run_rank(args):
     chans = [make_channel(c) for c in range(min(channels, 32))] if rank == 0 else []
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     out = torch.empty((bs.n_channels, bs.n), dtype=tdt, device='cuda')
-    fir = None
+    fir = chain = None
     if name == 'c4':
-        from waveforms_amd.distortion import FirStage
-        fir = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
-        out2 = torch.empty_like(out)
+        # C4 = predistort(wav(t), ker): ONE kernel when the plan is fully fused (the FIR workgroups
+        # evaluate their own input windows), else sampler -> FIR
+        from waveforms_amd.distortion import FirStage, SampledFir
+        a0, b0 = sh.start, sh.stop
+        chain = SampledFir([make_channel(c) for c in range(a0, b0)], grid, wl.c4_kernel(), dtype)
+        if not chain.fused:
+            fir = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
+            out2 = torch.empty_like(out)
 
     def step():
+        if chain is not None and chain.fused:
+            chain.launch_torch(out)
+            return
         bs.launch_torch(out)
         if fir is not None:
             fir.apply_torch(out, out2)
@@ -371,7 +379,10 @@ def run_rank(args):
     ev_fir = []
     for a, b in ev:
         a.record()          # events on torch's current stream == the launch stream
-        bs.launch_torch(out)
+        if chain is not None and chain.fused:
+            chain.launch_torch(out)
+        else:
+            bs.launch_torch(out)
         b.record()
         if fir is not None:
             fir.apply_torch(out, out2)
@@ -394,6 +405,11 @@ def run_rank(args):
             'kernel': bs.plan.kernel_name(dtype),
             'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': algo_bytes,
             'timing': 'HIP events around every launch on the launch stream, mean over the timed steps'}
+    if chain is not None and chain.fused:
+        # fused chain: the samples never touch HBM; algorithmic traffic = the filtered output only
+        roof['kernel'] = 'fir_sampled<%s,12>' % ('double' if dtype == np.float64 else 'float')
+        roof['note'] = ('sampler fused into the FIR transform: algorithmic bytes = B_out per sample '
+                        '(SURVEY 8(d) "fused sampler->FIR: B_out only")')
     if fir is not None:
         # the FIR stage dominates this workload: report ITS roofline (16 B/sample: read+write)
         fir_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_fir]))
@@ -459,13 +475,21 @@ def run_rank(args):
         fst = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
         out2 = torch.empty_like(out)
         fir_ms = timed(lambda: fst.apply_torch(out, out2), 5, 2)
+        from waveforms_amd.distortion import SampledFir
+        chn = SampledFir([make_channel(c) for c in range(sh.start, sh.stop)], grid, wl.c4_kernel(), dtype)
+        chain_ms = timed(lambda: chn.launch_torch(out2), 5, 2)
         also['c4'] = {
-            'fir_kernel': 'fir_fused<double>', 'fir_kernel_ms': fir_ms,
-            'fir_frac': 2 * algo_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            'step_ms': kern_ms + fir_ms,
-            'msamples_per_s': bs.n_channels * bs.n / ((kern_ms + fir_ms) * 1e-3) / 1e6,
-            'note': 'C4 (BASELINE configs[3]) = sampler256 + 1024-tap FIR (LDS-FFT kernel); '
-                    'frac = 16 B/sample (read + write) / FIR kernel time / 8 TB/s'}
+            'kernel': 'fir_sampled<double,12>' if chn.fused else 'wfk_sample_lean + fir_fused',
+            'fused': chn.fused, 'step_ms': chain_ms,
+            'msamples_per_s': bs.n_channels * bs.n / (chain_ms * 1e-3) / 1e6,
+            'algorithmic_bytes_per_launch': algo_bytes,
+            'frac': algo_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'unfused': {'fir_kernel': 'fir_fused<double>', 'fir_kernel_ms': fir_ms,
+                        'fir_frac_16B_per_sample': 2 * algo_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        'step_ms': kern_ms + fir_ms},
+            'note': 'C4 (BASELINE configs[3]) = predistort(wav(t), ker 1024 taps): sampler fused into the '
+                    'LDS-FFT FIR kernel; frac = 8 B/sample (output only) / kernel time / 8 TB/s'}
+        chn.close()
         del out2
         fst.close()
         # BASELINE configs[1] and [2] in the same line (kernel time by HIP events, frac of 8 TB/s)

@@ -186,6 +186,23 @@ int wfk_fir_apply(wfk_fir_plan* plan, const void* in_dev, int64_t in_stride,
                   void* out_dev, int64_t out_stride, void* hip_stream);
 int wfk_fir_plan_destroy(wfk_fir_plan* plan);
 
+/* -- sampler -> FIR chain (BASELINE configs[3]) --------------------------------- */
+/* out = predistort(wav(t), ker=ker): Waveform.__call__ (waveforms/waveform.py:529-563) followed by
+ * the FIR branch of predistort (waveforms/distortion.py:329-337), for every channel of `prog` on
+ * `grid`.  When every piece of the program is fully fused (carrier-envelope ops only, no clip, real
+ * amplitudes) and the kernel fits one on-chip transform (K <= 1537) the FIR workgroups EVALUATE
+ * their input windows instead of loading them: the samples never touch HBM and the chain moves the
+ * 8 (4) B/sample of the filtered output only.  Otherwise the plan owns a workspace and runs
+ * sampler -> workspace -> FIR (wfk_chain_is_fused() == 0, wfk_chain_unfused_reason() says why).
+ * wfk_chain_launch() allocates nothing and does not synchronise.                              */
+typedef struct wfk_chain_plan wfk_chain_plan;
+int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const double* ker_host,
+                          int32_t K, int kind /* WFK_OUT_F64|F32 */, wfk_chain_plan** out);
+int wfk_chain_is_fused(const wfk_chain_plan* plan);
+const char* wfk_chain_unfused_reason(const wfk_chain_plan* plan);
+int wfk_chain_launch(wfk_chain_plan* plan, void* out_dev, int64_t out_stride, void* hip_stream);
+int wfk_chain_plan_destroy(wfk_chain_plan* plan);
+
 /* -- IIR stage ---------------------------------------- */
 /* y = cascade of direct-form-II-transposed sections along each row, i.e.
  *   scipy.signal.sosfilt (n_sections sections of order 2)  -- Waveform.sample(filters=),

@@ -21,6 +21,7 @@ Outputs
   tests/golden/design.npz         extractKernel / exp_decay_filter_old / factor_filter / stable_filter
   tests/golden/fuzz.npz           reference wav(t) for random scripts (+ fuzz_frontend.json: tolist())
   tests/golden/edges.npz          wav(x) on empty / single / off-support / non-uniform x
+  tests/golden/c4_full.npz        C4 rows 0 and 7 at the full 1e7 points: sampled + FIR-filtered subsets
   tests/golden/user.npz           scripts with Python-callable primitives (function(), function_lib=)
 """
 import json
@@ -80,6 +81,28 @@ def enc(v):
     return float(v)
 
 
+def make_c4_full(ref, gold):
+    """C4 at FULL length (1e7 points): rows 0 and 7 sampled and FIR-filtered by the reference
+    (one >= 3e7-point fftconvolve each); strided subset + the samples around every piece edge."""
+    from waveforms_amd import workloads as wl
+    ker = wl.c4_kernel()
+    t = wl.make_grid(wl.c2_grid())
+    full = {}
+    for c in (0, 7):
+        w = wl.sum_channel(ref, 100, 1000 + c)
+        y = w(t)
+        z = ref.distortion.predistort(y, ker=ker)
+        edges = np.searchsorted(t, w.bounds)
+        near = np.unique(np.clip((edges[:, None] + np.arange(-3, 4)[None, :]).ravel(), 0, len(t) - 1))
+        pick = np.unique(np.concatenate([np.arange(0, len(t), 9973), near,
+                                         np.arange(0, 3000), np.arange(len(t) - 3000, len(t))]))
+        full[f'{c}.pick'] = pick
+        full[f'{c}.y'] = y[pick]
+        full[f'{c}.fir'] = z[pick]
+        full[f'{c}.firsum'] = np.array([z.sum(), np.abs(z).sum(), np.abs(z).max()])
+    np.savez_compressed(os.path.join(gold, 'c4_full.npz'), **full)
+
+
 def main():
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -90,6 +113,9 @@ def main():
 
     gold = os.path.join(REPO, 'tests', 'golden')
     os.makedirs(gold, exist_ok=True)
+    if sys.argv[1:] == ['c4_full']:        # regenerate this fixture only
+        make_c4_full(ref, gold)
+        return
 
     # ---- filter-design helpers of distortion.py (host-side, no sampling) ----------
     import waveforms.distortion as rdist
@@ -223,6 +249,7 @@ def main():
         big[f'c4_{c}.fir'] = z[big[f'c4_{c}.pick']]
         big[f'c4_{c}.firsum'] = np.array([z.sum(), np.abs(z).sum()])
     np.savez_compressed(os.path.join(gold, 'big.npz'), **big)
+    make_c4_full(ref, gold)
 
     # ---- FIR vectors (reference distortion.py:323-337; untested upstream) ----
     fir = {}

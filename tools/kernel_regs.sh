@@ -5,9 +5,10 @@ set -e
 cd "$(dirname "$0")/../waveforms_amd/csrc"
 tmp=$(mktemp -d)
 B=/opt/rocm/lib/llvm/bin
-# the fat binary sits in the .hip_fatbin section of the shared object
-$B/llvm-objcopy --dump-section .hip_fatbin=$tmp/fat.bin ${WFK_LIB:-libwfk_hip.so}
-$B/clang-offload-bundler --unbundle --type=o --input=$tmp/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$tmp/k.co
+# every translation unit carries its own fat binary: walk the object files (WFK_OBJ: one of them)
+for o in ${WFK_OBJ:-_obj/*.o}; do
+  $B/llvm-objcopy --dump-section .hip_fatbin=$tmp/fat.bin $o 2>/dev/null || continue
+  $B/clang-offload-bundler --unbundle --type=o --input=$tmp/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$tmp/k.co 2>/dev/null || continue
 $B/llvm-readelf --notes $tmp/k.co | python3 -c "
 import sys, re, subprocess
 pat = sys.argv[1] if len(sys.argv) > 1 else ''
@@ -28,4 +29,5 @@ for r in rows:
     if pat in n:
         print('%-100s vgpr %3s agpr %3s sgpr %3s spill %s/%s lds %6s scratch %s' % (n[:100], r.get('vgpr_count'), r.get('agpr_count'), r.get('sgpr_count'), r.get('vgpr_spill_count'), r.get('sgpr_spill_count'), r.get('group_segment_fixed_size'), r.get('private_segment_fixed_size')))
 " "$1"
+done
 rm -rf $tmp

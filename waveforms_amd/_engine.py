@@ -74,6 +74,12 @@ def lib():
         l.wfk_fir_plan_create.argtypes = [VP, I32, I64, I32, C.c_int, P(VP)]
         l.wfk_fir_apply.argtypes = [VP, VP, I64, VP, I64, VP]
         l.wfk_fir_plan_destroy.argtypes = [VP]
+        l.wfk_chain_plan_create.argtypes = [P(wfk_program), P(wfk_grid), VP, I32, C.c_int, P(VP)]
+        l.wfk_chain_is_fused.argtypes = [VP]
+        l.wfk_chain_unfused_reason.argtypes = [VP]
+        l.wfk_chain_unfused_reason.restype = C.c_char_p
+        l.wfk_chain_launch.argtypes = [VP, VP, I64, VP]
+        l.wfk_chain_plan_destroy.argtypes = [VP]
         l.wfk_iir_plan_create.argtypes = [I32, VP, VP, VP, I64, I32, C.c_int, P(VP)]
         l.wfk_iir_state_dim.argtypes = [VP]
         l.wfk_iir_apply.argtypes = [VP, VP, I64, VP, I64, VP, VP, C.c_double, VP]
@@ -195,6 +201,31 @@ class FirPlan:
     def close(self):
         if self._h and _lib is not None:
             _lib.wfk_fir_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class ChainPlan:
+    """sampler -> FIR for every channel of `prog` on `grid` (predistort(wav(t), ker=ker)); fused
+    into ONE kernel when the program is fully fused and K <= 1537 (`fused`, `why_not`)."""
+
+    def __init__(self, prog: Program, grid: wfk_grid, ker, dtype=np.float64):
+        ker = np.ascontiguousarray(ker, dtype=np.float64)
+        self.prog, self.grid, self.dtype = prog, grid, np.dtype(dtype)
+        self.n, self.n_channels = int(grid.n), prog.n_channels
+        self._h = C.c_void_p()
+        check(lib().wfk_chain_plan_create(C.byref(prog.struct), C.byref(grid), ker.ctypes.data, len(ker),
+                                          _KIND_OF[self.dtype], C.byref(self._h)))
+        self.fused = bool(lib().wfk_chain_is_fused(self._h))
+        self.why_not = lib().wfk_chain_unfused_reason(self._h).decode()
+
+    def launch(self, out_ptr: int, out_stride: int, stream: int = 0):
+        check(lib().wfk_chain_launch(self._h, out_ptr, out_stride, stream))
+
+    def close(self):
+        if self._h and _lib is not None:
+            _lib.wfk_chain_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

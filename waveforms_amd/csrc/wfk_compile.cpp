@@ -114,7 +114,17 @@ struct BlockBuilder {
 }  // namespace
 
 static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
-                        int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr);
+                        int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr,
+                        int lane_stride = 64, int ns_override = 0);
+
+// Grid plan for another evaluation geometry: lanes `lane_stride` samples apart, `ns` samples per
+// lane (the sampler fused into the FIR transform walks a window with stride 256, wfk_fir_sampled.hip).
+// Only the piece / parameter tables are meaningful in the result; H.lean tells whether every piece
+// is one block of fused ops (the only form that kernel evaluates).
+int wfk_compile_geom(const wfk_program* P, const wfk_grid* grid, int lane_stride, int ns, HostPlan& H,
+                     std::string& err) {
+  return compile_impl(P, grid, nullptr, 0, H, err, false, lane_stride, ns);
+}
 
 int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
                 int64_t n_tlist, HostPlan& H, std::string& err) {
@@ -127,7 +137,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
 }
 
 static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
-                        int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr) {
+                        int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr,
+                        int lane_stride, int ns_override) {
   if (!P || (!grid && !tlist && n_tlist != 0)) { err = "null program or time axis"; return WFK_EINVAL; }
   if (P->n_channels < 0 || P->n_members < 0) { err = "negative counts"; return WFK_EINVAL; }
   TimeAxis ax{grid, tlist, grid ? grid->n : n_tlist};
@@ -141,9 +152,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (ax.n > 1 && !(grid->step > 0)) { err = "grid step must be positive"; return WFK_EINVAL; }
   }
   H.ns = H.tlist ? (ax.n < WFK_TLIST_SMALL_N ? WFK_NS_TLIST_SMALL : WFK_NS_TLIST) : WFK_NS_GRID;
+  if (ns_override > 0 && !H.tlist) H.ns = ns_override;
   H.tile = WFK_WG * H.ns;
   const int NS = H.ns;
-  const double dstride = grid ? 64.0 * grid->step : 0.0;  // lane-to-lane sample stride in time
+  const double dstride = grid ? (double)lane_stride * grid->step : 0.0;  // time between a lane's samples
+  const int lean_par_cap = ns_override > 0 ? WFK_LDS_DOUBLES : WFK_LEAN_PAR;
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
   const bool nofast = nofast_env && nofast_env[0] == '1';
@@ -798,7 +811,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         int32_t len = flush_block(B);
         if (D.n_blk == 0) D.first_len = len;
         ++D.n_blk;
-        if (D.n_blk != 1 || len > WFK_LEAN_PAR) lean_ok = false;
+        if (D.n_blk != 1 || len > lean_par_cap) lean_ok = false;
         H.lean_par = std::max<int32_t>(H.lean_par, len);
       }
       // fuse adjacent zero pieces

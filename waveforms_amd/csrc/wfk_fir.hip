@@ -172,6 +172,14 @@ static int fir_run(wfk_fir_plan* p, const void* in_dev, int64_t in_stride, void*
   return WFK_OK;
 }
 
+// used by the sampler -> FIR chain (wfk_fir_sampled.hip): the kernel spectrum and twiddles of a
+// plan that runs as ONE pass of the on-chip transform
+extern "C" void wfk_internal_fir_tables(const wfk_fir_plan* p, const void** kspec, const void** tw,
+                                        int* fused, int* nseg, int* K, int* lead) {
+  *kspec = p->kspec; *tw = p->tw; *fused = p->fused ? 1 : 0; *nseg = p->nseg; *K = p->K;
+  *lead = (p->K - 1) - p->K / 2;
+}
+
 extern "C" {
 
 int wfk_fir_plan_destroy(wfk_fir_plan* p) {

@@ -155,6 +155,9 @@ struct HostPlan {
 int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tlist,
                 int64_t n, HostPlan& out, std::string& err);
 
+int wfk_compile_geom(const wfk_program* prog, const wfk_grid* grid, int lane_stride, int ns,
+                     HostPlan& out, std::string& err);
+
 // kernels (wfk_kernels.hip)
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns,
                        bool lean, bool generic, bool direct, void* stream, std::string& err);

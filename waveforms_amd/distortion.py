@@ -48,6 +48,50 @@ class FirStage:
         self.plan.close()
 
 
+class SampledFir:
+    """`predistort(wav(t), ker=ker)` for many channels on one uniform grid, device-resident:
+    the sampler runs INSIDE the FIR transform when the channels are fully fused (`fused`), so
+    the unfiltered samples never touch HBM (reference chain: waveform.py:529-563 ->
+    distortion.py:329-337).  Build once, launch many times.
+
+        sf = SampledFir(channels, ('linspace', 0.0, 3e-6, 10**7, False), ker)
+        sf.launch_torch(out)          # (n_channels, >= n) device tensor of the plan dtype
+    """
+
+    def __init__(self, channels, grid, ker, dtype=np.float64, function_lib=None):
+        from . import _flatten
+        if not isinstance(grid, _flatten.wfk_grid):
+            grid = _flatten.grid_from_desc(grid)
+        self.prog = _flatten.flatten(list(channels), grid, function_lib)
+        self.plan = _engine.ChainPlan(self.prog, grid, ker, dtype)
+        self.n, self.n_channels, self.dtype = self.plan.n, self.plan.n_channels, np.dtype(dtype)
+        self.fused, self.why_not = self.plan.fused, self.plan.why_not
+
+    def launch(self, out_ptr, out_stride=None, stream=0):
+        self.plan.launch(out_ptr, self.n if out_stride is None else out_stride, stream)
+
+    def launch_torch(self, out):
+        import torch
+        want = torch.float64 if self.dtype == np.float64 else torch.float32
+        if (not out.is_cuda or out.dtype != want or out.dim() != 2 or out.shape[0] != self.n_channels
+                or out.shape[1] < self.n or out.stride(1) != 1):
+            raise ValueError('out must be a (n_channels, >=n) row-contiguous device tensor of the plan dtype')
+        self.launch(out.data_ptr(), out.stride(0), torch.cuda.current_stream(out.device).cuda_stream)
+        return out
+
+    def to_host(self):
+        buf = _engine.DeviceBuffer(max(self.n_channels * self.n, 1) * self.dtype.itemsize)
+        try:
+            self.launch(buf.ptr)
+            _engine.sync()
+            return buf.download((self.n_channels, self.n), self.dtype)
+        finally:
+            buf.close()
+
+    def close(self):
+        self.plan.close()
+
+
 def fir_host(sig: np.ndarray, ker: np.ndarray) -> np.ndarray:
     """NumPy in, NumPy out: upload, rocFFT overlap-save on the device, download."""
     sig2 = np.ascontiguousarray(np.atleast_2d(sig), dtype=np.float64)
