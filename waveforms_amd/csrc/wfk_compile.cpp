@@ -156,7 +156,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.tile = WFK_WG * H.ns;
   const int NS = H.ns;
   const double dstride = grid ? (double)lane_stride * grid->step : 0.0;  // time between a lane's samples
-  const int lean_par_cap = ns_override > 0 ? WFK_LDS_DOUBLES : WFK_LEAN_PAR;
+  const int lean_par_cap = ns_override > 0 ? WFK_CHAIN_PAR : WFK_LEAN_PAR;
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
   const bool nofast = nofast_env && nofast_env[0] == '1';

@@ -77,9 +77,69 @@ __device__ __forceinline__ double chain_time(const ChainArgs& a, int64_t j) {
 
 struct ChSeeds { double c, s, g, r; };
 
-// exact per-thread seeds of one fused op (same arithmetic as fce_seeds in wfk_kernels.hip)
-__device__ __attribute__((noinline)) ChSeeds chain_seeds(double theta, double ea, double eb, int carrier,
-                                                         int env) {
+// ---- seeds: sin/cos(pi r) on |r| <= 1/2 and exp(x), straight-line --------------------------
+// The libm routines cost ~300 VALU instructions per op and thread here (general argument
+// reduction, special cases), a quarter of the kernel's time.  The arguments of the seeds are
+// already reduced / bounded by the host's range checks, so two short polynomial kernels do:
+//   sin(pi r), cos(pi r): fold to z in [0, 1/4], Taylor in t = pi z up to t^17 / t^18
+//   exp(x), |x| < 700:    n = rint(x log2 e), Cody-Waite r = x - n ln2 (two words), Taylor to
+//                         r^14 on |r| <= ln2/2, ldexp
+// Truncation < 5e-18 relative for all three; rounding of the Horner chains ~1e-16.
+__device__ __forceinline__ void sincospi_small(double r, double* sn, double* cs) {
+  const double a = fabs(r);
+  const bool swap = a > 0.25;
+  const double z = swap ? 0.5 - a : a;                    // exact
+  const double t = z * 3.141592653589793116 + z * 1.2246467991473532e-16;
+  const double t2 = t * t;
+  double ps = -2.8114572543455206e-15;                    // -1/17!
+  ps = fma(ps, t2, 7.6471637318198164e-13);               //  1/15!
+  ps = fma(ps, t2, -1.6059043836821613e-10);              // -1/13!
+  ps = fma(ps, t2, 2.5052108385441720e-08);               //  1/11!
+  ps = fma(ps, t2, -2.7557319223985893e-06);              // -1/9!
+  ps = fma(ps, t2, 1.9841269841269841e-04);               //  1/7!
+  ps = fma(ps, t2, -8.3333333333333332e-03);              // -1/5!
+  ps = fma(ps, t2, 1.6666666666666666e-01);               //  1/3!  (sign folded below)
+  const double s = fma(-t * t2, ps, t);                   // t - t^3/6 + ...   (ps holds +1/6 - t^2/120 ...)
+  double pc = 1.5619206968586226e-16;                     //  1/18!
+  pc = fma(pc, t2, -4.7794773323873853e-14);              // -1/16!
+  pc = fma(pc, t2, 1.1470745597729725e-11);               //  1/14!
+  pc = fma(pc, t2, -2.0876756987868099e-09);              // -1/12!
+  pc = fma(pc, t2, 2.7557319223985888e-07);               //  1/10!
+  pc = fma(pc, t2, -2.4801587301587302e-05);              // -1/8!
+  pc = fma(pc, t2, 1.3888888888888889e-03);               //  1/6!
+  pc = fma(pc, t2, -4.1666666666666664e-02);              // -1/4!
+  pc = fma(pc, t2, 0.5);                                  //  1/2! (sign folded below)
+  const double c = fma(-t2, pc, 1.0);                     // 1 - t^2/2 + t^4/24 ...
+  const double ss = swap ? c : s, cc = swap ? s : c;
+  *sn = r < 0.0 ? -ss : ss;
+  *cs = cc;
+}
+
+__device__ __forceinline__ double exp_small(double x) {
+#pragma clang fp contract(off)   // the reduction's fma()s are explicit
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);      // ln2 high word (low 11 bits zero: n * hi exact)
+  r = fma(-n, 1.90821492927058770002e-10, r);             // ln2 low word
+  double p = 1.1470745597729725e-11;                      // 1/14!
+  p = fma(p, r, 1.6059043836821613e-10);                  // 1/13!
+  p = fma(p, r, 2.0876756987868099e-09);
+  p = fma(p, r, 2.5052108385441720e-08);
+  p = fma(p, r, 2.7557319223985888e-07);
+  p = fma(p, r, 2.7557319223985893e-06);
+  p = fma(p, r, 2.4801587301587302e-05);
+  p = fma(p, r, 1.9841269841269841e-04);
+  p = fma(p, r, 1.3888888888888889e-03);
+  p = fma(p, r, 8.3333333333333332e-03);
+  p = fma(p, r, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
+// exact per-thread seeds of one fused op (the arithmetic of fce_seeds in wfk_kernels.hip)
+__device__ __forceinline__ ChSeeds chain_seeds(double theta, double ea, double eb, int carrier, int env) {
 #pragma clang fp contract(off)   // the explicit fma()s must stay the only ones (see sincos_phase)
   ChSeeds o;
   o.c = 1.0; o.s = 0.0; o.g = 1.0; o.r = 1.0;
@@ -89,110 +149,83 @@ __device__ __attribute__((noinline)) ChSeeds chain_seeds(double theta, double ea
     const double xl = fma(theta, IPI_HI, -xh) + theta * IPI_LO;
     const double n = rint(xh);
     double ss, cc;
-    sincospi((xh - n) + xl, &ss, &cc);
+    sincospi_small((xh - n) + xl, &ss, &cc);
     const bool odd = ((long long)n) & 1;
     o.s = odd ? -ss : ss;
     o.c = odd ? -cc : cc;
   }
   if (env) {
-    o.g = exp(ea);
-    o.r = exp(eb);
+    o.g = exp_small(ea);
+    o.r = exp_small(eb);
   }
   return o;
 }
 
 // one fused carrier-envelope op over the thread's chain:
 //   acc[k] += E_k * (A(u_k) cos th_k + B(u_k) sin th_k),  k < CL, samples 256 apart
-// DEG 0 / 1 / 3 (= 2..3); MASK: only the samples klo <= k < khi belong to the piece.
-// The Gaussian state stays in double (also for float output).
-template <typename T, int CL, int DEG, bool CARRIER, bool ENV, bool MASK>
+// ONE loop for every op shape (degree <= 3 Horner with zero high coefficients, a unit phasor
+// table for ops without carrier, q = 1 without envelope): with 2 * CL accumulator registers the
+// per-shape specialisations of the lean sampler kernel cost more in copies and spills at their
+// control-flow merges than the few multiplies they save.  MASK: only the samples
+// klo <= k < khi belong to the piece.  The Gaussian state stays in double (also for float output).
+// KC: the chain position that is the NEXT pair's first sample (2 * HOPB): the op state there
+// (phasor turned by table entry KC, Gaussian recurrence after KC steps) is returned in `nx`, so a
+// workgroup walking consecutive pairs needs exact seeds for its first pair only.
+template <typename T, int CL, int KC, bool MASK, bool DEG1>
 __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, const ChSeeds& sd, double u0,
-                                           T (&acc)[CL], int klo, int khi) {
-  asm volatile("" : "+v"(u0) : : "memory");   // keeps the variants' shared sub-expressions from being hoisted
+                                           double q, T (&acc)[CL], int klo, int khi, ChSeeds& nx) {
   const T c0 = (T)sd.c, s0 = (T)sd.s;
-  const T A0 = (T)r[WFK_FCE_A], A1 = (T)r[WFK_FCE_A + 1], B0 = (T)r[WFK_FCE_B], B1 = (T)r[WFK_FCE_B + 1];
-  const T A2 = DEG > 1 ? (T)r[WFK_FCE_A + 2] : (T)0, A3 = DEG > 1 ? (T)r[WFK_FCE_A + 3] : (T)0;
-  const T B2 = DEG > 1 ? (T)r[WFK_FCE_B + 2] : (T)0, B3 = DEG > 1 ? (T)r[WFK_FCE_B + 3] : (T)0;
-  const T ac = A0 * c0, as = A0 * s0;
+  const T A0 = (T)r[WFK_FCE_A], A1 = (T)r[WFK_FCE_A + 1], A2 = (T)r[WFK_FCE_A + 2], A3 = (T)r[WFK_FCE_A + 3];
+  const T B0 = (T)r[WFK_FCE_B], B1 = (T)r[WFK_FCE_B + 1], B2 = (T)r[WFK_FCE_B + 2], B3 = (T)r[WFK_FCE_B + 3];
   double g = sd.g, rr = sd.r;
-  const double q = r[WFK_FCE_Q];
   T u = (T)u0;
   const T Dt = (T)r[WFK_FCE_D];
   constexpr int SB = CL % 4 == 0 ? 4 : 2;   // sub-batch: bounds the live table entries / temporaries
   static_assert(CL % SB == 0, "chain length must be even");
   CH_EACH(CL / SB, kb)
     double2 tb[SB];
-    if (CARRIER) {
-      CH_EACH(SB, kk) tb[kk] = tab[kb * SB + kk]; CH_END   // wave-wide LDS broadcasts
-    }
+    CH_EACH(SB, kk) tb[kk] = tab[kb * SB + kk]; CH_END   // wave-wide LDS broadcasts (fetching a batch ahead
+                                                          // was measured slower: 13.0 vs 11.9 ms, spills)
     CH_EACH(SB, kk)
       constexpr int k = kb * SB + kk;
-      T val;
-      if (DEG == 0) {
-        val = CARRIER ? ac * (T)tb[kk].x - as * (T)tb[kk].y : A0;
-      } else {
-        T pa, pb;
-        if (DEG == 1) {
-          pa = A1 * u + A0;
-          pb = B1 * u + B0;
-        } else {
-          pa = ((A3 * u + A2) * u + A1) * u + A0;
-          pb = ((B3 * u + B2) * u + B1) * u + B0;
-        }
-        u += Dt;
-        if (CARRIER) {
-          const T ck = c0 * (T)tb[kk].x - s0 * (T)tb[kk].y;
-          const T sk = s0 * (T)tb[kk].x + c0 * (T)tb[kk].y;
-          val = pa * ck + pb * sk;
-        } else {
-          val = pa;
-        }
+      const T pa = DEG1 ? A1 * u + A0 : ((A3 * u + A2) * u + A1) * u + A0;
+      const T pb = DEG1 ? B1 * u + B0 : ((B3 * u + B2) * u + B1) * u + B0;
+      u += Dt;
+      const T ck = c0 * (T)tb[kk].x - s0 * (T)tb[kk].y;
+      const T sk = s0 * (T)tb[kk].x + c0 * (T)tb[kk].y;
+      const T val = (pa * ck + pb * sk) * (T)g;
+      if constexpr (k == KC) {
+        nx.g = g;
+        nx.r = rr;
+        nx.c = sd.c * tb[kk].x - sd.s * tb[kk].y;
+        nx.s = sd.s * tb[kk].x + sd.c * tb[kk].y;
       }
-      if (ENV) {
-        val *= (T)g;
-        g *= rr;
-        rr *= q;
-      }
+      g *= rr;
+      rr *= q;
       if (!MASK || (k >= klo && k < khi)) acc[k] += val;
     CH_END
     __builtin_amdgcn_sched_barrier(0);
   CH_END
 }
 
-template <typename T, int CL, bool MASK>
-__device__ __forceinline__ void chain_op(const double* blk, const double* r, double x, int fl, T (&acc)[CL],
-                                         int klo, int khi) {
-  const int deg = fl & 3, carrier = (fl >> 2) & 1, env = (fl >> 4) & 3;
+__device__ __forceinline__ ChSeeds chain_make_seeds(const double* r, double x, int fl) {
   const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
-  const ChSeeds sd = chain_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), -(v * v), -Hh * (2.0 * v + Hh), carrier,
-                                 env);
-  const double2* tab = reinterpret_cast<const double2*>(blk + (fl >> 8));
-  const double u0 = x - r[WFK_FCE_SLIN];
-#define CHAIN_CALL(DG, CA, EN) chain_loop<T, CL, DG, CA, EN, MASK>(tab, r, sd, u0, acc, klo, khi)
-  if (carrier) {
-    if (env) {
-      if (deg == 0) CHAIN_CALL(0, true, true); else if (deg == 1) CHAIN_CALL(1, true, true); else CHAIN_CALL(3, true, true);
-    } else {
-      if (deg == 0) CHAIN_CALL(0, true, false); else if (deg == 1) CHAIN_CALL(1, true, false); else CHAIN_CALL(3, true, false);
-    }
-  } else {
-    if (env) {
-      if (deg == 0) CHAIN_CALL(0, false, true); else CHAIN_CALL(3, false, true);
-    } else {
-      if (deg == 0) CHAIN_CALL(0, false, false); else CHAIN_CALL(3, false, false);
-    }
-  }
-#undef CHAIN_CALL
+  return chain_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), -(v * v), -Hh * (2.0 * v + Hh), (fl >> 2) & 1,
+                     ((fl >> 4) & 3) != 0);
 }
 
 // closing pseudo-op (envelope shared by all carriers of the piece): acc[k] *= g_k inside the piece
-template <typename T, int CL>
-__device__ __forceinline__ void chain_envmul(const double* r, double x, T (&acc)[CL], int klo, int khi) {
-  const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
-  const ChSeeds sd = chain_seeds(0.0, -(v * v), -Hh * (2.0 * v + Hh), 0, 1);
+template <typename T, int CL, int KC>
+__device__ __forceinline__ void chain_envmul(const double* r, const ChSeeds& sd, T (&acc)[CL], int klo, int khi,
+                                             ChSeeds& nx) {
   double g = sd.g, rr = sd.r;
   const double q = r[WFK_FCE_Q];
+  nx = sd;
   CH_EACH(CL, k)
+    if constexpr (k == KC) {
+      nx.g = g;
+      nx.r = rr;
+    }
     if (k >= klo && k < khi) acc[k] *= (T)g;
     g *= rr;
     rr *= q;
@@ -202,84 +235,127 @@ __device__ __forceinline__ void chain_envmul(const double* r, double x, T (&acc)
 #ifndef WFK_FIRS_WAVES
 #define WFK_FIRS_WAVES 3
 #endif
+#ifndef WFK_FIRS_PPW
+#define WFK_FIRS_PPW 1      // consecutive pairs per workgroup; > 1 carries the op state from pair to pair (exact
+                            // seeds for the first pair only).  Measured at 4: 20.7 ms vs 12.5 (the loop-carried
+                            // values push the allocator into 120 spills), so every workgroup takes ONE pair
+#endif
+#define WFK_FIRS_NCAR 2     // ops of a piece whose state is carried in registers from pair to pair
+
 template <typename T, int HOPB>
 __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainArgs a) {
   constexpr int CL = 16 + HOPB;     // chain length: both windows of the pair
+  constexpr int PPW = WFK_FIRS_PPW, NCAR = WFK_FIRS_NCAR;
+  constexpr bool CARRY = PPW > 1;
+  constexpr int KC = CARRY ? 2 * HOPB : -1;   // chain position of the next pair's first sample
+  static_assert(KC < CL, "the chains of consecutive pairs must overlap");
   __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
   double* const s_par = reinterpret_cast<double*>(lds);   // parameter block, before the transform needs the array
+  constexpr int LDS_DOUBLES = (int)(sizeof(T) * LDS_ELEMS / sizeof(double));
+  double2* const unit_tab = reinterpret_cast<double2*>(s_par + LDS_DOUBLES - 2 * CL);
   const int tid = threadIdx.x;
-  const int64_t pair = blockIdx.x;
   const int ch = blockIdx.y;
-  const int64_t s1 = 2 * pair * (int64_t)a.hop - a.lead;   // first sample of the first window
-  const int64_t j0 = s1 + tid;
-  const int64_t range_end = s1 + 256 * (int64_t)CL;
   const DevChannel C = a.channels[ch];
-
-  // ---- sampling phase: the chain of this thread ------------------------------------------
-  T acc[CL];
-  CH_EACH(CL, k) acc[k] = (T)0; CH_END
-  double x = chain_time(a, j0);
-  if (C.tshift != 0.0) x = x - C.tshift;
-  int q = cuni(a.pair_first[(int64_t)ch * a.npairs + pair]);
-  for (; q < C.piece_end; q = cuni(q + 1)) {
-    const DevPiece P = a.pieces[q];
-    if (P.start >= range_end) break;
-    if (P.n_blk == 0 || P.stop <= s1) continue;             // zero piece / entirely before the chain
-    __syncthreads();                                         // every wave is done with the previous block
-    for (int i = tid; i < P.first_len; i += 256) s_par[i] = a.params[P.par_off + i];
-    __syncthreads();
-    const int nops = cuni((int)s_par[1]);
-    const bool full = P.start <= s1 && P.stop >= range_end;  // wave-uniform: the whole chain range is inside
-    // samples k of this thread inside the piece: P.start <= j0 + 256 k < P.stop
-    int klo = 0, khi = CL;
-    if (!full) {
-      const int64_t lo = P.start - j0, hi = P.stop - j0;     // k >= lo/256 (ceil), k < hi/256 (ceil)
-      klo = lo <= 0 ? 0 : (int)((lo + 255) >> 8);
-      khi = hi <= 0 ? 0 : (int)((hi + 255) >> 8);
-      klo = klo > CL ? CL : klo;
-      khi = khi > CL ? CL : khi;
-    }
-    for (int op = 0; op < nops; ++op) {
-      const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
-      const int fl = cuni((int)rec[WFK_FCE_DEG]);
-      if (((fl >> 4) & 3) == 3) chain_envmul<T, CL>(rec, x, acc, klo, khi);
-      else if (full) chain_op<T, CL, false>(s_par, rec, x, fl, acc, 0, CL);
-      else chain_op<T, CL, true>(s_par, rec, x, fl, acc, klo, khi);
-    }
-  }
-  __syncthreads();   // parameter block no longer needed: the array becomes the FFT exchange buffer
-
-  // ---- zero padding, channel offset, packing of the two windows ---------------------------
-  const T base = (T)C.offset;
-  CH_EACH(CL, k)
-    const int64_t j = j0 + 256 * k;
-    acc[k] = (j >= 0 && j < a.n) ? acc[k] + base : (T)0;
-  CH_END
-  cx<T> v[16];
-  CH_EACH(16, n1)
-    v[n1].x = acc[n1];
-    v[n1].y = acc[n1 + HOPB];
-  CH_END
-
-  // ---- transform, multiply by the kernel spectrum, inverse transform (as fir_fused) ---------
   const cx<T>* hspec = static_cast<const cx<T>*>(a.hspec);
   const cx<T>* tw = static_cast<const cx<T>*>(a.tw);
-  const cx<T> wa = tw[tid], wb = tw[16 * (tid & 15)];
-  fft4096<false>(v, lds, wa, wb, tid);
-#pragma unroll
-  for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
-  __builtin_amdgcn_s_setprio(2);
-  fft4096<true>(v, lds, wa, wb, tid);
-  T* orow = static_cast<T*>(a.out) + (int64_t)ch * a.out_stride;
+  T* const orow = static_cast<T*>(a.out) + (int64_t)ch * a.out_stride;
   const int M = a.hop;
-  const int64_t b1 = 2 * pair, b2 = b1 + 1;
+
+  int car_piece = -1;               // piece whose op state at this pair's first sample sits in car[] (wave-uniform)
+  ChSeeds car[NCAR];
+  for (int i = 0; i < NCAR; ++i) { car[i].c = 1.0; car[i].s = 0.0; car[i].g = 1.0; car[i].r = 1.0; }
+
+  for (int pp = 0; pp < PPW; ++pp) {
+    const int64_t pair = (int64_t)blockIdx.x * PPW + pp;
+    if (pair >= a.npairs) break;
+    const int64_t s1 = 2 * pair * (int64_t)a.hop - a.lead;   // first sample of the first window
+    const int64_t j0 = s1 + tid;
+    const int64_t range_end = s1 + 256 * (int64_t)CL;
+
+    // ---- sampling phase: the chain of this thread ----------------------------------------
+    T acc[CL];
+    CH_EACH(CL, k) acc[k] = (T)0; CH_END
+    double x = chain_time(a, j0);
+    if (C.tshift != 0.0) x = x - C.tshift;
+    __syncthreads();                                         // the previous pair's transform is done with the array
+    if (tid < CL) unit_tab[tid] = make_double2(1.0, 0.0);    // phasor table of ops without a carrier
+    int next_car = -1;
+    int q = cuni(a.pair_first[(int64_t)ch * a.npairs + pair]);
+    for (; q < C.piece_end; q = cuni(q + 1)) {
+      const DevPiece P = a.pieces[q];
+      if (P.start >= range_end) break;
+      if (P.n_blk == 0 || P.stop <= s1) continue;           // zero piece / entirely before the chain
+      __syncthreads();                                       // every wave is done with the previous block
+      for (int i = tid; i < P.first_len; i += 256) s_par[i] = a.params[P.par_off + i];
+      __syncthreads();
+      const int nops = cuni((int)s_par[1]);
+      const bool full = P.start <= s1 && P.stop >= range_end;   // wave-uniform: the whole chain is inside
+      const bool carried = CARRY && full && car_piece == q;
+      // samples k of this thread inside the piece: P.start <= j0 + 256 k < P.stop
+      int klo = 0, khi = CL;
+      if (!full) {
+        const int64_t lo = P.start - j0, hi = P.stop - j0;   // k >= lo/256 (ceil), k < hi/256 (ceil)
+        klo = lo <= 0 ? 0 : (int)((lo + 255) >> 8);
+        khi = hi <= 0 ? 0 : (int)((hi + 255) >> 8);
+        klo = klo > CL ? CL : klo;
+        khi = khi > CL ? CL : khi;
+      }
+      for (int op = 0; op < nops; ++op) {
+        const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
+        const int fl = cuni((int)rec[WFK_FCE_DEG]);
+        const int env = (fl >> 4) & 3, carrier = (fl >> 2) & 1;
+        ChSeeds sd, nx;
+        if (carried && op == 0) sd = car[0];
+        else if (carried && NCAR > 1 && op == 1) sd = car[NCAR > 1 ? 1 : 0];
+        else sd = chain_make_seeds(rec, x, fl);              // exact (libm)
+        if (env == 3) {
+          chain_envmul<T, CL, KC>(rec, sd, acc, klo, khi, nx);
+        } else {
+          const double2* tab = carrier ? reinterpret_cast<const double2*>(s_par + (fl >> 8)) : unit_tab;
+          const double qq = env ? rec[WFK_FCE_Q] : 1.0;
+          const double u0 = x - rec[WFK_FCE_SLIN];
+          // (the common shapes -- whole chain inside the piece, polynomials of degree <= 1: a
+          //  DRAG-corrected pulse -- get the short loop; everything else the general one)
+          if (full && (fl & 3) <= 1) chain_loop<T, CL, KC, false, true>(tab, rec, sd, u0, qq, acc, 0, CL, nx);
+          else if (full) chain_loop<T, CL, KC, false, false>(tab, rec, sd, u0, qq, acc, 0, CL, nx);
+          else chain_loop<T, CL, KC, true, false>(tab, rec, sd, u0, qq, acc, klo, khi, nx);
+        }
+        if (CARRY && op == 0) car[0] = nx;
+        if (CARRY && NCAR > 1 && op == 1) car[NCAR > 1 ? 1 : 0] = nx;
+      }
+      // the next pair can start from car[] if it lies in this piece as a whole, too
+      if (full) next_car = q;
+    }
+    car_piece = next_car;
+    __syncthreads();   // parameter block no longer needed: the array becomes the FFT exchange buffer
+
+    // ---- zero padding, channel offset, packing of the two windows -------------------------
+    const T base = (T)C.offset;
+    CH_EACH(CL, k)
+      const int64_t j = j0 + 256 * k;
+      acc[k] = (j >= 0 && j < a.n) ? acc[k] + base : (T)0;
+    CH_END
+    cx<T> v[16];
+    CH_EACH(16, n1)
+      v[n1].x = acc[n1];
+      v[n1].y = acc[n1 + HOPB];
+    CH_END
+
+    // ---- transform, multiply by the kernel spectrum, inverse transform (as fir_fused) -------
+    const cx<T> wa = tw[tid], wb = tw[16 * (tid & 15)];
+    fft4096<false>(v, lds, wa, wb, tid);
 #pragma unroll
-  for (int q3 = 0; q3 < 16; ++q3) {
-    const int r = tid + 256 * q3 - (a.K - 1);
-    if (r >= 0 && r < M) {
-      const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
-      if (d1 < a.n) orow[d1] = v[q3].x;
-      if (d2 < a.n) orow[d2] = v[q3].y;
+    for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
+    fft4096<true>(v, lds, wa, wb, tid);
+    const int64_t b1 = 2 * pair, b2 = b1 + 1;
+#pragma unroll
+    for (int q3 = 0; q3 < 16; ++q3) {
+      const int r = tid + 256 * q3 - (a.K - 1);
+      if (r >= 0 && r < M) {
+        const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
+        if (d1 < a.n) orow[d1] = v[q3].x;
+        if (d2 < a.n) orow[d2] = v[q3].y;
+      }
     }
   }
 }
@@ -429,7 +505,7 @@ int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void*
   a.hspec = kspec; a.tw = tw;
   a.t0 = p->t0; a.step = p->step; a.last = p->last; a.has_last = p->has_last;
   a.hop = 256 * p->hopb; a.K = K; a.lead = lead;
-  const dim3 grid((unsigned)p->npairs, (unsigned)p->n_channels);
+  const dim3 grid((unsigned)((p->npairs + WFK_FIRS_PPW - 1) / WFK_FIRS_PPW), (unsigned)p->n_channels);
   if (p->kind == WFK_OUT_F32) {
     if (p->hopb == 12) hipLaunchKernelGGL((fir_sampled<float, 12>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((fir_sampled<float, 10>), grid, dim3(256), 0, s, a);

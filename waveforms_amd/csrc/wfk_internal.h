@@ -85,6 +85,8 @@
 // With the 8 KB of per-lane op state that makes 10 KB per wave = 16 waves per CU, which the
 // fp32 kernel (<= 128 VGPRs) uses: 2.11 -> 1.95 ms on 256 x 1e7 fp32 against 512 doubles.
 #define WFK_LEAN_PAR 640      // upper limit (10 ops x 56 doubles + header), reserved per plan as needed
+#define WFK_CHAIN_PAR 2048    // sampler inside the FIR transform: largest parameter block (doubles); it is staged
+                              // in the transform's exchange array (18.5 KB in the float kernel)
 #define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles
 
 #define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)
