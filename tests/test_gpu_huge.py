@@ -8,7 +8,7 @@ import pytest
 
 import waveforms_amd as wf
 from oracle import c_oracle
-from waveforms_amd import _engine, _flatten
+from waveforms_amd import _engine, _flatten, workloads as wl
 from waveforms_amd._sampling import BatchSampler
 from waveforms_amd.distortion import FirStage
 
@@ -98,3 +98,48 @@ def test_sampler_fir_iir_beyond_2_pow_31():
     assert np.all(np.isfinite(zf.cpu().numpy()))
     iir.close()
     bs.close()
+
+
+def test_c5_per_rank_shape_512_channels_1e7():
+    """BASELINE configs[4] as ONE rank sees it: 512 channels x 1e7 points fp64 (41 GB) in a single
+    launch (4096 channels over 8 GPUs, seeds 1000+c).  Determinism, per-channel
+    equality with single-channel plans, reference rows (c4_full.npz holds the reference's own
+    samples of channels 0 and 7 at 1e7 points) and probes against the C oracle."""
+    import torch
+    import golden_io
+    from oracle import c_oracle
+    from waveforms_amd import _flatten
+    from waveforms_amd._dist import ShardedSampler
+    full = golden_io.npz('c4_full.npz')
+    grid = wl.c2_grid()
+    make = lambda c: wl.sum_channel(wf, 100, 1000 + c)
+    sh = ShardedSampler(4096, make, grid, rank=0, world=8)          # rank 0's block: channels 0..511
+    assert (sh.start, sh.stop) == (0, 512) and sh.local.n_channels == 512
+    out = torch.empty((512, sh.n), dtype=torch.float64, device='cuda')
+    sh.launch_torch(out)
+    torch.cuda.synchronize()
+    for c in (0, 7):
+        pick = torch.as_tensor(full[f'{c}.pick'], device='cuda')
+        assert np.max(np.abs(out[c][pick].cpu().numpy() - full[f'{c}.y'])) <= 1e-9
+    out2 = torch.empty_like(out)
+    sh.launch_torch(out2)
+    assert torch.equal(out, out2)                                   # deterministic
+    del out2
+    for c in (3, 255, 256, 511):                                    # no dependence on the batch position
+        one = BatchSampler([make(c)], grid)
+        row = torch.empty((1, sh.n), dtype=torch.float64, device='cuda')
+        one.launch_torch(row)
+        assert torch.equal(row[0], out[c]), c
+        one.close()
+    # probes: 4096 samples of channel 300 around a piece edge against the plain-C oracle
+    prog = _flatten.flatten([make(300)])
+    idx0 = int(np.searchsorted(wl.make_grid(grid), make(300).bounds[37]))
+    sub = _flatten.wfk_grid(g.t0, g.step, g.n, g.has_last, g.last)
+    want = c_oracle.eval_grid(_flatten.flatten([make(300)]), sub)[0][idx0 - 2048:idx0 + 2048] \\
+        if False else None
+    t = wl.make_grid(grid)[idx0 - 2048:idx0 + 2048]
+    want = c_oracle.eval_tlist(prog, t)[0]
+    assert np.max(np.abs(out[300][idx0 - 2048:idx0 + 2048].cpu().numpy() - want)) <= 1e-9
+    # the last rank's block of the same job: global channel index carries the seeds
+    last = ShardedSampler(4096, make, grid, rank=7, world=8)
+    assert (last.start, last.stop) == (3584, 4096)

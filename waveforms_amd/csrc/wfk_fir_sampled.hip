@@ -330,11 +330,21 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
     __syncthreads();   // parameter block no longer needed: the array becomes the FFT exchange buffer
 
     // ---- zero padding, channel offset, packing of the two windows -------------------------
+    // (interior pairs -- all but the first and the last few of a row -- need no range checks at all:
+    //  a wave-uniform branch keeps ~100 compares and selects out of their way)
     const T base = (T)C.offset;
-    CH_EACH(CL, k)
-      const int64_t j = j0 + 256 * k;
-      acc[k] = (j >= 0 && j < a.n) ? acc[k] + base : (T)0;
-    CH_END
+    const int64_t b1 = 2 * pair, b2 = b1 + 1;
+    const bool interior = s1 >= 0 && range_end <= a.n && (b2 + 1) * (int64_t)M <= a.n;
+    if (interior) {
+      if (base != (T)0) {
+        CH_EACH(CL, k) acc[k] += base; CH_END
+      }
+    } else {
+      CH_EACH(CL, k)
+        const int64_t j = j0 + 256 * k;
+        acc[k] = (j >= 0 && j < a.n) ? acc[k] + base : (T)0;
+      CH_END
+    }
     cx<T> v[16];
     CH_EACH(16, n1)
       v[n1].x = acc[n1];
@@ -347,14 +357,26 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
 #pragma unroll
     for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
     fft4096<true>(v, lds, wa, wb, tid);
-    const int64_t b1 = 2 * pair, b2 = b1 + 1;
+    if (interior) {
+      T* const o1 = orow + b1 * M + (tid - (a.K - 1));      // wave-uniform base + lane offset
+      T* const o2 = o1 + M;
 #pragma unroll
-    for (int q3 = 0; q3 < 16; ++q3) {
-      const int r = tid + 256 * q3 - (a.K - 1);
-      if (r >= 0 && r < M) {
-        const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
-        if (d1 < a.n) orow[d1] = v[q3].x;
-        if (d2 < a.n) orow[d2] = v[q3].y;
+      for (int q3 = 0; q3 < 16; ++q3) {
+        const int r = tid + 256 * q3 - (a.K - 1);
+        if (r >= 0 && r < M) {
+          o1[256 * q3] = v[q3].x;
+          o2[256 * q3] = v[q3].y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q3 = 0; q3 < 16; ++q3) {
+        const int r = tid + 256 * q3 - (a.K - 1);
+        if (r >= 0 && r < M) {
+          const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
+          if (d1 < a.n) orow[d1] = v[q3].x;
+          if (d2 < a.n) orow[d2] = v[q3].y;
+        }
       }
     }
   }
