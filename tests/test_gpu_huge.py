@@ -134,9 +134,6 @@ def test_c5_per_rank_shape_512_channels_1e7():
     # probes: 4096 samples of channel 300 around a piece edge against the plain-C oracle
     prog = _flatten.flatten([make(300)])
     idx0 = int(np.searchsorted(wl.make_grid(grid), make(300).bounds[37]))
-    sub = _flatten.wfk_grid(g.t0, g.step, g.n, g.has_last, g.last)
-    want = c_oracle.eval_grid(_flatten.flatten([make(300)]), sub)[0][idx0 - 2048:idx0 + 2048] \\
-        if False else None
     t = wl.make_grid(grid)[idx0 - 2048:idx0 + 2048]
     want = c_oracle.eval_tlist(prog, t)[0]
     assert np.max(np.abs(out[300][idx0 - 2048:idx0 + 2048].cpu().numpy() - want)) <= 1e-9
