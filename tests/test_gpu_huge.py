@@ -129,7 +129,9 @@ def test_c5_per_rank_shape_512_channels_1e7():
         one = BatchSampler([make(c)], grid)
         row = torch.empty((1, sh.n), dtype=torch.float64, device='cuda')
         one.launch_torch(row)
-        assert torch.equal(row[0], out[c]), c
+        # (chunking -- hence the exact-reseed points of the carried op state -- depends on the batch
+        #  size: equal to rounding, not bit for bit)
+        assert float((row[0] - out[c]).abs().max()) <= 1e-12, c
         one.close()
     # probes: 4096 samples of channel 300 around a piece edge against the plain-C oracle
     prog = _flatten.flatten([make(300)])
