@@ -72,3 +72,49 @@ def test_complex_amplitudes_fused(nt):
     assert np.max(np.abs(plan.run_host(np.complex64) - ora)) <= 5e-5 * pk
     # a real-output launch of a complex channel keeps the real part (like WaveVStack's .real)
     assert np.max(np.abs(plan.run_host(np.float64) - ora.real)) <= 1e-9 * pk
+
+
+def test_mixed_plan_lean_plateau_generic_edges():
+    """A flat-top pulse with erf edges under several tones: the plateau and the gaps are lean pieces,
+    the edges carry generic ERF terms.  The plan runs as TWO launches over disjoint pieces (lean
+    kernel + general kernel); every sample is written exactly once."""
+    import os
+    rng = np.random.default_rng(11)
+    tones = None
+    for k in range(6):
+        tone = rng.uniform(0.05, 0.1) * wf.cos(2 * np.pi * rng.uniform(-300e6, 300e6), rng.uniform(0, 6))
+        tones = tone if tones is None else tones + tone
+    chans = []
+    for c in range(3):
+        w = wf.zero()
+        for k in range(7):
+            w = w + ((wf.square(200e-9, edge=8e-9) >> ((k + 0.5) * 300e-9 + c * 1e-9)) * tones)
+        chans.append(w)
+    grid = ('linspace', 0.0, 7 * 300e-9, 210013, False)
+    g = _flatten.grid_from_desc(grid)
+    prog = _flatten.flatten(chans)
+    plan = _engine.Plan(prog, grid=g)
+    assert ' + ' in plan.kernel_name(), plan.kernel_name()          # lean + general
+    want = c_oracle.eval_grid(prog, g)
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+        got = plan.run_host(dtype)
+        assert np.max(np.abs(got - want)) <= tol
+    # poisoned output buffer: every sample must be overwritten (no sample left to either kernel)
+    buf = _engine.DeviceBuffer(want.size * 8)
+    buf.upload(np.full(want.shape, np.nan))
+    plan.launch(buf.ptr, g.n, _engine.OUT_F64)
+    _engine.sync()
+    got = buf.download(want.shape, np.float64)
+    assert not np.isnan(got).any() and np.max(np.abs(got - want)) <= 1e-11
+    # accumulate adds exactly once per sample
+    plan.launch(buf.ptr, g.n, _engine.OUT_F64, accumulate=True)
+    _engine.sync()
+    assert np.max(np.abs(buf.download(want.shape, np.float64) - 2 * want)) <= 2e-11
+    buf.close()
+    os.environ['WFK_DISABLE_MIXED'] = '1'
+    try:
+        single = _engine.Plan(prog, grid=g)
+        assert ' + ' not in single.kernel_name()
+        assert np.max(np.abs(single.run_host(np.float64) - want)) <= 1e-11
+    finally:
+        del os.environ['WFK_DISABLE_MIXED']

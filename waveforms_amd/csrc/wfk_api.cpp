@@ -129,6 +129,7 @@ struct wfk_plan {
   double* d_params = nullptr;
   double* d_pool = nullptr;
   int32_t* d_chunk_first = nullptr;
+  int32_t* d_lean_chunk_first = nullptr;   // mixed plans: chunk table of the lean launch
   double* d_tlist = nullptr;
   void* d_scratch = nullptr;   // wfk_plan_run_host output buffer
   size_t scratch_bytes = 0;
@@ -152,9 +153,10 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   const size_t b_pa = h.params.size() * sizeof(double);
   const size_t b_po = h.pool.size() * sizeof(double);
   const size_t b_cf = h.chunk_first.size() * sizeof(int32_t);
+  const size_t b_lf = h.lean_chunk_first.size() * sizeof(int32_t);
   const size_t o_ch = 0, o_pc = align256(o_ch + b_ch), o_pa = align256(o_pc + b_pc),
                o_po = align256(o_pa + b_pa), o_cf = align256(o_po + b_po),
-               o_tl = align256(o_cf + b_cf);
+               o_lf = align256(o_cf + b_cf), o_tl = align256(o_lf + b_lf);
   const size_t b_tl = tlist ? (size_t)h.n * sizeof(double) : 0;
   const size_t total = align256(o_tl + b_tl) + 256;
   HIP_TRY(dev_cache().get(total, &p->d_tables, &p->tables_cap, &p->dev));
@@ -164,6 +166,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   p->d_params = reinterpret_cast<double*>(base + o_pa);
   p->d_pool = reinterpret_cast<double*>(base + o_po);
   p->d_chunk_first = reinterpret_cast<int32_t*>(base + o_cf);
+  p->d_lean_chunk_first = reinterpret_cast<int32_t*>(base + o_lf);
   p->d_tlist = tlist ? reinterpret_cast<double*>(base + o_tl) : nullptr;
   // the small tables travel in ONE copy; the time axis (as large as the output) on its own
   std::vector<char> stage(o_tl);
@@ -172,6 +175,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   if (b_pa) std::memcpy(stage.data() + o_pa, h.params.data(), b_pa);
   if (b_po) std::memcpy(stage.data() + o_po, h.pool.data(), b_po);
   if (b_cf) std::memcpy(stage.data() + o_cf, h.chunk_first.data(), b_cf);
+  if (b_lf) std::memcpy(stage.data() + o_lf, h.lean_chunk_first.data(), b_lf);
   if (o_tl) HIP_TRY(hipMemcpy(base, stage.data(), o_tl, hipMemcpyHostToDevice));
   if (b_tl) HIP_TRY(hipMemcpy(base + o_tl, tlist, b_tl, hipMemcpyHostToDevice));
   p->on_device = true;
@@ -285,14 +289,16 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   const char* T = (out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64) ? "float" : "double";
   const char* cplx = (out_kind == WFK_OUT_C128 || out_kind == WFK_OUT_C64) ? "true" : "false";
   const HostPlan& h = p->h;
+  const std::string lean_name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +
+      (h.n_corr > 0 && out_kind != WFK_OUT_F32 && out_kind != WFK_OUT_C64 ? ",true>" : ",false>");
   if (!h.tlist && h.lean) {
-    name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +
-           (h.n_corr > 0 && out_kind != WFK_OUT_F32 && out_kind != WFK_OUT_C64 ? ",true>" : ",false>");
+    name = lean_name;
   } else {
     const bool direct = h.tlist || h.n_direct > 0, generic = direct || h.n_generic > 0;
     name = std::string("wfk_sample<") + T + "," + cplx + "," + (h.tlist ? "true" : "false") + "," +
            (generic ? "true" : "false") + "," + (direct ? "true" : "false") + "," +
            std::to_string(h.ns) + ">";
+    if (h.mixed) name = lean_name + " + " + name;   // two launches over disjoint pieces
   }
   return name.c_str();
 }
@@ -327,10 +333,23 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   a.corr = p->h.n_corr > 0 ? 1 : 0;
   if (hip_stream) p->async_launch = true;
   std::string err;
-  int rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.ns, p->h.lean,
-                              p->h.n_generic > 0,
-                              p->h.n_direct > 0,
-                              hip_stream, err);
+  int rc = WFK_OK;
+  if (p->h.mixed) {
+    // lean and zero pieces first (own chunking: one wave per workgroup) ...
+    KArgs l = a;
+    l.mixed = 1;
+    l.chunk_first = p->d_lean_chunk_first;
+    l.chunks_per_ch = p->h.lean_chunks_per_ch;
+    l.n_chunks = p->h.lean_chunks_per_ch * p->h.n_channels;
+    l.tiles_per_chunk = p->h.lean_tiles_per_chunk;
+    rc = wfk_launch_sampler(l, p->h.n_channels, out_kind, false, p->h.ns, true, false, false, hip_stream, err);
+    if (rc) return fail(rc, err);
+    a.mixed = 1;   // ... then the pieces with generic terms
+  }
+  rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.ns, p->h.lean,
+                          p->h.n_generic > 0,
+                          p->h.n_direct > 0,
+                          hip_stream, err);
   return rc ? fail(rc, err) : WFK_OK;
 }
 

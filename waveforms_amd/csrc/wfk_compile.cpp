@@ -132,7 +132,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   // first-order per-sample correction, which only the lean kernel implements.  A plan that turns
   // out not to be lean is compiled again with such carriers on the exact (libm) path.
   int rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
-  if (rc == WFK_OK && H.n_corr > 0 && !H.lean) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
+  if (rc == WFK_OK && H.n_corr > 0 && !H.lean && !H.mixed) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
   return rc;
 }
 
@@ -295,9 +295,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // t = 0, as mixing()'s is: what the subtraction rounds away is recovered with a TwoSum.)
   const char* nocorr_env = std::getenv("WFK_DISABLE_CORR");
   const bool corr_enabled = allow_corr && !(nocorr_env && nocorr_env[0] == '1');
+  bool piece_corr_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
   auto corr_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {
     const double x = std::fabs(rate) * grid_jitter(s0, s1);
-    return corr_enabled && std::isfinite(x) && 2.0 * x * x <= 1e-11;   // (d <= ~2 W e)
+    return corr_enabled && piece_corr_ok && std::isfinite(x) && 2.0 * x * x <= 1e-11;   // (d <= ~2 W e)
   };
 
   // ---- factor record emission -------------------------------------------------
@@ -690,6 +691,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
 
   // ---- merge members into disjoint device pieces -----------------------------
   bool lean_ok = can_fuse;
+  int64_t n_lean_pieces = 0;
   H.channels.resize(P->n_channels);
   H.channel_complex.assign(P->n_channels, 0);
   for (int32_t c = 0; c < P->n_channels; ++c) {
@@ -723,7 +725,14 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       D.start = s0; D.stop = s1; D.n_blk = 0; D.flags = 0; D.first_len = 0; D.pad = 0;
       if (H.params.size() & 1) H.params.push_back(0.0);
       D.par_off = (int64_t)H.params.size();
-      if (!live.empty()) {
+      // A piece is built at most twice: the corrected (far-from-origin) carriers exist in the lean
+      // kernel only, so a piece that turns out NOT to be lean is rebuilt with them on the exact path.
+      struct Snap { size_t params, pool; int32_t nf, nd, nu, ng, nc; std::map<int64_t, int64_t> sampled; };
+      const Snap snap{H.params.size(), H.pool.size(), H.n_fast, H.n_direct, H.n_fused, H.n_generic, H.n_corr, sampled_at};
+      const DevPiece D0 = D;
+      bool piece_lean = false;
+      for (int attempt = 0; attempt < 2 && !live.empty(); ++attempt) {
+        const int32_t corr_before = H.n_corr;
         D.flags |= WFK_PF_HAS_TERMS;
         BlockBuilder B;
         auto room_for = [&](size_t need) -> int {
@@ -784,8 +793,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             groups.push_back(E);
           }
         }
-        if (!generic.empty() || groups.size() > WFK_LEAN_OPS) lean_ok = false;
-        H.lean_ops = std::max<int32_t>(H.lean_ops, (int32_t)groups.size());
+        piece_lean = generic.empty() && !groups.empty() && groups.size() <= WFK_LEAN_OPS;
+        const int32_t piece_ops = (int32_t)groups.size();
         for (FceGroup& G : groups) {
           if (room_for(WFK_FCE_REC + 2 * (NS + 1)) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
           emit_group(B, G);
@@ -811,9 +820,27 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         int32_t len = flush_block(B);
         if (D.n_blk == 0) D.first_len = len;
         ++D.n_blk;
-        if (D.n_blk != 1 || len > lean_par_cap) lean_ok = false;
-        H.lean_par = std::max<int32_t>(H.lean_par, len);
+        piece_lean = piece_lean && D.n_blk == 1 && len <= lean_par_cap;
+        if (!piece_lean && H.n_corr > corr_before && attempt == 0) {
+          // roll back and build the piece again without corrected carriers
+          H.params.resize(snap.params); H.pool.resize(snap.pool);
+          H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
+          sampled_at = snap.sampled;
+          D = D0;
+          piece_corr_ok = false;
+          continue;
+        }
+        if (piece_lean) {
+          D.flags |= WFK_PF_LEAN;
+          ++n_lean_pieces;
+          H.lean_ops = std::max<int32_t>(H.lean_ops, piece_ops);
+          H.lean_par = std::max<int32_t>(H.lean_par, len);
+        } else {
+          lean_ok = false;
+        }
+        break;
       }
+      piece_corr_ok = true;
       // fuse adjacent zero pieces
       if (D.n_blk == 0 && (int32_t)H.pieces.size() > C.piece_begin &&
           H.pieces.back().n_blk == 0 && H.pieces.back().stop == s0) {
@@ -829,32 +856,45 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
   // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
   H.lean = lean_ok && !nolean && H.n_fused > 0;
+  // mixed plans: some pieces are lean, some are not (the erf edges of a flat-top pulse next to its
+  // multi-tone plateau).  Two launches over the same output: the lean kernel takes the lean and the
+  // zero pieces, the general kernel the rest -- every sample is still written exactly once.
+  const char* nomix_env = std::getenv("WFK_DISABLE_MIXED");
+  H.mixed = !H.lean && can_fuse && !nolean && n_lean_pieces > 0 && ns_override == 0 &&
+            !(nomix_env && nomix_env[0] == '1');
   H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
   H.lean_ops = std::max(4, H.lean_ops);                          // likewise: 4 ops = 8 KB of state
-  if (H.lean) H.tile = 64 * H.ns;
-  int64_t tiles_per_ch = (ax.n + H.tile - 1) / H.tile;
-  int64_t total_tiles = tiles_per_ch * P->n_channels;
-  // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves.  Longer
-  // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
-  // any moment compact, which is what the HBM write rate depends on:
-  // measured best at 8 tiles (= one seed per chunk) on the headline config, 4 on C2.
-  int64_t tpc = total_tiles / (H.lean ? 2048 : 8192);
-  H.tiles_per_chunk = (int32_t)std::min<int64_t>(H.lean ? 8 : 16, std::max<int64_t>(1, tpc));
-  if (const char* e = std::getenv("WFK_TPC")) {   // tuning override
-    int v = std::atoi(e);
-    if (v >= 1 && v <= 64) H.tiles_per_chunk = v;
-  }
-  H.chunks_per_ch = (tiles_per_ch + H.tiles_per_chunk - 1) / H.tiles_per_chunk;
-  H.chunk_first.assign((size_t)(H.chunks_per_ch * P->n_channels), 0);
-  const int64_t chunk_samples = (int64_t)H.tiles_per_chunk * H.tile;
-  for (int32_t c = 0; c < P->n_channels; ++c) {
-    int32_t p = H.channels[c].piece_begin;
-    for (int64_t k = 0; k < H.chunks_per_ch; ++k) {
-      int64_t g0 = k * chunk_samples;
-      while (p < H.channels[c].piece_end - 1 && H.pieces[p].stop <= g0) ++p;
-      H.chunk_first[(size_t)(c * H.chunks_per_ch + k)] = p;
+  auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
+                      std::vector<int32_t>& chunk_first) {
+    // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
+    // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
+    tile = (lean_geom ? 64 : WFK_WG) * H.ns;
+    const int64_t tiles_per_ch = (ax.n + tile - 1) / tile;
+    const int64_t total_tiles = tiles_per_ch * P->n_channels;
+    // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves.  Longer
+    // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
+    // any moment compact, which is what the HBM write rate depends on:
+    // measured best at 8 tiles (= one seed per chunk) on the headline config, 4 on C2.
+    const int64_t tpc = total_tiles / (lean_geom ? 2048 : 8192);
+    tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? 8 : 16, std::max<int64_t>(1, tpc));
+    if (const char* e = std::getenv("WFK_TPC")) {   // tuning override
+      int v = std::atoi(e);
+      if (v >= 1 && v <= 64) tiles_per_chunk = v;
     }
-  }
+    chunks_per_ch = (tiles_per_ch + tiles_per_chunk - 1) / tiles_per_chunk;
+    chunk_first.assign((size_t)(chunks_per_ch * P->n_channels), 0);
+    const int64_t chunk_samples = (int64_t)tiles_per_chunk * tile;
+    for (int32_t c = 0; c < P->n_channels; ++c) {
+      int32_t p = H.channels[c].piece_begin;
+      for (int64_t k = 0; k < chunks_per_ch; ++k) {
+        int64_t g0 = k * chunk_samples;
+        while (p < H.channels[c].piece_end - 1 && H.pieces[p].stop <= g0) ++p;
+        chunk_first[(size_t)(c * chunks_per_ch + k)] = p;
+      }
+    }
+  };
+  chunking(H.lean, H.tile, H.tiles_per_chunk, H.chunks_per_ch, H.chunk_first);
+  if (H.mixed) chunking(true, H.lean_tile, H.lean_tiles_per_chunk, H.lean_chunks_per_ch, H.lean_chunk_first);
   if (H.pool.empty()) H.pool.push_back(0.0);
   if (H.params.empty()) H.params.push_back(0.0);
   return WFK_OK;

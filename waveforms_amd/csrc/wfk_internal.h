@@ -90,6 +90,7 @@
 #define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles
 
 #define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)
+#define WFK_PF_LEAN 2         // piece is one block of <= WFK_LEAN_OPS fused ops (lean kernel can take it)
 
 struct DevPiece {
   int64_t start, stop;        // sample range [start, stop)
@@ -123,7 +124,9 @@ struct KArgs {
   double t0, step, last;
   int32_t has_last, pad;
   int32_t lean_par, lean_ops;  // lean kernel: doubles of parameter block / ops of state to reserve in LDS
-  int32_t corr, pad2;          // plan holds carriers that need the grid-rounding correction (lean kernel variant)
+  int32_t corr;                // plan holds carriers that need the grid-rounding correction (lean kernel variant)
+  int32_t mixed;               // mixed plan: the lean kernel skips the pieces without WFK_PF_LEAN, the general
+                               // kernel skips the lean and the zero pieces (two launches, one output)
 };
 
 #ifdef __cplusplus
@@ -149,6 +152,10 @@ struct HostPlan {
   int32_t n_fast = 0, n_direct = 0, n_fused = 0, n_generic = 0;
   int32_t n_corr = 0;          // fused ops carrying the grid-rounding correction
   bool lean = false;           // wave-per-workgroup fused kernel (see WFK_LEAN_*)
+  bool mixed = false;          // lean pieces go to the lean kernel, the rest to the general kernel
+  int32_t lean_tile = 0, lean_tiles_per_chunk = 1;   // mixed: the lean launch's own chunking
+  int64_t lean_chunks_per_ch = 0;
+  std::vector<int32_t> lean_chunk_first;
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most ops of a piece
 };
 

@@ -904,7 +904,9 @@ wfk_sample_lean(const KArgs a) {
       T acc[NS], acci[CPLX ? NS : 1];
       WFK_EACH(NS, k) acc[k] = (T)0; WFK_END
       WFK_EACH(CPLX ? NS : 1, k) acci[k] = (T)0; WFK_END
-      if (P.n_blk != 0) {
+      // mixed plans: pieces with generic terms belong to the general kernel's launch
+      const bool mine = !a.mixed || P.n_blk == 0 || (P.flags & WFK_PF_LEAN);
+      if (P.n_blk != 0 && mine) {
         if (P.par_off != staged) {
           __syncthreads();
           for (int i = lane; i < P.first_len; i += 64) s_par[i] = a.params[P.par_off + i];
@@ -969,7 +971,7 @@ wfk_sample_lean(const KArgs a) {
       }
       // tile base pinned to SGPRs: the stores become `global_store v_lane_off, data, s[base]
       // offset:k*512` (one address VGPR instead of a hoisted 64-bit pointer pair per store)
-      store_tile<T, CPLX, NS>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
+      if (mine) store_tile<T, CPLX, NS>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
       if (P.stop >= w1 || q + 1 >= C.piece_end) break;   // the tile ends inside this piece
       q = uni(q + 1);
       cur = load_piece(a.pieces + q);
@@ -1013,6 +1015,8 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
     for (int q = p; q < C.piece_end; q = uni(q + 1)) {
       const DevPiece P = load_piece(a.pieces + q);
       if (P.start >= g1) break;
+      // (mixed plans: the lean and the zero pieces were written by the lean kernel's launch)
+      if (a.mixed && (P.n_blk == 0 || (P.flags & WFK_PF_LEAN))) continue;
       const bool active = w0 < a.n && P.start < w0 + WT && P.stop > w0;  // wave-uniform
 
       T acc[NS], acci[CPLX ? NS : 1];
