@@ -85,30 +85,39 @@ struct ChSeeds { double c, s, g, r; };
 //   exp(x), |x| < 700:    n = rint(x log2 e), Cody-Waite r = x - n ln2 (two words), Taylor to
 //                         r^14 on |r| <= ln2/2, ldexp
 // Truncation < 5e-18 relative for all three; rounding of the Horner chains ~1e-16.
+// A polynomial coefficient pinned to an SGPR pair where it is used.  Left to itself the compiler
+// hoists all ~35 coefficients of the seed kernels out of the piece / op loops into VGPRs and then
+// SPILLS them there (the accumulators need the registers): 150 B of scratch per thread, 16 GB of
+// extra HBM writes per launch of the C4 chain (rocprofv3 WRITE_SIZE 35 GB for 20 GB of output).
+__device__ __forceinline__ double kc(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
 __device__ __forceinline__ void sincospi_small(double r, double* sn, double* cs) {
   const double a = fabs(r);
   const bool swap = a > 0.25;
   const double z = swap ? 0.5 - a : a;                    // exact
   const double t = z * 3.141592653589793116 + z * 1.2246467991473532e-16;
   const double t2 = t * t;
-  double ps = -2.8114572543455206e-15;                    // -1/17!
-  ps = fma(ps, t2, 7.6471637318198164e-13);               //  1/15!
-  ps = fma(ps, t2, -1.6059043836821613e-10);              // -1/13!
-  ps = fma(ps, t2, 2.5052108385441720e-08);               //  1/11!
-  ps = fma(ps, t2, -2.7557319223985893e-06);              // -1/9!
-  ps = fma(ps, t2, 1.9841269841269841e-04);               //  1/7!
-  ps = fma(ps, t2, -8.3333333333333332e-03);              // -1/5!
-  ps = fma(ps, t2, 1.6666666666666666e-01);               //  1/3!  (sign folded below)
+  double ps = kc(-2.8114572543455206e-15);                    // -1/17!
+  ps = fma(ps, t2, kc(7.6471637318198164e-13));               //  1/15!
+  ps = fma(ps, t2, kc(-1.6059043836821613e-10));              // -1/13!
+  ps = fma(ps, t2, kc(2.5052108385441720e-08));               //  1/11!
+  ps = fma(ps, t2, kc(-2.7557319223985893e-06));              // -1/9!
+  ps = fma(ps, t2, kc(1.9841269841269841e-04));               //  1/7!
+  ps = fma(ps, t2, kc(-8.3333333333333332e-03));              // -1/5!
+  ps = fma(ps, t2, kc(1.6666666666666666e-01));               //  1/3!  (sign folded below)
   const double s = fma(-t * t2, ps, t);                   // t - t^3/6 + ...   (ps holds +1/6 - t^2/120 ...)
-  double pc = 1.5619206968586226e-16;                     //  1/18!
-  pc = fma(pc, t2, -4.7794773323873853e-14);              // -1/16!
-  pc = fma(pc, t2, 1.1470745597729725e-11);               //  1/14!
-  pc = fma(pc, t2, -2.0876756987868099e-09);              // -1/12!
-  pc = fma(pc, t2, 2.7557319223985888e-07);               //  1/10!
-  pc = fma(pc, t2, -2.4801587301587302e-05);              // -1/8!
-  pc = fma(pc, t2, 1.3888888888888889e-03);               //  1/6!
-  pc = fma(pc, t2, -4.1666666666666664e-02);              // -1/4!
-  pc = fma(pc, t2, 0.5);                                  //  1/2! (sign folded below)
+  double pc = kc(1.5619206968586226e-16);                     //  1/18!
+  pc = fma(pc, t2, kc(-4.7794773323873853e-14));              // -1/16!
+  pc = fma(pc, t2, kc(1.1470745597729725e-11));               //  1/14!
+  pc = fma(pc, t2, kc(-2.0876756987868099e-09));              // -1/12!
+  pc = fma(pc, t2, kc(2.7557319223985888e-07));               //  1/10!
+  pc = fma(pc, t2, kc(-2.4801587301587302e-05));              // -1/8!
+  pc = fma(pc, t2, kc(1.3888888888888889e-03));               //  1/6!
+  pc = fma(pc, t2, kc(-4.1666666666666664e-02));              // -1/4!
+  pc = fma(pc, t2, kc(0.5));                                  //  1/2! (sign folded below)
   const double c = fma(-t2, pc, 1.0);                     // 1 - t^2/2 + t^4/24 ...
   const double ss = swap ? c : s, cc = swap ? s : c;
   *sn = r < 0.0 ? -ss : ss;
@@ -120,21 +129,21 @@ __device__ __forceinline__ double exp_small(double x) {
   const double n = rint(x * 1.4426950408889634);
   double r = fma(-n, 6.93147180369123816490e-01, x);      // ln2 high word (low 11 bits zero: n * hi exact)
   r = fma(-n, 1.90821492927058770002e-10, r);             // ln2 low word
-  double p = 1.1470745597729725e-11;                      // 1/14!
-  p = fma(p, r, 1.6059043836821613e-10);                  // 1/13!
-  p = fma(p, r, 2.0876756987868099e-09);
-  p = fma(p, r, 2.5052108385441720e-08);
-  p = fma(p, r, 2.7557319223985888e-07);
-  p = fma(p, r, 2.7557319223985893e-06);
-  p = fma(p, r, 2.4801587301587302e-05);
-  p = fma(p, r, 1.9841269841269841e-04);
-  p = fma(p, r, 1.3888888888888889e-03);
-  p = fma(p, r, 8.3333333333333332e-03);
-  p = fma(p, r, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
+  double p = kc(1.1470745597729725e-11);                      // 1/14!
+  p = fma(p, r, kc(1.6059043836821613e-10));                  // 1/13!
+  p = fma(p, r, kc(2.0876756987868099e-09));
+  p = fma(p, r, kc(2.5052108385441720e-08));
+  p = fma(p, r, kc(2.7557319223985888e-07));
+  p = fma(p, r, kc(2.7557319223985893e-06));
+  p = fma(p, r, kc(2.4801587301587302e-05));
+  p = fma(p, r, kc(1.9841269841269841e-04));
+  p = fma(p, r, kc(1.3888888888888889e-03));
+  p = fma(p, r, kc(8.3333333333333332e-03));
+  p = fma(p, r, kc(4.1666666666666664e-02));
+  p = fma(p, r, kc(1.6666666666666666e-01));
+  p = fma(p, r, kc(0.5));
+  p = fma(p, r, kc(1.0));
+  p = fma(p, r, kc(1.0));
   return ldexp(p, (int)n);
 }
 
@@ -352,17 +361,21 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
     CH_END
 
     // ---- transform, multiply by the kernel spectrum, inverse transform (as fir_fused) -------
-    const cx<T> wa = tw[tid], wb = tw[16 * (tid & 15)];
-    fft4096<false>(v, lds, wa, wb, tid);
+    // (nothing of the transform -- twiddles, exchange addresses -- may be hoisted above the sampling
+    //  phase: it would be spilled there, and 150 B of scratch per thread are 16 GB per launch)
+    int tf = tid;                      // the transform's view of the thread index, opaque: everything
+    asm volatile("" : "+v"(tf));       // derived from it is computed HERE, after the sampling phase
+    const cx<T> wa = tw[tf], wb = tw[16 * (tf & 15)];
+    fft4096<false>(v, lds, wa, wb, tf);
 #pragma unroll
-    for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
-    fft4096<true>(v, lds, wa, wb, tid);
+    for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tf + 256 * k3]);
+    fft4096<true>(v, lds, wa, wb, tf);
     if (interior) {
-      T* const o1 = orow + b1 * M + (tid - (a.K - 1));      // wave-uniform base + lane offset
+      T* const o1 = orow + b1 * M + (tf - (a.K - 1));       // wave-uniform base + lane offset
       T* const o2 = o1 + M;
 #pragma unroll
       for (int q3 = 0; q3 < 16; ++q3) {
-        const int r = tid + 256 * q3 - (a.K - 1);
+        const int r = tf + 256 * q3 - (a.K - 1);
         if (r >= 0 && r < M) {
           o1[256 * q3] = v[q3].x;
           o2[256 * q3] = v[q3].y;
@@ -371,7 +384,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
     } else {
 #pragma unroll
       for (int q3 = 0; q3 < 16; ++q3) {
-        const int r = tid + 256 * q3 - (a.K - 1);
+        const int r = tf + 256 * q3 - (a.K - 1);
         if (r >= 0 && r < M) {
           const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
           if (d1 < a.n) orow[d1] = v[q3].x;
