@@ -189,7 +189,10 @@ __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, 
   double g = sd.g, rr = sd.r;
   T u = (T)u0;
   const T Dt = (T)r[WFK_FCE_D];
-  constexpr int SB = CL % 4 == 0 ? 4 : 2;   // sub-batch: bounds the live table entries / temporaries
+#ifndef WFK_FIRS_SB
+#define WFK_FIRS_SB 4
+#endif
+  constexpr int SB = CL % WFK_FIRS_SB == 0 ? WFK_FIRS_SB : 2;   // sub-batch: bounds the live table entries / temporaries
   static_assert(CL % SB == 0, "chain length must be even");
   CH_EACH(CL / SB, kb)
     double2 tb[SB];
@@ -278,13 +281,13 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
     const int64_t pair = (int64_t)blockIdx.x * PPW + pp;
     if (pair >= a.npairs) break;
     const int64_t s1 = 2 * pair * (int64_t)a.hop - a.lead;   // first sample of the first window
-    const int64_t j0 = s1 + tid;
-    const int64_t range_end = s1 + 256 * (int64_t)CL;
+    const int64_t range_end = s1 + 256 * (int64_t)CL;   // (per-thread sample index: s1 + tid + 256 k; kept as
+                                                         //  the 32-bit `tid`, a 64-bit copy would be spilled)
 
     // ---- sampling phase: the chain of this thread ----------------------------------------
     T acc[CL];
     CH_EACH(CL, k) acc[k] = (T)0; CH_END
-    double x = chain_time(a, j0);
+    double x = chain_time(a, s1 + tid);
     if (C.tshift != 0.0) x = x - C.tshift;
     __syncthreads();                                         // the previous pair's transform is done with the array
     if (tid < CL) unit_tab[tid] = make_double2(1.0, 0.0);    // phasor table of ops without a carrier
@@ -303,9 +306,14 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
       // samples k of this thread inside the piece: P.start <= j0 + 256 k < P.stop
       int klo = 0, khi = CL;
       if (!full) {
-        const int64_t lo = P.start - j0, hi = P.stop - j0;   // k >= lo/256 (ceil), k < hi/256 (ceil)
-        klo = lo <= 0 ? 0 : (int)((lo + 255) >> 8);
-        khi = hi <= 0 ? 0 : (int)((hi + 255) >> 8);
+        // k >= (P.start - j0)/256 (ceil), k < (P.stop - j0)/256 (ceil), j0 = s1 + tid; the scalar parts
+        // are clamped to what matters for k in [0, CL) so that the per-thread part is 32-bit
+        const int64_t lim = 256 * (int64_t)(CL + 2);
+        const int64_t los = P.start - s1, his = P.stop - s1;
+        const int lo = (int)(los < -lim ? -lim : (los > lim ? lim : los)) - tid;
+        const int hi = (int)(his < -lim ? -lim : (his > lim ? lim : his)) - tid;
+        klo = lo <= 0 ? 0 : (lo + 255) >> 8;
+        khi = hi <= 0 ? 0 : (hi + 255) >> 8;
         klo = klo > CL ? CL : klo;
         khi = khi > CL ? CL : khi;
       }
@@ -350,7 +358,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
       }
     } else {
       CH_EACH(CL, k)
-        const int64_t j = j0 + 256 * k;
+        const int64_t j = s1 + tid + 256 * k;
         acc[k] = (j >= 0 && j < a.n) ? acc[k] + base : (T)0;
       CH_END
     }
