@@ -96,7 +96,9 @@ def launch_ranks(args, argv):
         except subprocess.TimeoutExpired:
             p.kill()                                   # the exact child we started
             rcs.append(p.wait())
-    sys.stdout.write(out0.decode('utf-8', 'replace'))
+    # rank 0's JSON line goes to stdout; anything else it printed there (backend chatter) to stderr
+    for ln in out0.decode('utf-8', 'replace').splitlines():
+        (sys.stdout if ln.startswith('{') else sys.stderr).write(ln + '\n')
     sys.stdout.flush()
     bad = [rc for rc in rcs if rc != 0]
     return bad[0] if bad else 0
