@@ -540,7 +540,8 @@ def run_rank(args):
                 'rows_per_rank': rows, 'bytes_per_rank': nbytes, 'ms': g_ms,
                 'ingress_GBps_per_rank': (world - 1) * nbytes / (g_ms * 1e-3) / 1e9,
                 'full_block_est_ms': g_ms * bs.n_channels / rows,
-                'note': 'all_gather (RCCL over xGMI) of a row slice; full block extrapolated linearly'}
+                'note': ('all_gather (RCCL over xGMI)' if args.backend == 'nccl' else 'all_gather (gloo, host)') +
+                        ' of a row slice; full block extrapolated linearly'}
             del dst
         except Exception as exc:   # placement is optional: never lose the bench line over it
             line['gather'] = {'error': repr(exc)}

@@ -243,3 +243,55 @@ def test_predistort_combined_order_above_16():
     assert np.max(np.abs(got - want)) <= 1e-9
     with pytest.raises(NotImplementedError):
         distortion.predistort(x, filters, initial=0.3)
+
+
+@pytest.mark.parametrize('nsec,n,rows', [(2, 100003, 3), (1, 65536, 2), (2, 8192 * 4, 5), (2, 1_000_001, 7)])
+def test_single_pass_chained_scan(nsec, n, rows):
+    """One or two biquads on long rows as ONE kernel (chained scan with decoupled look-back: x is
+    read once; WFK_IIR_ONEPASS=1).  Against scipy.signal.sosfilt with random initial state, final state, DC
+    offset, in place, float32, and the three-launch form of the same plan."""
+    import os
+    rng = np.random.default_rng(n + nsec)
+    sos = butter(2 * nsec, 0.07, output='sos')
+    secs = [(r[:3], r[3:]) for r in sos]
+    x = rng.normal(size=(rows, n))
+    zi = rng.normal(size=(rows, nsec, 2)) * 0.1
+    want = np.empty_like(x)
+    zfw = np.empty_like(zi)
+    for r in range(rows):
+        want[r], zfw[r] = sosfilt(sos, x[r] - 0.25, zi=zi[r])
+    want += 0.25
+
+    def run(dtype, inplace=False):
+        plan = _engine.IirPlan(secs, n, rows, dtype)
+        es = np.dtype(dtype).itemsize
+        dx, dy = _engine.DeviceBuffer(rows * n * es), _engine.DeviceBuffer(rows * n * es)
+        dzi, dzf = _engine.DeviceBuffer(zi.nbytes), _engine.DeviceBuffer(zi.nbytes)
+        dx.upload(x.astype(dtype))
+        dzi.upload(zi)
+        for _ in range(2):                      # twice: flags of the first launch must not leak into the second
+            if inplace:
+                dx.upload(x.astype(dtype))
+            plan.apply(dx.ptr, n, dx.ptr if inplace else dy.ptr, n, dzi.ptr, dzf.ptr, 0.25)
+            _engine.sync()
+        got = (dx if inplace else dy).download((rows, n), dtype)
+        zf = dzf.download(zi.shape, np.float64)
+        for b in (dx, dy, dzi, dzf):
+            b.close()
+        plan.close()
+        return got, zf
+
+    os.environ['WFK_IIR_ONEPASS'] = '1'        # experimental form (off by default: slower, DESIGN 3.6)
+    try:
+        got, zf = run(np.float64)
+        got_ip, _ = run(np.float64, inplace=True)
+        g32, _ = run(np.float32)
+    finally:
+        del os.environ['WFK_IIR_ONEPASS']
+    pk = max(1.0, np.abs(want).max())
+    assert np.max(np.abs(got - want)) <= 1e-11 * pk
+    assert np.max(np.abs(zf - zfw)) <= 1e-11 * max(1.0, np.abs(zfw).max())
+    assert np.array_equal(got_ip, got)
+    assert np.max(np.abs(g32 - want)) <= 2e-5 * pk
+    three, zf3 = run(np.float64)               # the default three-launch form of the same plan
+    assert np.max(np.abs(three - got)) <= 1e-12 * pk and np.max(np.abs(zf3 - zf)) <= 1e-12 * max(1.0, np.abs(zf).max())

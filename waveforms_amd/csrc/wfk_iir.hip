@@ -313,6 +313,261 @@ __global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const
   }
 }
 
+
+// ---- single pass: chained scan with decoupled look-back (state dimension <= 4) -----------------
+// The three-launch form reads x twice (24 B/sample for 16 algorithmic).  Here a wave owns a CHUNK of
+// 64 lane-blocks of OP_LB = 32 samples and keeps them in registers between the two sweeps:
+//   1. load the chunk (coalesced, transposed through LDS into lane blocks), sweep from ZERO state,
+//      in-wave scan of the 64 block states (T1 = 32-step transition; T1^(2^k) tables) -> the
+//      chunk AGGREGATE (state at its end from a zero state at its start), published with flag 1;
+//   2. state at the chunk's start: look back over the preceding chunks of the row -- lane k reads
+//      chunk c-1-k; the nearest one that has published its inclusive PREFIX (flag 2) closes the sum
+//      S_in = sum_{k<m} U^k agg_{c-1-k} + U^m prefix_{c-1-m}   (U = T1^64, powers from a table),
+//      evaluated by the 64 lanes in parallel (double-double mat-vecs) and reduced over the wave;
+//   3. publish the prefix agg_c + U S_in (flag 2); sweep again from the true block states
+//      v_{l-1} + T1^l S_in, write y (transposed back through LDS).
+// Chunks are handed out by an atomic TICKET per row (workgroup b serves row b % rows and takes that
+// row's next chunk): every predecessor a wave waits for holds a smaller ticket of the same row, i.e.
+// is already running or done, so the waits cannot deadlock; they are bounded all the same (OP_SPIN polls, then NaN).
+// Flags and states travel as device-scope atomics (no cache-wide flush): a thread's state stores
+// are acknowledged (vmcnt 0) before its flag store is issued.
+#ifndef OP_LB
+#define OP_LB 32
+#endif
+#define OP_CHUNK (64 * OP_LB)
+#ifndef OP_WAVES
+#define OP_WAVES 2
+#endif
+#define OP_SPIN (1 << 22)
+
+__device__ __forceinline__ void op_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double op_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// in-wave scan and mat-vec in plain double (hi words only): for block transitions whose powers up to
+// T1^32 have entries of order 1 (no cancellation to protect), a tenth of the double-double work
+template <int DD>
+__device__ __forceinline__ void wave_scan_plain(double (&v)[IIR_MAXD], const double* __restrict__ pw, int lane) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int d = 1 << k;
+    double u[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) u[i] = __shfl_up(v[i], d);
+    if (lane >= d) {
+      const double* M = pw + (int64_t)k * DD * DD * 2;
+#pragma unroll
+      for (int i = 0; i < DD; ++i) {
+        double acc = v[i];
+#pragma unroll
+        for (int j = 0; j < DD; ++j) acc = fma(M[(i * DD + j) * 2], u[j], acc);
+        v[i] = acc;
+      }
+    }
+  }
+}
+template <int DD>
+__device__ __forceinline__ void matvec_add_plain(double (&v)[IIR_MAXD], const double* __restrict__ M,
+                                                 const double (&c)[IIR_MAXD]) {
+#pragma unroll
+  for (int i = 0; i < DD; ++i) {
+    double acc = v[i];
+#pragma unroll
+    for (int j = 0; j < DD; ++j) acc = fma(M[(i * DD + j) * 2], c[j], acc);
+    v[i] = acc;
+  }
+}
+
+template <typename T, int NSEC, bool PLAIN>
+__global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, const T* __restrict__ in, int64_t in_stride,
+                                                  T* __restrict__ out, int64_t out_stride,
+                                                  unsigned* __restrict__ status, double* __restrict__ aggbuf,
+                                                  double* __restrict__ prefbuf, unsigned* __restrict__ ticket,
+                                                  const double* __restrict__ pw1, const double* __restrict__ lanep1,
+                                                  const double* __restrict__ lanepU, const double* __restrict__ zi,
+                                                  double* __restrict__ zf, int64_t n, int64_t nchunks, int rows,
+                                                  unsigned epoch, double pre_sub, double post_add) {
+  constexpr int DD = 2 * NSEC;
+  __shared__ T tile[64][OP_LB + 1];
+  const int lane = threadIdx.x;
+  // one ticket counter per row (64 B apart): a single counter for all rows serialises 3e5 atomics on
+  // one address -- measured 5.2 ms for the whole kernel against 3.1 ms of the three-launch form
+  const int row = (int)(blockIdx.x % (unsigned)rows);
+  unsigned t = 0;
+  if (lane == 0) t = atomicAdd(ticket + 16 * row, 1u);
+  t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+  const int64_t chunk = t;
+  if (chunk >= nchunks) return;
+  const T* x = in + (int64_t)row * in_stride + chunk * OP_CHUNK;
+  T* y = out + (int64_t)row * out_stride + chunk * OP_CHUNK;
+  const int64_t left = n - chunk * OP_CHUNK;                 // samples of this row from the chunk's start
+  const int cnt = (int)(left - (int64_t)lane * OP_LB < 0 ? 0 : (left - (int64_t)lane * OP_LB > OP_LB ? OP_LB : left - (int64_t)lane * OP_LB));
+  const bool whole = left >= OP_CHUNK;                       // wave-uniform
+
+  // ---- load: sample j = i*64 + lane of the chunk belongs to block j / OP_LB, position j % OP_LB
+#pragma unroll
+  for (int i = 0; i < OP_LB; ++i) {
+    const int64_t j = (int64_t)i * 64 + lane;
+    tile[(int)(j / OP_LB)][(int)(j % OP_LB)] = (whole || j < left) ? x[j] : (T)0;
+  }
+  __syncthreads();
+  double xr[OP_LB];
+#pragma unroll
+  for (int i = 0; i < OP_LB; ++i) xr[i] = (double)tile[lane][i] - pre_sub;
+  __syncthreads();
+
+  // ---- sweep 1: zero state -> local final state; scan over the 64 blocks
+  double z[IIR_MAXD];
+#pragma unroll
+  for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
+  if (whole) {
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, 2>(c, xr[i], z);
+  } else {
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i)
+      if (i < cnt) (void)iir_step_t<NSEC, 2>(c, xr[i], z);
+  }
+  // (a block past the end of the row leaves its state alone: T1^0; the scan below still multiplies
+  //  by T1 per block, which only matters AFTER the last sample -- nothing there is used)
+  if (PLAIN) wave_scan_plain<DD>(z, pw1, lane);
+  else wave_scan<DD>(z, pw1, DD, lane);                      // z = v_l (inclusive)
+  double vprev[DD], agg[DD];
+#pragma unroll
+  for (int i = 0; i < DD; ++i) {
+    const double up = __shfl_up(z[i], 1);
+    vprev[i] = lane == 0 ? 0.0 : up;
+    agg[i] = __shfl(z[i], 63);
+  }
+  const int64_t slot = ((int64_t)row * nchunks + chunk);
+  const unsigned F_AGG = epoch * 4u + 1u, F_PRE = epoch * 4u + 2u;
+  if (chunk > 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < DD; ++i) op_store(aggbuf + slot * DD + i, agg[i]);
+    __builtin_amdgcn_s_waitcnt(0);                           // the state is in memory before the flag is
+    __hip_atomic_store(status + slot, F_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- state at the chunk's start
+  double sin_[IIR_MAXD];
+#pragma unroll
+  for (int i = 0; i < IIR_MAXD; ++i) sin_[i] = 0.0;
+  bool poisoned = false;
+  if (chunk == 0) {
+#pragma unroll
+    for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
+  } else {
+    int64_t base = chunk - 1;                                // lane k looks at chunk base - k
+    double carry_pow_applied[1];                             // (unused placeholder keeps the loop shape simple)
+    (void)carry_pow_applied;
+    // one window of 64 predecessors; if none of them has a prefix yet, wait for the nearest one's
+    for (;;) {
+      const int64_t pc = base - lane;
+      unsigned st = 0;
+      if (pc >= 0) {
+        const unsigned* f = status + (int64_t)row * nchunks + pc;
+        int spins = 0;
+        do {
+          st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (st >= F_AGG && st <= F_PRE) break;
+          __builtin_amdgcn_s_sleep(2);
+        } while (++spins < OP_SPIN);
+        if (!(st >= F_AGG && st <= F_PRE)) { poisoned = true; st = F_PRE; }
+      }
+      const unsigned long long has_pre = __ballot(pc >= 0 && st == F_PRE);
+      if (has_pre == 0ull) {
+        // nobody within reach has a prefix: wait for the nearest predecessor's (it is computing the
+        // very same thing one chunk earlier), then take it alone
+        unsigned s1 = 0;
+        int spins = 0;
+        const unsigned* f = status + (int64_t)row * nchunks + base;
+        do {
+          s1 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (s1 == F_PRE) break;
+          __builtin_amdgcn_s_sleep(4);
+        } while (++spins < OP_SPIN);
+        if (s1 != F_PRE) poisoned = true;
+        continue;                                            // lane 0 now sees a prefix at distance 0
+      }
+      const int kstop = __ffsll((long long)has_pre) - 1;     // nearest chunk with a prefix
+      double contrib[IIR_MAXD];
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i) contrib[i] = 0.0;
+      if (lane <= kstop && pc >= 0) {
+        const double* src = (lane == kstop ? prefbuf : aggbuf) + ((int64_t)row * nchunks + pc) * DD;
+        double v[IIR_MAXD];
+#pragma unroll
+        for (int i = 0; i < IIR_MAXD; ++i) v[i] = i < DD ? op_load(src + i) : 0.0;
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < DD; ++i) contrib[i] = v[i];   // U^0
+        } else {
+          dd_matvec_add<DD>(contrib, lanepU + (int64_t)(lane - 1) * DD * DD * 2, v, DD);   // U^lane
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < DD; ++i) {
+        double sum = contrib[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        sin_[i] = sum;
+      }
+      break;
+    }
+  }
+  poisoned = __any(poisoned);
+
+  // ---- publish the inclusive prefix: agg + U * S_in
+  if (lane == 0) {
+    double so[IIR_MAXD];
+#pragma unroll
+    for (int i = 0; i < IIR_MAXD; ++i) so[i] = i < DD ? agg[i < DD ? i : 0] : 0.0;
+    dd_matvec_add<DD>(so, lanepU, sin_, DD);                 // U^1
+    if (chunk + 1 < nchunks) {
+#pragma unroll
+      for (int i = 0; i < DD; ++i) op_store(prefbuf + slot * DD + i, so[i]);
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_store(status + slot, F_PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  // ---- sweep 2 from the true block states: v_{l-1} + T1^l * S_in
+#pragma unroll
+  for (int i = 0; i < IIR_MAXD; ++i) z[i] = i < DD ? vprev[i < DD ? i : 0] : 0.0;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < DD; ++i) z[i] = sin_[i];
+  } else if (PLAIN) {
+    matvec_add_plain<DD>(z, lanep1 + (int64_t)(lane - 1) * DD * DD * 2, sin_);
+  } else {
+    dd_matvec_add<DD>(z, lanep1 + (int64_t)(lane - 1) * DD * DD * 2, sin_, DD);
+  }
+  const double bad = poisoned ? __builtin_nan("") : 0.0;
+  if (whole) {
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i) tile[lane][i] = (T)(iir_step_t<NSEC, 2>(c, xr[i], z) + post_add + bad);
+  } else {
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i)
+      if (i < cnt) tile[lane][i] = (T)(iir_step_t<NSEC, 2>(c, xr[i], z) + post_add + bad);
+  }
+  // final state of the row: the block that holds its last sample
+  if (zf && chunk == nchunks - 1) {
+    const int64_t lastblk = (left - 1) / OP_LB;
+    if (lane == lastblk)
+      for (int i = 0; i < DD; ++i) zf[(int64_t)row * DD + i] = z[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < OP_LB; ++i) {
+    const int64_t j = (int64_t)i * 64 + lane;
+    if (whole || j < left) y[j] = tile[(int)(j / OP_LB)][(int)(j % OP_LB)];
+  }
+}
+
 // state dimension 0 (every section is a bare gain): y = g (x - pre) + post
 template <typename T>
 __global__ void __launch_bounds__(256) iir_scale(const T* __restrict__ in, int64_t in_stride,
@@ -375,6 +630,19 @@ struct wfk_iir_plan {
   double* zi_tmp = nullptr;      // [batch][D_part] repacked state slices
   double* zf_tmp = nullptr;
   double gain = 1.0;             // D == 0: y = gain * (x - pre) + post
+  // single-pass form (biquad cascades with <= 4 states): chunk flags / aggregates / prefixes, ticket,
+  // and the tables of the 32-step block transition T1 and of U = T1^64
+  bool onepass = false;
+  bool op_plain = false;         // in-wave scan in plain double (entries of T1^1..T1^64 of order 1)
+  int64_t op_chunks = 0;
+  unsigned epoch = 0;
+  unsigned* op_status = nullptr;
+  unsigned* op_ticket = nullptr;
+  double* op_agg = nullptr;
+  double* op_pref = nullptr;
+  double* op_pw1 = nullptr;
+  double* op_lanep1 = nullptr;
+  double* op_lanepU = nullptr;
 };
 
 extern "C" {
@@ -384,6 +652,13 @@ int wfk_iir_plan_destroy(wfk_iir_plan* p) {
   for (wfk_iir_plan* q : p->parts) wfk_iir_plan_destroy(q);
   (void)hipFree(p->zi_tmp);
   (void)hipFree(p->zf_tmp);
+  (void)hipFree(p->op_status);
+  (void)hipFree(p->op_ticket);
+  (void)hipFree(p->op_agg);
+  (void)hipFree(p->op_pref);
+  (void)hipFree(p->op_pw1);
+  (void)hipFree(p->op_lanep1);
+  (void)hipFree(p->op_lanepU);
   (void)hipFree(p->state);
   (void)hipFree(p->grp);
   (void)hipFree(p->pw);
@@ -548,6 +823,49 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     wfk_iir_plan_destroy(p);
     return iir_fail(WFK_ENOMEM, "IIR buffer allocation failed");
   }
+  // single-pass form: one or two biquads (state dimension <= 4), rows long enough to chain
+  {
+    bool biq = n_sections <= 2;
+    for (int s2 = 0; s2 < n_sections; ++s2) biq = biq && orders[s2] == 2;
+    // OFF by default: measured 4.95 ms against 3.0 ms of the three-launch form on 64 x 1e7 (fp64, two
+    // biquads).  It does move 16 instead of 24 B/sample, but a chunk of 2048 samples is a serial
+    // pipeline -- load, sweep, scan, publish, look back (device-scope polls), sweep, store -- on a wave
+    // that holds its 32 samples per lane in registers (252 VGPRs: 2 waves per SIMD), so nothing
+    // hides its latencies; 16- and 8-sample blocks are slower still (5.6 / 10.9 ms: more look-backs
+    // per sample), and with fewer rows than waves in flight the single look-back window of 64 chunks
+    // degenerates into a serial chain (4 rows: 10.5 ms).  WFK_IIR_ONEPASS=1 selects it (tests do).
+    const char* on = getenv("WFK_IIR_ONEPASS");
+    if (biq && n >= 4 * OP_CHUNK && on && on[0] == '1') {
+      std::vector<quad> T1((size_t)D * D);
+      for (int i = 0; i < D; ++i) {
+        quad z[IIR_MAXD];
+        for (int r = 0; r < IIR_MAXD; ++r) z[r] = 0;
+        z[i] = 1;
+        for (int k = 0; k < OP_LB; ++k) quad_step(c, (quad)0, z);
+        for (int r = 0; r < D; ++r) T1[(size_t)r * D + i] = z[r];
+      }
+      std::vector<double> pw1, lanep1, pwU, lanepU;
+      const std::vector<quad> U1 = tables(T1, pw1, lanep1);    // U1 = T1^64: one chunk
+      tables(U1, pwU, lanepU);                                  // U1^(l+1), l < 64: the look-back window
+      double tmax = 0.0;                                        // largest entry of T1^1 .. T1^64 (hi words)
+      for (size_t e = 0; e < lanep1.size(); e += 2) tmax = std::max(tmax, std::fabs(lanep1[e]));
+      const char* ddenv = getenv("WFK_IIR_DD");
+      p->op_plain = tmax < 16.0 && !(ddenv && ddenv[0] == '1');
+      p->op_chunks = (n + OP_CHUNK - 1) / OP_CHUNK;
+      const size_t slots = (size_t)batch * (size_t)p->op_chunks;
+      bool ok1 = hipMalloc(&p->op_status, slots * 4) == hipSuccess &&
+                 hipMemset(p->op_status, 0, slots * 4) == hipSuccess &&
+                 hipMalloc(&p->op_ticket, (size_t)batch * 64) == hipSuccess &&
+                 hipMalloc(&p->op_agg, slots * D * 8) == hipSuccess &&
+                 hipMalloc(&p->op_pref, slots * D * 8) == hipSuccess && upload(&p->op_pw1, pw1) &&
+                 upload(&p->op_lanep1, lanep1) && upload(&p->op_lanepU, lanepU);
+      if (!ok1) {
+        wfk_iir_plan_destroy(p);
+        return iir_fail(WFK_ENOMEM, "IIR single-pass buffer allocation failed");
+      }
+      p->onepass = true;
+    }
+  }
   *out = p;
   return WFK_OK;
 }
@@ -629,6 +947,29 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
                            hipMemcpyDeviceToDevice, s) != hipSuccess)
         return iir_fail(WFK_EHIP, "IIR state repack failed");
     }
+    return WFK_OK;
+  }
+  if (p->onepass) {
+    // tickets restart at 0; the flags of earlier launches are told apart by the epoch
+    if (hipMemsetAsync(p->op_ticket, 0, (size_t)p->batch * 64, s) != hipSuccess)
+      return iir_fail(WFK_EHIP, "IIR ticket reset failed");
+    const unsigned epoch = ++p->epoch;
+    const unsigned total = (unsigned)(p->op_chunks * p->batch);
+#define OP_LAUNCH(TT, NS)                                                                                     \
+    if (p->op_plain)                                                                                          \
+    hipLaunchKernelGGL((iir_onepass<TT, NS, true>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
+                       (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
+                       p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
+                       initial, post);                                                                         \
+    else                                                                                                       \
+    hipLaunchKernelGGL((iir_onepass<TT, NS, false>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
+                       (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
+                       p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
+                       initial, post)
+    if (p->kind == WFK_OUT_F32) { if (p->c.nsec == 1) OP_LAUNCH(float, 1); else OP_LAUNCH(float, 2); }
+    else { if (p->c.nsec == 1) OP_LAUNCH(double, 1); else OP_LAUNCH(double, 2); }
+#undef OP_LAUNCH
+    if (hipGetLastError() != hipSuccess) return iir_fail(WFK_EHIP, "IIR kernel launch failed");
     return WFK_OK;
   }
   if (p->kind == WFK_OUT_F32) iir_launch<float>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, post, s);
