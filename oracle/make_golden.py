@@ -22,6 +22,7 @@ Outputs
   tests/golden/fuzz.npz           reference wav(t) for random scripts (+ fuzz_frontend.json: tolist())
   tests/golden/edges.npz          wav(x) on empty / single / off-support / non-uniform x
   tests/golden/c4_full.npz        C4 rows 0 and 7 at the full 1e7 points: sampled + FIR-filtered subsets
+  tests/golden/logic.json         marker / mask / | / & flat lists per case
   tests/golden/user.npz           scripts with Python-callable primitives (function(), function_lib=)
 """
 import json
@@ -132,6 +133,26 @@ def main():
     design['stable'] = np.array([rdist.stable_filter(f, fs) for f, fs in cases.stable_cases()])
     np.savez_compressed(os.path.join(gold, 'design.npz'), **design)
     if sys.argv[1:] == ['design']:         # regenerate this fixture only
+        return
+
+    # ---- marker / mask / | / & (host-side symbolic layer) -------------------
+    logic = {}
+    plain = [(n_, b_) for n_, (b_, _g) in cases.CASES.items() if not isinstance(b_(ref), WaveVStack)]
+    for i, (name, build) in enumerate(plain):
+        w = build(ref)
+        try:
+            logic[name] = {'marker': [enc(v) for v in w.marker.tolist()],
+                           'mask0': [enc(v) for v in w.mask().tolist()],
+                           'mask_e': [enc(v) for v in w.mask(0.37).tolist()]}
+            other = plain[(i * 7 + 3) % len(plain)][1](ref)
+            logic[name]['or'] = [enc(v) for v in (w | other).tolist()]
+            logic[name]['and'] = [enc(v) for v in (w & other).tolist()]
+            logic[name]['other'] = plain[(i * 7 + 3) % len(plain)][0]
+        except Exception as exc:
+            logic[name] = {'error': type(exc).__name__}
+    with open(os.path.join(gold, 'logic.json'), 'w') as f:
+        json.dump(logic, f)
+    if sys.argv[1:] == ['logic']:          # regenerate this fixture only
         return
 
     # ---- Python-callable primitives: function() / registerBaseFunc / function_lib= -------

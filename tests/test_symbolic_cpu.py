@@ -148,3 +148,22 @@ def test_cli_argument_parsing():
     assert a.sample_rate == 2e9 and a.stop == 1e-6
     with pytest.raises(SystemExit):
         p.parse_args(['play', 'one()'])
+
+
+def test_marker_mask_or_and_match_reference():
+    """marker / mask(edge) / | / & on every plain-Waveform case against flat lists produced by the
+    real reference (tests/golden/logic.json, oracle/make_golden.py): the window conventions of
+    mask() -- which piece of a run sets a bound -- are the reference's, quirks included."""
+    import json
+    import os
+    import cases
+    import golden_io
+    with open(os.path.join(golden_io.GOLDEN, 'logic.json')) as f:
+        gold = json.load(f)
+    assert len(gold) >= 60
+    for name, v in gold.items():
+        w = cases.CASES[name][0](wf)
+        other = cases.CASES[v['other']][0](wf)
+        for key, got in (('marker', w.marker), ('mask0', w.mask()), ('mask_e', w.mask(0.37)),
+                         ('or', w | other), ('and', w & other)):
+            assert got.tolist() == [golden_io.dec(x) for x in v[key]], (name, key)

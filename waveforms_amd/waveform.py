@@ -273,28 +273,32 @@ class Waveform:
         return Waveform(w.bounds, tuple(ZERO if e == ZERO else ONE for e in w.seq))
 
     def mask(self, edge: float = 0):
-        w = self.marker
-        bounds, seq = [], []
-        inside = w.seq[0] == ZERO
-        if w.seq[0] == ZERO:
-            inside = False
-            bounds.append(w.bounds[0] - edge)
-            seq.append(ZERO)
-        for b, e in zip(w.bounds[1:], w.seq[1:]):
-            if not inside and e != ZERO:
-                inside = True
-                bounds.append(b + edge)
-                seq.append(ONE)
-            elif inside and e == ZERO:
-                inside = False
-                b = b - edge
-                if b > bounds[-1]:
-                    bounds.append(b)
-                    seq.append(ZERO)
+        """0/1 window over the support, widened by `edge` at the rising side of a run of non-zero
+        pieces and narrowed by `edge` at the first zero piece after it (reference:
+        waveforms/waveform.py:455-482, whose conventions -- the FIRST non-zero piece of a run sets the
+        upper bound of the window, the FIRST zero piece after it the next one, piece 0 is only looked
+        at when it is zero -- are kept; pinned by tests/golden/logic.json)."""
+        from itertools import groupby
+        m = self.marker
+        live = [e != ZERO for e in m.seq]
+        out = [] if live[0] else [(m.bounds[0] - edge, ZERO)]
+        # runs of equal liveness over pieces 1..: only the first piece of a run acts.  The walk
+        # starts "outside", so a leading run of zero pieces (or of live pieces after a live piece 0
+        # -- the reference's state starts outside there too) is handled by the same two rules.
+        outside = True
+        for is_live, run in groupby(range(1, len(live)), key=live.__getitem__):
+            first = next(run)
+            if is_live and outside:
+                out.append((m.bounds[first] + edge, ONE))
+                outside = False
+            elif not is_live and not outside:
+                b = m.bounds[first] - edge
+                if b <= out[-1][0]:
+                    out[-1] = (b, out[-1][1])    # the narrowed window closes before it opened: pull its bound in
                 else:
-                    bounds.pop()
-                    bounds.append(b)
-        return Waveform(tuple(bounds), tuple(seq))
+                    out.append((b, ZERO))
+                outside = True
+        return Waveform(tuple(b for b, _ in out), tuple(e for _, e in out))
 
     def __or__(self, other):
         if isinstance(other, (int, float, complex)):
