@@ -42,12 +42,25 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
   // out ahead of the arithmetic of its neighbours, and one on the way out (inverse transform)
   // goes ahead of one on the way in, so slots free sooner
   __builtin_amdgcn_s_setprio(3);
+  // interior pairs (all but the first and the last of a row): both windows and both output blocks lie
+  // inside [0, n) -- no range checks, scalar base + lane offset + immediate addressing
+  const bool interior = s1 >= 0 && s2 + FL <= n && (b2 + 1) * (int64_t)M <= n && !accumulate;
+  if (interior) {
+    const T* p1 = row + s1 + tid;
+    const T* p2 = row + s2 + tid;
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) {
-    const int i = 256 * n1 + tid;
-    const int64_t j1 = s1 + i, j2 = s2 + i;
-    v[n1].x = (j1 >= 0 && j1 < n) ? row[j1] : (T)0;
-    v[n1].y = (j2 >= 0 && j2 < n) ? row[j2] : (T)0;
+    for (int n1 = 0; n1 < 16; ++n1) {
+      v[n1].x = p1[256 * n1];
+      v[n1].y = p2[256 * n1];
+    }
+  } else {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int i = 256 * n1 + tid;
+      const int64_t j1 = s1 + i, j2 = s2 + i;
+      v[n1].x = (j1 >= 0 && j1 < n) ? row[j1] : (T)0;
+      v[n1].y = (j2 >= 0 && j2 < n) ? row[j2] : (T)0;
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   // base twiddles loaded up front with the window (one wait), not between the passes
@@ -57,6 +70,19 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
   for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tid + 256 * k3]);
   __builtin_amdgcn_s_setprio(2);
   fft4096<true>(v, lds, wa, wb, tid);
+  if (interior) {
+    T* const o1 = orow + b1 * M + (tid - (K - 1));
+    T* const o2 = o1 + M;
+#pragma unroll
+    for (int q3 = 0; q3 < 16; ++q3) {
+      const int r = tid + 256 * q3 - (K - 1);
+      if (r >= 0 && r < M) {
+        o1[256 * q3] = v[q3].x;
+        o2[256 * q3] = v[q3].y;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int q3 = 0; q3 < 16; ++q3) {
     const int r = tid + 256 * q3 - (K - 1);
