@@ -461,8 +461,6 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
     for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
   } else {
     int64_t base = chunk - 1;                                // lane k looks at chunk base - k
-    double carry_pow_applied[1];                             // (unused placeholder keeps the loop shape simple)
-    (void)carry_pow_applied;
     // one window of 64 predecessors; if none of them has a prefix yet, wait for the nearest one's
     for (;;) {
       const int64_t pc = base - lane;
