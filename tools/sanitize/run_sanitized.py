@@ -135,6 +135,22 @@ def drive(n_scripts):
         broken(e)
         done += 1
     assert compile_(_flatten.flatten([wf.gaussian(0.5)]), grid=_flatten.wfk_grid(0.0, -1.0, 10, 0, 0.0)) < 0
+    # wfk_grid_detect walks a caller array (threaded above 2^20 elements, bisection on a probe set)
+    comp.wfk_grid_detect.argtypes = [C.c_void_p, C.c_int64, C.POINTER(_flatten.wfk_grid)]
+    g = _flatten.wfk_grid()
+    for t in (np.linspace(-1e-6, 9e-6, 10001), np.linspace(0, 3e-6, 1_300_003, endpoint=False),
+              np.arange(-1e-6, 2e-6, 1e-9), np.linspace(-7.3e-3, -7.3e-3 + 1e-5, 70001, endpoint=False),
+              np.sort(rng.uniform(0, 1, 5000)), np.zeros(17), np.linspace(0, 1, 16), np.linspace(0, 1, 15)):
+        t = np.ascontiguousarray(t)
+        rc = comp.wfk_grid_detect(t.ctypes.data, len(t), C.byref(g))
+        assert rc in (0, 1)
+        if rc == 1:
+            assert np.array_equal(_flatten.grid_values(g), t)
+        bad_t = t.copy()
+        if len(bad_t) > 20:
+            bad_t[len(bad_t) // 2] = np.nextafter(bad_t[len(bad_t) // 2], np.inf)
+            assert comp.wfk_grid_detect(bad_t.ctypes.data, len(bad_t), C.byref(g)) == 0 or not np.all(np.diff(t) > 0)
+        done += 1
     print(f'sanitized run clean: {done} programs through wfk_compile (ASan+UBSan), oracle C alongside')
 
 

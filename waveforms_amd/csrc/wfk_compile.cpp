@@ -944,8 +944,7 @@ struct GridProbe {
     int64_t at_[nt];
     for (int k = 0; k < nt; ++k) at_[k] = -1;
     std::vector<std::thread> th;
-    for (int k = 0; k < nt; ++k)
-      th.emplace_back([&, k] {
+    auto work = [&](int k) {
         const int64_t a = count * k / nt, b = count * (k + 1) / nt;
         // blocks of 64k so that a thread stops early once an earlier mismatch is known
         for (int64_t s0 = a; s0 < b && s0 < worst.load(std::memory_order_relaxed); s0 += 65536) {
@@ -957,7 +956,14 @@ struct GridProbe {
             break;
           }
         }
-      });
+    };
+    // (no exception may cross the C boundary: if threads cannot be had the slices run here)
+    int started = 0;
+    try {
+      for (; started < nt - 1; ++started) th.emplace_back(work, started);
+    } catch (...) {
+    }
+    for (int k = started; k < nt; ++k) work(k);
     for (auto& x : th) x.join();
     for (int k = 0; k < nt; ++k)
       if (at_[k] >= 0) { if (sign) *sign = signs[k]; return at_[k]; }   // lowest thread = lowest index
