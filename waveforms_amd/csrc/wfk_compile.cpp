@@ -97,6 +97,8 @@ struct FceGroup {
   int deg = 0, nterms = 0;
   bool imag = false;            // the group adds to the IMAGINARY part of the output
   bool envmul = false;          // pseudo-op: multiply the accumulators by the shared Gaussian envelope
+  bool erfmul = false;          // pseudo-op: multiply them by m0 + m1 erf((t - sg) / sigma) (flat-top edge)
+  double m0 = 0, m1 = 1;
   bool corr = false;            // carrier needs the per-sample rounding correction (WFK_FCE_PACK bit 7)
   double wm = 0, sm = 0;        // corr: the reference COS factor (w, shift) whose rounded phase fl(w*fl(x-shift)) is mimicked
 };
@@ -455,8 +457,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const char* nofuse_env = std::getenv("WFK_DISABLE_FUSE");
   const bool can_fuse = !H.tlist && !nofast && !(nofuse_env && nofuse_env[0] == '1');
 
+  const char* noerf_env = std::getenv("WFK_DISABLE_ERFMUL");
+  const bool erfmod = can_fuse && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
+
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
-                       int64_t s1) -> bool {
+                       int64_t s1, int32_t skip = -1) -> bool {   // skip: a factor handled by the caller
     // a complex amplitude a + ib contributes a * (...) to the real part and b * (...) to the
     // imaginary part of the output: two real-coefficient contributions, the second into groups
     // marked `imag` (their op accumulates into the imaginary accumulators)
@@ -486,6 +491,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       return true;
     };
     for (int32_t f = f0; f < f1; ++f) {
+      if (f == skip) continue;
       const double pw = P->fc_power[f], sh = P->fc_shift[f];
       const double* a = P->pool + P->fc_arg_off[f];
       switch (P->fc_type[f]) {
@@ -663,6 +669,27 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       sref = (double)((long double)G.sref + phi / (long double)G.W);
       A0 = R; B0 = 0.0L;
     }
+    if (G.erfmul) {
+      // closing erf multiplier (wfk_kernels.hip: fce_erfmul): step series about the midpoint,
+      //   2/sqrt(pi) [h + H2 h^3/24 + H4 h^5/1920 + H6 h^7/322560] as a cubic in w = vm^2
+      const long double h = (long double)dstride / G.sigma;
+      const long double c = 2.0L * h / sqrtl(3.141592653589793238462643383279502884L);
+      const long double a2 = h * h / 24, a4 = h * h * h * h / 1920, a6 = h * h * h * h * h * h / 322560;
+      rec[0] = WFK_OP_FCE;
+      rec[WFK_FCE_DEG] = (double)WFK_FCE_PACK(1, 0, 0, 3, 0);
+      rec[WFK_FCE_A] = G.m0; rec[WFK_FCE_A + 1] = G.m1;
+      rec[WFK_FCE_B] = (double)(c * (1 - 2 * a2 + 12 * a4 - 120 * a6));
+      rec[WFK_FCE_B + 1] = (double)(c * (4 * a2 - 48 * a4 + 720 * a6));
+      rec[WFK_FCE_B + 2] = (double)(c * (16 * a4 - 480 * a6));
+      rec[WFK_FCE_B + 3] = (double)(c * 64 * a6);
+      rec[WFK_FCE_SIGMA] = G.sigma; rec[WFK_FCE_SG] = G.sg;
+      rec[WFK_FCE_H] = (double)h; rec[WFK_FCE_Q] = (double)expl(-2.0L * h * h);
+      rec[WFK_FCE_D] = dstride;
+      const size_t at = B.body.size();
+      B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
+      B.fce_ats.push_back(at);
+      return;
+    }
     rec[0] = WFK_OP_FCE;
     rec[WFK_FCE_W] = G.W;
     rec[WFK_FCE_SREF] = sref;
@@ -771,16 +798,97 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
                              [&](int32_t x, int32_t y) { return weight_of(x) > weight_of(y); });
           }
         }
+        // Terms with ONE erf factor (the edge of a flat-top pulse: square(width, edge), 0.5 + 0.5 erf)
+        // whose other factors fuse: the rest goes into a second group list, and a closing op multiplies
+        // what those groups accumulated by the erf (advanced by its own Taylor step, see emit_group);
+        // the unmodulated groups follow it.  One erf (sigma, shift) per piece.
+        std::vector<FceGroup> mgroups;
+        bool mod_on = false;
+        double mod_sigma = 0, mod_shift = 0;
+        auto erf_factor_of = [&](int32_t k, double& sg_out, double& sh_out) -> int32_t {
+          if (!erfmod) return -1;
+          int32_t at = -1;
+          for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
+            if (P->fc_type[f] == WFK_ERF) {
+              if (at >= 0 || P->fc_power[f] != 1.0) return -1;
+              at = f;
+            }
+          if (at < 0) return -1;
+          const double sg = P->pool[P->fc_arg_off[at]], sh = P->fc_shift[at];
+          if (!std::isfinite(sg) || sg == 0.0 || !std::isfinite(sh)) return -1;
+          if (!(std::fabs(dstride / sg) <= 0.09) || !rate_safe(1.13 / sg, s0, s1)) return -1;
+          bool ok64, ok32;
+          gauss_range(sg, sh, C.tshift, s0, s1, ok64, ok32);
+          if (!ok64) return -1;
+          if (mod_on && (mod_sigma != sg || mod_shift != sh)) return -1;
+          sg_out = sg; sh_out = sh;
+          return at;
+        };
         for (int32_t k : order) {
           if (P->tm_amp_im[k] != 0.0) H.channel_complex[c] = 1;
-          if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
+          double esg = 0, esh = 0;
+          const int32_t fe = can_fuse ? erf_factor_of(k, esg, esh) : -1;
+          if (fe >= 0 && fuse_term(mgroups, k, C.tshift, s0, s1, fe)) {
+            mod_on = true; mod_sigma = esg; mod_shift = esh;
+            ++H.n_fused;
+          } else if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
           else generic.push_back(k);
+        }
+        if (mod_on) {
+          // out = S0 + erf S1.  Where every group of S1 has a twin in S0 with the same coefficients
+          // times ONE ratio rho (0.5 cos + 0.5 erf cos), the twins go: out = (rho + erf) S1 + rest.
+          FceGroup E;
+          E.erfmul = true; E.sigma = mod_sigma; E.sg = mod_shift; E.m0 = 0.0; E.m1 = 1.0;
+          std::vector<int> twin(mgroups.size(), -1);
+          bool all = !groups.empty();
+          long double rho = 0;
+          for (size_t i = 0; i < mgroups.size() && all; ++i) {
+            const FceGroup& m = mgroups[i];
+            int big = -1;                       // the largest coefficient of the modulated group
+            long double bigv = 0;
+            for (int j = 0; j < 8; ++j) {
+              const long double v = fabsl(j < 4 ? m.A[j] : m.B[j - 4]);
+              if (v > bigv) { bigv = v; big = j; }
+            }
+            if (big < 0) { all = false; break; }
+            for (size_t j = 0; j < groups.size() && twin[i] < 0; ++j) {
+              const FceGroup& g = groups[j];
+              if (std::find(twin.begin(), twin.end(), (int)j) != twin.end()) continue;
+              if (g.W != m.W || g.imag != m.imag || g.has_env != m.has_env || g.sigma != m.sigma || g.sg != m.sg ||
+                  g.sref != m.sref || g.psi_ref != m.psi_ref || g.has_lin != m.has_lin || g.slin != m.slin ||
+                  g.deg != m.deg || g.corr != m.corr || g.wm != m.wm || g.sm != m.sm)
+                continue;
+              const long double r = (big < 4 ? g.A[big] : g.B[big - 4]) / (big < 4 ? m.A[big] : m.B[big - 4]);
+              bool same = true;
+              for (int q = 0; q < 8 && same; ++q) {
+                const long double gv = q < 4 ? g.A[q] : g.B[q - 4], mv = q < 4 ? m.A[q] : m.B[q - 4];
+                same = fabsl(gv - r * mv) <= 1e-14L * fabsl(r) * bigv;
+              }
+              if (same && (i == 0 || fabsl(r - rho) <= 1e-14L * fabsl(rho))) {
+                if (i == 0) rho = r;
+                twin[i] = (int)j;
+              }
+            }
+            all = twin[i] >= 0;
+          }
+          if (all && std::isfinite((double)rho)) {
+            std::vector<bool> gone(groups.size(), false);
+            for (int j : twin) gone[(size_t)j] = true;
+            std::vector<FceGroup> rest;
+            for (size_t j = 0; j < groups.size(); ++j)
+              if (!gone[j]) rest.push_back(groups[j]);
+            groups.swap(rest);
+            E.m0 = (double)rho;
+          }
+          mgroups.push_back(E);
+          mgroups.insert(mgroups.end(), groups.begin(), groups.end());
+          groups.swap(mgroups);
         }
         // When every carrier of the piece sits under the SAME Gaussian (a frequency-multiplexed
         // pulse), the envelope is factored out: the ops run without envelope and one closing
         // pseudo-op multiplies the accumulators by it -- 2 instead of 5 FMAs per sample and tone.
         // (From four carriers on: the extra op costs a pair of pieces what it saves them.)
-        if (groups.size() >= 4) {
+        if (groups.size() >= 4 && !mod_on) {
           bool shared = true, e32 = true;
           for (const FceGroup& g : groups) {
             shared = shared && g.has_env && g.sigma == groups[0].sigma && g.sg == groups[0].sg;

@@ -397,8 +397,12 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   // one address -- measured 5.2 ms for the whole kernel against 3.1 ms of the three-launch form
   const int row = (int)(blockIdx.x % (unsigned)rows);
   unsigned t = 0;
+#if defined(OP_PROBE) && OP_PROBE >= 4
+  t = blockIdx.x / (unsigned)rows;
+#else
   if (lane == 0) t = atomicAdd(ticket + 16 * row, 1u);
   t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+#endif
   const int64_t chunk = t;
   if (chunk >= nchunks) return;
   const T* x = in + (int64_t)row * in_stride + chunk * OP_CHUNK;
@@ -407,6 +411,16 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   const int cnt = (int)(left - (int64_t)lane * OP_LB < 0 ? 0 : (left - (int64_t)lane * OP_LB > OP_LB ? OP_LB : left - (int64_t)lane * OP_LB));
   const bool whole = left >= OP_CHUNK;                       // wave-uniform
 
+#if defined(OP_PROBE) && OP_PROBE == 5
+  {
+    T v[OP_LB];
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i) { const int64_t j = (int64_t)i * 64 + lane; v[i] = (whole || j < left) ? x[j] : (T)0; }
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i) { const int64_t j = (int64_t)i * 64 + lane; if (whole || j < left) y[j] = v[i] + (T)post_add; }
+    return;
+  }
+#endif
   // ---- load: sample j = i*64 + lane of the chunk belongs to block j / OP_LB, position j % OP_LB
 #pragma unroll
   for (int i = 0; i < OP_LB; ++i) {
@@ -419,6 +433,17 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   for (int i = 0; i < OP_LB; ++i) xr[i] = (double)tile[lane][i] - pre_sub;
   __syncthreads();
 
+#if defined(OP_PROBE) && (OP_PROBE == 1 || OP_PROBE == 4)
+#pragma unroll
+  for (int i = 0; i < OP_LB; ++i) tile[lane][i] = (T)(xr[i] + post_add);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < OP_LB; ++i) {
+    const int64_t j = (int64_t)i * 64 + lane;
+    if (whole || j < left) y[j] = tile[(int)(j / OP_LB)][(int)(j % OP_LB)];
+  }
+  return;
+#endif
   // ---- sweep 1: zero state -> local final state; scan over the 64 blocks
   double z[IIR_MAXD];
 #pragma unroll
@@ -444,7 +469,12 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   }
   const int64_t slot = ((int64_t)row * nchunks + chunk);
   const unsigned F_AGG = epoch * 4u + 1u, F_PRE = epoch * 4u + 2u;
-  if (chunk > 0 && lane == 0) {
+#if defined(OP_PROBE) && OP_PROBE == 2
+  const bool publish = false;
+#else
+  const bool publish = true;
+#endif
+  if (publish && chunk > 0 && lane == 0) {
 #pragma unroll
     for (int i = 0; i < DD; ++i) op_store(aggbuf + slot * DD + i, agg[i]);
     __builtin_amdgcn_s_waitcnt(0);                           // the state is in memory before the flag is
@@ -456,7 +486,11 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
   for (int i = 0; i < IIR_MAXD; ++i) sin_[i] = 0.0;
   bool poisoned = false;
+#if defined(OP_PROBE) && (OP_PROBE == 2 || OP_PROBE == 3)
+  if (true) {
+#else
   if (chunk == 0) {
+#endif
 #pragma unroll
     for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
   } else {
@@ -524,7 +558,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
     for (int i = 0; i < IIR_MAXD; ++i) so[i] = i < DD ? agg[i < DD ? i : 0] : 0.0;
     dd_matvec_add<DD>(so, lanepU, sin_, DD);                 // U^1
-    if (chunk + 1 < nchunks) {
+    if (publish && chunk + 1 < nchunks) {
 #pragma unroll
       for (int i = 0; i < DD; ++i) op_store(prefbuf + slot * DD + i, so[i]);
       __builtin_amdgcn_s_waitcnt(0);

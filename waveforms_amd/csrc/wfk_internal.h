@@ -77,7 +77,7 @@
 // "lean" plans: every piece is one block of <= WFK_LEAN_OPS fused ops and nothing else.
 // They run on the wave-per-workgroup kernel that carries per-lane op state across tiles.
 #ifndef WFK_LEAN_OPS
-#define WFK_LEAN_OPS 10       // upper limit (beyond it the occupancy the 2 KB of state per op costs outweighs
+#define WFK_LEAN_OPS 11       // upper limit (beyond it the occupancy the 2 KB of state per op costs outweighs
                               // the state carry: 16 tones measured 7.9 ms lean vs 5.8 ms general); LDS is
                               // reserved for what the plan actually has
 #endif

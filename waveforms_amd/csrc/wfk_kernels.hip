@@ -512,7 +512,7 @@ __device__ __attribute__((noinline)) FceSeeds fce_seeds(double theta, double the
 #pragma clang fp contract(off)   // see sincos_phase(): the explicit fma()s below must stay the only ones
   FceSeeds o;
   o.c = 1.0; o.s = 0.0; o.g = 1.0; o.r = 1.0;
-  if (carrier) {
+  if (carrier == 1) {
     // phase = theta + theta_lo (the low word is the rounding error of the product W * (x - s_ref),
     // passed by the kernels that correct per sample and therefore need the EXACT seed phase)
     const double IPI_HI = 0.31830988618379069, IPI_LO = -1.9678676675182486e-17;
@@ -525,6 +525,7 @@ __device__ __attribute__((noinline)) FceSeeds fce_seeds(double theta, double the
     o.s = odd ? -ss : ss;
     o.c = odd ? -cc : cc;
   }
+  if (carrier == 2) o.c = erf(theta);   // closing erf multiplier: the running value E = erf(v)
   if (env) {
     o.g = exp(ea);
     o.r = exp(eb);
@@ -684,7 +685,14 @@ __device__ __forceinline__ void fce_env(const double2* tab, const double* r, Fce
 // `fl`: the op's packed word (WFK_FCE_DEG), read once by the caller
 template <bool EXACT = false>
 __device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x, int fl) {
-  const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
+  double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA];
+  const double Hh = r[WFK_FCE_H];
+  if ((fl & 0x33) == 0x31) {
+    // closing erf multiplier: E = erf(v) at the sample, the Gaussian state half a stride further on
+    // (the midpoint of the first step, see fce_erfmul)
+    const double vm = v + 0.5 * Hh;
+    return fce_seeds(v, 0.0, -(vm * vm), -Hh * (2.0 * vm + Hh), 2, 1);
+  }
   const double sref = r[WFK_FCE_SREF], W = r[WFK_FCE_W];
   const double d = x - sref;
   const double th = W * d;
@@ -740,6 +748,38 @@ __device__ __forceinline__ void fce_envmul(const double* r, FceSeeds& sd, T (&ac
     g *= rr;
     rr *= q;
   WFK_END
+  sd.g = g;
+  sd.r = rr;
+}
+
+// closing pseudo-op "erf edge" (env == 3, deg == 1): everything accumulated so far is multiplied by
+//   M_k = m0 + m1 erf(v_k),  v_k = (x_k - s) / sigma,  v_{k+1} = v_k + h  (h = lane stride / sigma)
+// -- the flat-top pulse's edge, 0.5 + 0.5 erf, over its carriers.  erf advances by its own integral:
+//   erf(v + h) - erf(v) = 2/sqrt(pi) exp(-vm^2) * [h + H2(vm) h^3/24 + H4(vm) h^5/1920 + H6(vm) h^7/322560 + ...]
+// about the MIDPOINT vm = v + h/2 (odd orders vanish; Hn = Hermite polynomials), the Gaussian at the
+// midpoints from the same two-multiplier recurrence the envelopes use and the bracket as a cubic
+// in w = vm^2 with host-made coefficients (B0..B3).  Nine fp64 operations per sample instead of a
+// libm erf (~100); the host admits the op for |h| <= 0.09 only, where the first neglected term is
+// below 8e-15 per step (the state is reseeded exactly every WFK_LEAN_RESEED tiles).
+template <typename T, int NS, bool CPLX>
+__device__ __forceinline__ void fce_erfmul(const double* r, FceSeeds& sd, double x, T (&acc)[NS],
+                                           T (&acci)[CPLX ? NS : 1]) {
+  double E = sd.c, g = sd.g, rr = sd.r;
+  const double q = r[WFK_FCE_Q], h = r[WFK_FCE_H];
+  const double m0 = r[WFK_FCE_A], m1 = r[WFK_FCE_A + 1];
+  const double p0 = r[WFK_FCE_B], p1 = r[WFK_FCE_B + 1], p2 = r[WFK_FCE_B + 2], p3 = r[WFK_FCE_B + 3];
+  double vm = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA] + 0.5 * h;
+  WFK_EACH(NS, k)
+    const T m = (T)fma(m1, E, m0);
+    acc[k] *= m;
+    if constexpr (CPLX) acci[k] *= m;
+    const double w = vm * vm;
+    E = fma(g, fma(fma(fma(p3, w, p2), w, p1), w, p0), E);
+    g *= rr;
+    rr *= q;
+    vm += h;
+  WFK_END
+  sd.c = E;
   sd.g = g;
   sd.r = rr;
 }
@@ -954,7 +994,8 @@ wfk_sample_lean(const KArgs a) {
           // launch of such a channel keeps the real part only, like WaveVStack's `.real`
           const int fl = uni((int)rec[WFK_FCE_DEG]);     // packed op word: one read for all flags
           if (((fl >> 4) & 3) == 3) {
-            fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
+            if (fl & 3) fce_erfmul<T, NS, CPLX>(rec, sd, x, acc, acci);
+            else fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
           } else if (fl & 8) {
             if constexpr (CPLX) fce_eval<T, NS, CORR>(s_par, rec, sd, x, true, acci, fl, &cc);
           } else {
@@ -1047,7 +1088,8 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
                 double x = grid_time(a, j0);
                 if (C.tshift != 0.0) x = x - C.tshift;
                 FceSeeds sd = fce_make_seeds(s_par + pos, x, fl);
-                fce_envmul<T, NS, CPLX>(s_par + pos, sd, acc, acci);
+                if (fl & 3) fce_erfmul<T, NS, CPLX>(s_par + pos, sd, x, acc, acci);
+                else fce_envmul<T, NS, CPLX>(s_par + pos, sd, acc, acci);
               } else if (fl & 8) {
                 if constexpr (CPLX) apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acci);
               } else {
