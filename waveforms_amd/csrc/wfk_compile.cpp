@@ -110,6 +110,7 @@ struct BlockBuilder {
   std::vector<size_t> fce_ats;                      // body index of every fused-op record (packed word fix-up)
   std::map<double, int> table_of_w;               // dedupe COS tables by dphase
   int n_terms = 0;                                // ops in this block
+  int state_units = 0;                            // lean kernel: per-lane state handed out so far (128 doubles each)
   size_t size() const { return WFK_BLK_HDR + body.size() + tables.size() + 1; }
 };
 
@@ -685,6 +686,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       rec[WFK_FCE_SIGMA] = G.sigma; rec[WFK_FCE_SG] = G.sg;
       rec[WFK_FCE_H] = (double)h; rec[WFK_FCE_Q] = (double)expl(-2.0L * h * h);
       rec[WFK_FCE_D] = dstride;
+      rec[WFK_FCE_DEG] += (double)((B.state_units << 19) | WFK_FCE_HAS_CS | WFK_FCE_HAS_GR);
+      B.state_units += 2;
       const size_t at = B.body.size();
       B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
       B.fce_ats.push_back(at);
@@ -710,6 +713,16 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
     }
     rec[WFK_FCE_D] = dstride;
+    {
+      // per-lane state of the lean kernel: a phasor (c, s) and / or a Gaussian (g, r), 1 KB each
+      const bool cs = G.W != 0.0, gr = G.has_env || G.envmul;
+      if (B.state_units + (cs ? 1 : 0) + (gr ? 1 : 0) <= 63) {
+        rec[WFK_FCE_DEG] += (double)((B.state_units << 19) | (cs ? WFK_FCE_HAS_CS : 0) | (gr ? WFK_FCE_HAS_GR : 0));
+        B.state_units += (cs ? 1 : 0) + (gr ? 1 : 0);
+      } else {
+        B.state_units = 1000;   // (a block this large is never lean)
+      }
+    }
     size_t at = B.body.size();
     B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
     B.fce_ats.push_back(at);
@@ -903,10 +916,12 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         }
         piece_lean = generic.empty() && !groups.empty() && groups.size() <= WFK_LEAN_OPS;
         const int32_t piece_ops = (int32_t)groups.size();
+        int32_t piece_units = 0;
         for (FceGroup& G : groups) {
           if (room_for(WFK_FCE_REC + 2 * (NS + 1)) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
           emit_group(B, G);
           ++B.n_terms;
+          piece_units = B.state_units;
         }
         // pass 2: whatever is left, factor by factor
         for (int32_t k : generic) {
@@ -928,7 +943,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         int32_t len = flush_block(B);
         if (D.n_blk == 0) D.first_len = len;
         ++D.n_blk;
-        piece_lean = piece_lean && D.n_blk == 1 && len <= lean_par_cap;
+        piece_lean = piece_lean && D.n_blk == 1 && len <= lean_par_cap && piece_units <= 63;
+        (void)piece_ops;
         if (!piece_lean && H.n_corr > corr_before && attempt == 0) {
           // roll back and build the piece again without corrected carriers
           H.params.resize(snap.params); H.pool.resize(snap.pool);
@@ -941,7 +957,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         if (piece_lean) {
           D.flags |= WFK_PF_LEAN;
           ++n_lean_pieces;
-          H.lean_ops = std::max<int32_t>(H.lean_ops, piece_ops);
+          H.lean_ops = std::max<int32_t>(H.lean_ops, piece_units);
           H.lean_par = std::max<int32_t>(H.lean_par, len);
         } else {
           lean_ok = false;
@@ -971,7 +987,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.mixed = !H.lean && can_fuse && !nolean && n_lean_pieces > 0 && ns_override == 0 &&
             !(nomix_env && nomix_env[0] == '1');
   H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
-  H.lean_ops = std::max(4, H.lean_ops);                          // likewise: 4 ops = 8 KB of state
+  H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
   auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
                       std::vector<int32_t>& chunk_first) {
     // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles

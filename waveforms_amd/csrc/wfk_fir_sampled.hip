@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
         if (env == 3) {
           chain_envmul<T, CL, KC>(rec, sd, acc, klo, khi, nx);
         } else {
-          const double2* tab = carrier ? reinterpret_cast<const double2*>(s_par + (fl >> 8)) : unit_tab;
+          const double2* tab = carrier ? reinterpret_cast<const double2*>(s_par + WFK_FCE_TABOFF(fl)) : unit_tab;
           const double qq = env ? rec[WFK_FCE_Q] : 1.0;
           const double u0 = x - rec[WFK_FCE_SLIN];
           // (the common shapes -- whole chain inside the piece, polynomials of degree <= 1: a

@@ -49,7 +49,13 @@
 #define WFK_FCE_DEG 4         // PACKED op word (one LDS read instead of five dependent ones per op and tile):
                               // deg (bits 0-1) | carrier << 2 | imag << 3 | env << 4 (2 bits) | f32ok << 6 |
                               // corr << 7 (per-sample grid-rounding correction of the carrier) | table offset << 8
+                              // (11 bits) | state offset << 19 (6 bits, units of 128 doubles of the lean kernel's
+                              // per-lane state) | has (c, s) state << 25 | has (g, r) state << 26
 #define WFK_FCE_PACK(deg, carrier, imag, env, f32ok) ((deg) | ((carrier) << 2) | ((imag) << 3) | ((env) << 4) | ((f32ok) << 6))
+#define WFK_FCE_TABOFF(fl) (((fl) >> 8) & 0x7FF)
+#define WFK_FCE_STOFF(fl) ((((fl) >> 19) & 63) * 128)
+#define WFK_FCE_HAS_CS (1 << 25)
+#define WFK_FCE_HAS_GR (1 << 26)
 #define WFK_FCE_A 5           // A0..A3
 #define WFK_FCE_B 9           // B0..B3
 #define WFK_FCE_WM 13         // corr ops: |w| of the reference COS factor whose rounded phase is mimicked
@@ -77,14 +83,17 @@
 // "lean" plans: every piece is one block of <= WFK_LEAN_OPS fused ops and nothing else.
 // They run on the wave-per-workgroup kernel that carries per-lane op state across tiles.
 #ifndef WFK_LEAN_OPS
-#define WFK_LEAN_OPS 11       // upper limit (beyond it the occupancy the 2 KB of state per op costs outweighs
-                              // the state carry: 16 tones measured 7.9 ms lean vs 5.8 ms general); LDS is
-                              // reserved for what the plan actually has
+#define WFK_LEAN_OPS 15       // upper limit; LDS is reserved for what the plan actually has: 1 KB per op for a
+                              // phasor (c, s), 1 KB for a Gaussian / erf state (g, r).  Same-box A/B of 11 vs
+                              // 17 (64 x 1e7, Gaussian pulses under N tones): 12 tones 4.0 vs 3.4 ms, 14 tones
+                              // 4.5 vs 4.2, 16 tones 5.0 vs 5.3 -- the general kernel wins from 16 on
 #endif
 // doubles of LDS parameter buffer per wave: header + 4 ops x (22 record + 34 table) = 232.
 // With the 8 KB of per-lane op state that makes 10 KB per wave = 16 waves per CU, which the
 // fp32 kernel (<= 128 VGPRs) uses: 2.11 -> 1.95 ms on 256 x 1e7 fp32 against 512 doubles.
-#define WFK_LEAN_PAR 640      // upper limit (10 ops x 56 doubles + header), reserved per plan as needed
+#ifndef WFK_LEAN_PAR
+#define WFK_LEAN_PAR 896      // upper limit (15 ops x 56 doubles + header), reserved per plan as needed
+#endif
 #define WFK_CHAIN_PAR 2048    // sampler inside the FIR transform: largest parameter block (doubles); it is staged
                               // in the transform's exchange array (18.5 KB in the float kernel)
 #define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles
@@ -123,7 +132,7 @@ struct KArgs {
   int32_t accumulate;
   double t0, step, last;
   int32_t has_last, pad;
-  int32_t lean_par, lean_ops;  // lean kernel: doubles of parameter block / ops of state to reserve in LDS
+  int32_t lean_par, lean_ops;  // lean kernel: doubles of parameter block / units (128 doubles) of op state to reserve in LDS
   int32_t corr;                // plan holds carriers that need the grid-rounding correction (lean kernel variant)
   int32_t mixed;               // mixed plan: the lean kernel skips the pieces without WFK_PF_LEAN, the general
                                // kernel skips the lean and the zero pieces (two launches, one output)
@@ -156,7 +165,7 @@ struct HostPlan {
   int32_t lean_tile = 0, lean_tiles_per_chunk = 1;   // mixed: the lean launch's own chunking
   int64_t lean_chunks_per_ch = 0;
   std::vector<int32_t> lean_chunk_first;
-  int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most ops of a piece
+  int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most state units (128 doubles) of a piece
 };
 
 // host compiler: flattened program + time axis -> device tables.  Returns 0 or a

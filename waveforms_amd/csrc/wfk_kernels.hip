@@ -715,7 +715,7 @@ __device__ __forceinline__ void fce_eval(const double* blk, const double* r, Fce
   const int carrier = (fl >> 2) & 1;
   int env = (fl >> 4) & 3;
   if (env && sizeof(T) == 4 && (wide_env || ((fl >> 6) & 1) == 0)) env = 2;
-  const double2* tab = reinterpret_cast<const double2*>(blk + (fl >> 8));
+  const double2* tab = reinterpret_cast<const double2*>(blk + WFK_FCE_TABOFF(fl));
   const double u0 = x - r[WFK_FCE_SLIN];
   if constexpr (CORR && sizeof(T) == 8) {
     if (carrier && ((fl >> 7) & 1)) {   // this carrier's phase feels the grid rounding
@@ -905,7 +905,7 @@ wfk_sample_lean(const KArgs a) {
   // takes 25 KB instead of falling back to the general kernel.
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double* const s_par = s_dyn;
-  double* const s_st = s_dyn + a.lean_par;      // [op][c | s | g | r][64]
+  double* const s_st = s_dyn + a.lean_par;      // per op: [c | s][64] and / or [g | r][64] (WFK_FCE_STOFF)
   constexpr int WT = 64 * NS;
   using OutR = typename OutOps<T>::Real;
   using OutC = typename OutOps<T>::Cplx;
@@ -961,12 +961,18 @@ wfk_sample_lean(const KArgs a) {
           // seed phase: libm, nothing else live
           for (int op = 0; op < nops; ++op) {
             const double* srec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
-            const FceSeeds sd = fce_make_seeds<CORR>(srec, x, uni((int)srec[WFK_FCE_DEG]));
-            double* st = s_st + op * 256 + lane;
-            st[0] = sd.c;
-            st[64] = sd.s;
-            st[128] = sd.g;
-            st[192] = sd.r;
+            const int sfl = uni((int)srec[WFK_FCE_DEG]);
+            const FceSeeds sd = fce_make_seeds<CORR>(srec, x, sfl);
+            double* st = s_st + WFK_FCE_STOFF(sfl) + lane;
+            if (sfl & WFK_FCE_HAS_CS) {
+              st[0] = sd.c;
+              st[64] = sd.s;
+              st += 128;
+            }
+            if (sfl & WFK_FCE_HAS_GR) {
+              st[0] = sd.g;
+              st[64] = sd.r;
+            }
           }
           since_seed = 0;
         }
@@ -984,15 +990,19 @@ wfk_sample_lean(const KArgs a) {
         }
         for (int op = 0; op < nops; ++op) {
           FceSeeds sd;
-          double* st = s_st + op * 256 + lane;
-          sd.c = st[0];
-          sd.s = st[64];
-          sd.g = st[128];
-          sd.r = st[192];
           const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
           // an op of the imaginary part (complex amplitudes) adds into acci; a real-output
           // launch of such a channel keeps the real part only, like WaveVStack's `.real`
           const int fl = uni((int)rec[WFK_FCE_DEG]);     // packed op word: one read for all flags
+          // per-lane state: (c, s) and / or (g, r), 64 doubles each, only what the op has
+          double* const st = s_st + WFK_FCE_STOFF(fl) + lane;
+          double* const stg = st + ((fl & (WFK_FCE_HAS_CS | WFK_FCE_HAS_GR)) == (WFK_FCE_HAS_CS | WFK_FCE_HAS_GR) ? 128 : 0);
+          // (all four loads issue at once whatever the op has: a pair it lacks reads the pair it has,
+          //  and is never used or written back)
+          sd.c = st[0];
+          sd.s = st[64];
+          sd.g = stg[0];
+          sd.r = stg[64];
           if (((fl >> 4) & 3) == 3) {
             if (fl & 3) fce_erfmul<T, NS, CPLX>(rec, sd, x, acc, acci);
             else fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
@@ -1001,10 +1011,14 @@ wfk_sample_lean(const KArgs a) {
           } else {
             fce_eval<T, NS, CORR>(s_par, rec, sd, x, true, acc, fl, &cc);
           }
-          st[0] = sd.c;
-          st[64] = sd.s;
-          st[128] = sd.g;
-          st[192] = sd.r;
+          if (fl & WFK_FCE_HAS_CS) {
+            st[0] = sd.c;
+            st[64] = sd.s;
+          }
+          if (fl & WFK_FCE_HAS_GR) {
+            stg[0] = sd.g;
+            stg[64] = sd.r;
+          }
         }
         state_piece = q;
         state_w0 = w0 + WT;
@@ -1132,7 +1146,7 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
   const dim3 g((unsigned)blocks), b(WFK_WG);
   if constexpr (!TLIST) {   // (the lean kernel exists for grid plans only)
     if (lean) {
-      const size_t lds = (size_t)(a.lean_par + 256 * a.lean_ops) * sizeof(double);
+      const size_t lds = (size_t)(a.lean_par + 128 * a.lean_ops) * sizeof(double);
       if constexpr (sizeof(T) == 8) {
         if (a.corr) {
           hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, true>), g, dim3(64), lds, s, a);
