@@ -16,6 +16,12 @@ OUT=gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT" gpurun_out/profiles
 export TMPDIR=/tmp
 ARGS="bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline --no-also"   # (--no-also: the c2 / c3 / c4 legs of the default line run the same kernel symbols; each is profiled by its own workload)
+# stage benches outside bench.py (their own scripts): iir, readout, multitone
+case "$WL" in
+  iir) ARGS="tools/iir_bench.py" ;;
+  readout) ARGS="tools/readout_bench.py" ;;
+  multitone) ARGS="tools/multitone_bench.py 10" ;;
+esac
 echo "== stats pass ($WL)"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/stats.log" 2>&1
 for grp in WRITE_SIZE FETCH_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
