@@ -422,10 +422,24 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   }
 #endif
   // ---- load: sample j = i*64 + lane of the chunk belongs to block j / OP_LB, position j % OP_LB
+  // (a whole chunk loads unconditionally: with the bounds test inside the loop every load sits in
+  //  its own branch and is waited for before the next one is issued -- the whole kernel then runs
+  //  at a fraction of the copy rate, tools/iir_stream_probe.hip)
+  if (whole) {
+    T v[OP_LB];
 #pragma unroll
-  for (int i = 0; i < OP_LB; ++i) {
-    const int64_t j = (int64_t)i * 64 + lane;
-    tile[(int)(j / OP_LB)][(int)(j % OP_LB)] = (whole || j < left) ? x[j] : (T)0;
+    for (int i = 0; i < OP_LB; ++i) v[i] = x[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i) {
+      const int j = i * 64 + lane;
+      tile[j / OP_LB][j % OP_LB] = v[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i) {
+      const int64_t j = (int64_t)i * 64 + lane;
+      tile[(int)(j / OP_LB)][(int)(j % OP_LB)] = j < left ? x[j] : (T)0;
+    }
   }
   __syncthreads();
   double xr[OP_LB];
@@ -494,37 +508,30 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
     for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
   } else {
-    int64_t base = chunk - 1;                                // lane k looks at chunk base - k
-    // one window of 64 predecessors; if none of them has a prefix yet, wait for the nearest one's
-    for (;;) {
-      const int64_t pc = base - lane;
-      unsigned st = 0;
-      if (pc >= 0) {
-        const unsigned* f = status + (int64_t)row * nchunks + pc;
-        int spins = 0;
-        do {
-          st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (st >= F_AGG && st <= F_PRE) break;
-          __builtin_amdgcn_s_sleep(2);
-        } while (++spins < OP_SPIN);
-        if (!(st >= F_AGG && st <= F_PRE)) { poisoned = true; st = F_PRE; }
+    const int64_t base = chunk - 1;                          // lane k looks at chunk base - k
+    const int64_t pc = base - lane;
+    const unsigned* f = status + (int64_t)row * nchunks + (pc >= 0 ? pc : 0);
+    // Poll the whole window until (i) some chunk in it has published its PREFIX and (ii) every chunk
+    // nearer than that one has at least its aggregate.  (Waiting for the NEAREST predecessor's prefix
+    // instead -- the first version -- chains the chunks in flight one behind the other.)  The oldest
+    // chunk in flight finds finished predecessors at once, so prefixes appear without any chunk
+    // waiting for a particular neighbour.
+    unsigned st = 0;
+    int kstop = -1;
+    for (int spins = 0; spins < OP_SPIN; ++spins) {
+      if (pc >= 0 && !(st == F_PRE)) st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool pre = pc >= 0 && st == F_PRE;
+      const bool agg = pc >= 0 && (st == F_AGG || st == F_PRE);
+      const unsigned long long has_pre = __ballot(pre), has_agg = __ballot(agg);
+      if (has_pre != 0ull) {
+        const int k = __ffsll((long long)has_pre) - 1;       // nearest chunk with a prefix
+        const unsigned long long need = k == 0 ? 0ull : (~0ull >> (64 - k));   // lanes 0 .. k-1
+        if ((has_agg & need) == need) { kstop = k; break; }
       }
-      const unsigned long long has_pre = __ballot(pc >= 0 && st == F_PRE);
-      if (has_pre == 0ull) {
-        // nobody within reach has a prefix: wait for the nearest predecessor's (it is computing the
-        // very same thing one chunk earlier), then take it alone
-        unsigned s1 = 0;
-        int spins = 0;
-        const unsigned* f = status + (int64_t)row * nchunks + base;
-        do {
-          s1 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (s1 == F_PRE) break;
-          __builtin_amdgcn_s_sleep(4);
-        } while (++spins < OP_SPIN);
-        if (s1 != F_PRE) poisoned = true;
-        continue;                                            // lane 0 now sees a prefix at distance 0
-      }
-      const int kstop = __ffsll((long long)has_pre) - 1;     // nearest chunk with a prefix
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (kstop < 0) { poisoned = true; kstop = 0; }
+    {
       double contrib[IIR_MAXD];
 #pragma unroll
       for (int i = 0; i < IIR_MAXD; ++i) contrib[i] = 0.0;
@@ -547,7 +554,6 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
         for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
         sin_[i] = sum;
       }
-      break;
     }
   }
   poisoned = __any(poisoned);
@@ -593,10 +599,18 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
       for (int i = 0; i < DD; ++i) zf[(int64_t)row * DD + i] = z[i];
   }
   __syncthreads();
+  if (whole) {
 #pragma unroll
-  for (int i = 0; i < OP_LB; ++i) {
-    const int64_t j = (int64_t)i * 64 + lane;
-    if (whole || j < left) y[j] = tile[(int)(j / OP_LB)][(int)(j % OP_LB)];
+    for (int i = 0; i < OP_LB; ++i) {
+      const int j = i * 64 + lane;
+      y[j] = tile[j / OP_LB][j % OP_LB];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < OP_LB; ++i) {
+      const int64_t j = (int64_t)i * 64 + lane;
+      if (j < left) y[j] = tile[(int)(j / OP_LB)][(int)(j % OP_LB)];
+    }
   }
 }
 
