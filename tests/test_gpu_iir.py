@@ -13,6 +13,17 @@ from oracle import np_oracle
 from waveforms_amd import _engine, distortion
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=['default', 'three-launch'])
+def _iir_form(request):
+    """every test runs with the library's own choice (single pass where the shape allows: one or two
+    biquads on rows of >= 8192 samples) and with the three-launch block scan forced"""
+    import os
+    if request.param == 'three-launch':
+        os.environ['WFK_IIR_ONEPASS'] = '0'
+    yield
+    os.environ.pop('WFK_IIR_ONEPASS', None)
 IIR = golden_io.npz('iir.npz')
 
 
@@ -245,11 +256,13 @@ def test_predistort_combined_order_above_16():
         distortion.predistort(x, filters, initial=0.3)
 
 
-@pytest.mark.parametrize('nsec,n,rows', [(2, 100003, 3), (1, 65536, 2), (2, 8192 * 4, 5), (2, 1_000_001, 7)])
+@pytest.mark.parametrize('nsec,n,rows', [(2, 100003, 3), (1, 65536, 2), (2, 8192 * 4, 5), (2, 1_000_001, 7),
+                                          (2, 3_000_017, 1), (1, 2_000_003, 2)])   # (few long rows: several look-back windows)
 def test_single_pass_chained_scan(nsec, n, rows):
     """One or two biquads on long rows as ONE kernel (chained scan with decoupled look-back: x is
-    read once; WFK_IIR_ONEPASS=1).  Against scipy.signal.sosfilt with random initial state, final state, DC
-    offset, in place, float32, and the three-launch form of the same plan."""
+    read once; the default for these shapes).  Against scipy.signal.sosfilt with random initial state,
+    final state, DC offset, in place, float32, and the three-launch form of the same plan
+    (WFK_IIR_ONEPASS=0)."""
     import os
     rng = np.random.default_rng(n + nsec)
     sos = butter(2 * nsec, 0.07, output='sos')
@@ -281,17 +294,17 @@ def test_single_pass_chained_scan(nsec, n, rows):
         plan.close()
         return got, zf
 
-    os.environ['WFK_IIR_ONEPASS'] = '1'        # experimental form (off by default: slower)
-    try:
-        got, zf = run(np.float64)
-        got_ip, _ = run(np.float64, inplace=True)
-        g32, _ = run(np.float32)
-    finally:
-        del os.environ['WFK_IIR_ONEPASS']
+    got, zf = run(np.float64)
+    got_ip, _ = run(np.float64, inplace=True)
+    g32, _ = run(np.float32)
     pk = max(1.0, np.abs(want).max())
     assert np.max(np.abs(got - want)) <= 1e-11 * pk
     assert np.max(np.abs(zf - zfw)) <= 1e-11 * max(1.0, np.abs(zfw).max())
     assert np.array_equal(got_ip, got)
     assert np.max(np.abs(g32 - want)) <= 2e-5 * pk
-    three, zf3 = run(np.float64)               # the default three-launch form of the same plan
+    os.environ['WFK_IIR_ONEPASS'] = '0'        # the three-launch form of the same plan
+    try:
+        three, zf3 = run(np.float64)
+    finally:
+        del os.environ['WFK_IIR_ONEPASS']
     assert np.max(np.abs(three - got)) <= 1e-12 * pk and np.max(np.abs(zf3 - zf)) <= 1e-12 * max(1.0, np.abs(zf).max())

@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const
 #define OP_WAVES 2
 #endif
 #define OP_SPIN (1 << 22)
+#define OP_WINDOWS 4            // look-back reach: 256 chunks of the row in flight
 
 __device__ __forceinline__ void op_store(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -508,30 +509,40 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
     for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
   } else {
-    const int64_t base = chunk - 1;                          // lane k looks at chunk base - k
-    const int64_t pc = base - lane;
-    const unsigned* f = status + (int64_t)row * nchunks + (pc >= 0 ? pc : 0);
-    // Poll the whole window until (i) some chunk in it has published its PREFIX and (ii) every chunk
-    // nearer than that one has at least its aggregate.  (Waiting for the NEAREST predecessor's prefix
-    // instead -- the first version -- chains the chunks in flight one behind the other.)  The oldest
-    // chunk in flight finds finished predecessors at once, so prefixes appear without any chunk
-    // waiting for a particular neighbour.
-    unsigned st = 0;
-    int kstop = -1;
-    for (int spins = 0; spins < OP_SPIN; ++spins) {
-      if (pc >= 0 && !(st == F_PRE)) st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool pre = pc >= 0 && st == F_PRE;
-      const bool agg = pc >= 0 && (st == F_AGG || st == F_PRE);
-      const unsigned long long has_pre = __ballot(pre), has_agg = __ballot(agg);
-      if (has_pre != 0ull) {
-        const int k = __ffsll((long long)has_pre) - 1;       // nearest chunk with a prefix
-        const unsigned long long need = k == 0 ? 0ull : (~0ull >> (64 - k));   // lanes 0 .. k-1
-        if ((has_agg & need) == need) { kstop = k; break; }
+    // Look back window by window (64 chunks each, lane l of window w looks at chunk c - 1 - 64 w - l).
+    // A window is closed by the nearest chunk in it that has published its PREFIX, once every chunk
+    // nearer than that one has at least its aggregate; a window in which all 64 chunks have aggregates
+    // but none a prefix yet (more than 64 chunks of the row in flight: few rows, long rows) is summed
+    // whole and the walk goes on one window further back (its sum then passes through U^64 once per
+    // window).  Nothing waits for a PARTICULAR neighbour's prefix -- the first version did and chained
+    // the chunks in flight one behind the other.  Bounded: OP_SPIN polls, then NaN.
+    double hop[IIR_MAXD];                                    // sum over the windows so far
+#pragma unroll
+    for (int i = 0; i < IIR_MAXD; ++i) hop[i] = 0.0;
+    int spins = 0;
+    for (int w = 0;; ++w) {
+      const int64_t pc = chunk - 1 - 64 * (int64_t)w - lane;
+      const unsigned* f = status + (int64_t)row * nchunks + (pc >= 0 ? pc : 0);
+      unsigned st = 0;
+      int kstop = -1;
+      bool whole_window = false;
+      for (; spins < OP_SPIN; ++spins) {
+        if (pc >= 0 && !(st == F_PRE)) st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool pre = pc >= 0 && st == F_PRE;
+        const bool agg = pc >= 0 && (st == F_AGG || st == F_PRE);
+        const unsigned long long has_pre = __ballot(pre), has_agg = __ballot(agg);
+        if (has_pre != 0ull) {
+          const int k = __ffsll((long long)has_pre) - 1;     // nearest chunk with a prefix
+          const unsigned long long need = k == 0 ? 0ull : (~0ull >> (64 - k));   // lanes 0 .. k-1
+          if ((has_agg & need) == need) { kstop = k; break; }
+        } else if (has_agg == ~0ull && w < OP_WINDOWS - 1) {
+          whole_window = true;
+          kstop = 64;                                        // every lane contributes an aggregate
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (kstop < 0) { poisoned = true; kstop = 0; }
-    {
+      if (kstop < 0) { poisoned = true; kstop = 0; }
       double contrib[IIR_MAXD];
 #pragma unroll
       for (int i = 0; i < IIR_MAXD; ++i) contrib[i] = 0.0;
@@ -547,14 +558,30 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
           dd_matvec_add<DD>(contrib, lanepU + (int64_t)(lane - 1) * DD * DD * 2, v, DD);   // U^lane
         }
       }
+      double wsum[IIR_MAXD];
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i) wsum[i] = 0.0;
 #pragma unroll
       for (int i = 0; i < DD; ++i) {
         double sum = contrib[i];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-        sin_[i] = sum;
+        wsum[i] = sum;
       }
+      for (int q = 0; q < w; ++q) {                          // this window lies 64 w chunks back: U^(64 w)
+        double nx[IIR_MAXD];
+#pragma unroll
+        for (int i = 0; i < IIR_MAXD; ++i) nx[i] = 0.0;
+        dd_matvec_add<DD>(nx, lanepU + (int64_t)63 * DD * DD * 2, wsum, DD);
+#pragma unroll
+        for (int i = 0; i < IIR_MAXD; ++i) wsum[i] = nx[i];
+      }
+#pragma unroll
+      for (int i = 0; i < DD; ++i) hop[i] += wsum[i];
+      if (!whole_window) break;
     }
+#pragma unroll
+    for (int i = 0; i < DD; ++i) sin_[i] = hop[i];
   }
   poisoned = __any(poisoned);
 
@@ -873,15 +900,13 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
   {
     bool biq = n_sections <= 2;
     for (int s2 = 0; s2 < n_sections; ++s2) biq = biq && orders[s2] == 2;
-    // OFF by default: measured 4.95 ms against 3.0 ms of the three-launch form on 64 x 1e7 (fp64, two
-    // biquads).  It does move 16 instead of 24 B/sample, but a chunk of 2048 samples is a serial
-    // pipeline -- load, sweep, scan, publish, look back (device-scope polls), sweep, store -- on a wave
-    // that holds its 32 samples per lane in registers (252 VGPRs: 2 waves per SIMD), so nothing
-    // hides its latencies; 16- and 8-sample blocks are slower still (5.6 / 10.9 ms: more look-backs
-    // per sample), and with fewer rows than waves in flight the single look-back window of 64 chunks
-    // degenerates into a serial chain (4 rows: 10.5 ms).  WFK_IIR_ONEPASS=1 selects it (tests do).
+    // The default for these shapes since its loads are issued in one batch and the look-back no
+    // longer chains on the nearest prefix (tools/iir_sweep.py, fp64, 1 / 2 biquads, three-launch vs
+    // single pass): 1024 x 1e6 4.65 / 4.71 vs 3.08 / 3.44 ms (66 / 60 % of the HBM peak on 16 B/sample),
+    // 256 x 1e7 11.7 / 11.5 vs 8.6 / 9.9, 64 x 1e7 3.0 / 3.2 vs 2.8 / 3.1, 64 x 1e5 0.39 / 0.46 vs
+    // 0.04 / 0.05 (one launch instead of three).  WFK_IIR_ONEPASS=0 keeps the three-launch form.
     const char* on = getenv("WFK_IIR_ONEPASS");
-    if (biq && n >= 4 * OP_CHUNK && on && on[0] == '1') {
+    if (biq && n >= 4 * OP_CHUNK && !(on && on[0] == '0')) {
       std::vector<quad> T1((size_t)D * D);
       for (int i = 0; i < D; ++i) {
         quad z[IIR_MAXD];
