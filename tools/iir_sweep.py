@@ -1,4 +1,5 @@
-"""IIR stage: three-launch block scan vs single-pass chained scan over shapes (same process, same box).
+"""IIR stage: three-launch block scan vs single-pass chained scan over shapes (same process, same box),
+and what the library picks by itself.
 python tools/iir_sweep.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,10 @@ from waveforms_amd import _engine
 
 
 def bench(rows, n, nsec, dtype, onepass):
-    os.environ['WFK_IIR_ONEPASS'] = '1' if onepass else '0'
+    if onepass is None:
+        os.environ.pop('WFK_IIR_ONEPASS', None)
+    else:
+        os.environ['WFK_IIR_ONEPASS'] = '1' if onepass else '0'
     sos = butter(2 * nsec, 0.1, output='sos')
     plan = _engine.IirPlan([(s[:3], s[3:]) for s in sos], n, rows, dtype)
     td = torch.float64 if dtype == np.float64 else torch.float32
@@ -35,13 +39,14 @@ def bench(rows, n, nsec, dtype, onepass):
 
 for dtype in (np.float64, np.float32):
     for nsec in (1, 2):
-        for rows, n in ((1, 10**7), (4, 10**7), (8, 10**6), (16, 10**7), (64, 10**5), (64, 10**6), (64, 10**7), (256, 10**6),
+        for rows, n in ((1, 10**7), (4, 10**7), (8, 10**6), (16, 10**7), (32, 10**7), (64, 10**5), (64, 10**6), (64, 10**7), (256, 10**6),
                         (256, 10**7), (1024, 10**6), (4096, 10**5)):
             if rows * n * (8 if dtype == np.float64 else 4) * 2 > 60e9:
                 continue
             t3, y3 = bench(rows, n, nsec, dtype, False)
             t1, y1 = bench(rows, n, nsec, dtype, True)
+            td, _ = bench(rows, n, nsec, dtype, None)
             err = float((y1.double() - y3.double()).abs().max())
             b = 8 if dtype == np.float64 else 4
             print(f'{np.dtype(dtype).name} {nsec} biquad(s) {rows:5d} x {n:.0e}: three-launch {t3:8.4f} ms ({rows*n*2*b/t3*1e-9/8*100:4.1f}%)  '
-                  f'single-pass {t1:8.4f} ms ({rows*n*2*b/t1*1e-9/8*100:4.1f}%)  ratio {t3/t1:5.2f}  max|diff| {err:.1e}', flush=True)
+                  f'single-pass {t1:8.4f} ms ({rows*n*2*b/t1*1e-9/8*100:4.1f}%)  ratio {t3/t1:5.2f}  default {td:8.4f} ms  max|diff| {err:.1e}', flush=True)

@@ -390,20 +390,20 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
                                                   const double* __restrict__ pw1, const double* __restrict__ lanep1,
                                                   const double* __restrict__ lanepU, const double* __restrict__ zi,
                                                   double* __restrict__ zf, int64_t n, int64_t nchunks, int rows,
-                                                  unsigned epoch, double pre_sub, double post_add) {
+                                                  unsigned epoch, double pre_sub, double post_add, int persist) {
   constexpr int DD = 2 * NSEC;
   __shared__ T tile[64][OP_LB + 1];
   const int lane = threadIdx.x;
   // one ticket counter per row (64 B apart): a single counter for all rows serialises 3e5 atomics on
   // one address -- measured 5.2 ms for the whole kernel against 3.1 ms of the three-launch form
   const int row = (int)(blockIdx.x % (unsigned)rows);
+  // persist != 0: the grid holds a bounded number of waves per row and each walks the ticket counter
+  // until the row is used up (few long rows: otherwise hundreds of chunks of one row are in flight
+  // and every look-back reads all of them); persist == 0: one chunk per workgroup
+  for (;;) {
   unsigned t = 0;
-#if defined(OP_PROBE) && OP_PROBE >= 4
-  t = blockIdx.x / (unsigned)rows;
-#else
   if (lane == 0) t = atomicAdd(ticket + 16 * row, 1u);
   t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-#endif
   const int64_t chunk = t;
   if (chunk >= nchunks) return;
   const T* x = in + (int64_t)row * in_stride + chunk * OP_CHUNK;
@@ -412,16 +412,6 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   const int cnt = (int)(left - (int64_t)lane * OP_LB < 0 ? 0 : (left - (int64_t)lane * OP_LB > OP_LB ? OP_LB : left - (int64_t)lane * OP_LB));
   const bool whole = left >= OP_CHUNK;                       // wave-uniform
 
-#if defined(OP_PROBE) && OP_PROBE == 5
-  {
-    T v[OP_LB];
-#pragma unroll
-    for (int i = 0; i < OP_LB; ++i) { const int64_t j = (int64_t)i * 64 + lane; v[i] = (whole || j < left) ? x[j] : (T)0; }
-#pragma unroll
-    for (int i = 0; i < OP_LB; ++i) { const int64_t j = (int64_t)i * 64 + lane; if (whole || j < left) y[j] = v[i] + (T)post_add; }
-    return;
-  }
-#endif
   // ---- load: sample j = i*64 + lane of the chunk belongs to block j / OP_LB, position j % OP_LB
   // (a whole chunk loads unconditionally: with the bounds test inside the loop every load sits in
   //  its own branch and is waited for before the next one is issued -- the whole kernel then runs
@@ -448,17 +438,6 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   for (int i = 0; i < OP_LB; ++i) xr[i] = (double)tile[lane][i] - pre_sub;
   __syncthreads();
 
-#if defined(OP_PROBE) && (OP_PROBE == 1 || OP_PROBE == 4)
-#pragma unroll
-  for (int i = 0; i < OP_LB; ++i) tile[lane][i] = (T)(xr[i] + post_add);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < OP_LB; ++i) {
-    const int64_t j = (int64_t)i * 64 + lane;
-    if (whole || j < left) y[j] = tile[(int)(j / OP_LB)][(int)(j % OP_LB)];
-  }
-  return;
-#endif
   // ---- sweep 1: zero state -> local final state; scan over the 64 blocks
   double z[IIR_MAXD];
 #pragma unroll
@@ -484,12 +463,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   }
   const int64_t slot = ((int64_t)row * nchunks + chunk);
   const unsigned F_AGG = epoch * 4u + 1u, F_PRE = epoch * 4u + 2u;
-#if defined(OP_PROBE) && OP_PROBE == 2
-  const bool publish = false;
-#else
-  const bool publish = true;
-#endif
-  if (publish && chunk > 0 && lane == 0) {
+  if (chunk > 0 && lane == 0) {
 #pragma unroll
     for (int i = 0; i < DD; ++i) op_store(aggbuf + slot * DD + i, agg[i]);
     __builtin_amdgcn_s_waitcnt(0);                           // the state is in memory before the flag is
@@ -501,11 +475,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
   for (int i = 0; i < IIR_MAXD; ++i) sin_[i] = 0.0;
   bool poisoned = false;
-#if defined(OP_PROBE) && (OP_PROBE == 2 || OP_PROBE == 3)
-  if (true) {
-#else
   if (chunk == 0) {
-#endif
 #pragma unroll
     for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
   } else {
@@ -591,7 +561,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
     for (int i = 0; i < IIR_MAXD; ++i) so[i] = i < DD ? agg[i < DD ? i : 0] : 0.0;
     dd_matvec_add<DD>(so, lanepU, sin_, DD);                 // U^1
-    if (publish && chunk + 1 < nchunks) {
+    if (chunk + 1 < nchunks) {
 #pragma unroll
       for (int i = 0; i < DD; ++i) op_store(prefbuf + slot * DD + i, so[i]);
       __builtin_amdgcn_s_waitcnt(0);
@@ -638,6 +608,9 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
       const int64_t j = (int64_t)i * 64 + lane;
       if (j < left) y[j] = tile[(int)(j / OP_LB)][(int)(j % OP_LB)];
     }
+  }
+  if (!persist) return;
+  __syncthreads();
   }
 }
 
@@ -906,7 +879,14 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     // 256 x 1e7 11.7 / 11.5 vs 8.6 / 9.9, 64 x 1e7 3.0 / 3.2 vs 2.8 / 3.1, 64 x 1e5 0.39 / 0.46 vs
     // 0.04 / 0.05 (one launch instead of three).  WFK_IIR_ONEPASS=0 keeps the three-launch form.
     const char* on = getenv("WFK_IIR_ONEPASS");
-    if (biq && n >= 4 * OP_CHUNK && !(on && on[0] == '0')) {
+    // Between 8 and 64 LONG rows the three-launch form is still ahead (tools/iir_depth.py, 2 biquads,
+    // fp64, three-launch vs single pass: 8 x 1e7 0.61 vs 0.75 ms, 16 x 1e7 0.80 vs 1.22, 32 x 1e7 1.55 vs
+    // 1.84, 48 x 1e7 2.29 vs 2.48; but 16 x 1e6 0.49 vs 0.12, 4 x 1e7 0.54 vs 0.38, 1 x 1e7 0.51 vs 0.15):
+    // 2304 / rows chunks of a row are in flight there and every look-back reads all of them.
+    // WFK_IIR_ONEPASS=1 / 0 force one form or the other.
+    const bool band = batch >= 8 && batch < 64 && (double)batch * (double)n >= 6e7;
+    const bool want = on ? on[0] != '0' : !band;
+    if (biq && n >= 4 * OP_CHUNK && want) {
       std::vector<quad> T1((size_t)D * D);
       for (int i = 0; i < D; ++i) {
         quad z[IIR_MAXD];
@@ -1025,18 +1005,38 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
     if (hipMemsetAsync(p->op_ticket, 0, (size_t)p->batch * 64, s) != hipSuccess)
       return iir_fail(WFK_EHIP, "IIR ticket reset failed");
     const unsigned epoch = ++p->epoch;
-    const unsigned total = (unsigned)(p->op_chunks * p->batch);
+    // Few long rows: with one chunk per workgroup 2304 / rows chunks of a row are in flight, and a
+    // look-back reads every one of them.  Below OP_DEPTH_ROWS rows the grid is op_depth persistent waves
+    // per row instead (WFK_IIR_OP_DEPTH: experiments).
+    unsigned total = (unsigned)(p->op_chunks * p->batch);
+    int persist = 0;
+    {
+      // from 64 rows on: about two waves per SIMD's worth of persistent waves (same box, 2 biquads, one
+      // chunk per workgroup vs this: 128 x 1e7 5.86 vs 5.41 ms, 256 x 1e7 10.8 vs 9.6, 512 x 1e6 2.15 vs
+      // 2.03, 1024 x 1e6 3.82 vs 3.74); fewer rows run faster with everything in flight
+      int depth = 0;
+      // (float rows under two biquads are the exception: 256 x 1e7 7.4 vs 8.4 ms)
+      if (p->batch >= 64 && p->batch <= 1152 && !(p->kind == WFK_OUT_F32 && p->c.nsec == 2)) {
+        depth = (int)((4608 + p->batch - 1) / p->batch);
+        depth = depth < 4 ? 4 : (depth > 36 ? 36 : depth);
+      }
+      if (const char* e = getenv("WFK_IIR_OP_DEPTH")) depth = atoi(e);
+      if (depth > 0 && (int64_t)depth < p->op_chunks) {
+        total = (unsigned)(depth * p->batch);
+        persist = 1;
+      }
+    }
 #define OP_LAUNCH(TT, NS)                                                                                     \
     if (p->op_plain)                                                                                          \
     hipLaunchKernelGGL((iir_onepass<TT, NS, true>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
                        (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
                        p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
-                       initial, post);                                                                         \
+                       initial, post, persist);                                                                         \
     else                                                                                                       \
     hipLaunchKernelGGL((iir_onepass<TT, NS, false>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
                        (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
                        p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
-                       initial, post)
+                       initial, post, persist)
     if (p->kind == WFK_OUT_F32) { if (p->c.nsec == 1) OP_LAUNCH(float, 1); else OP_LAUNCH(float, 2); }
     else { if (p->c.nsec == 1) OP_LAUNCH(double, 1); else OP_LAUNCH(double, 2); }
 #undef OP_LAUNCH
