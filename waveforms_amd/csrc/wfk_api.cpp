@@ -130,6 +130,7 @@ struct wfk_plan {
   double* d_pool = nullptr;
   int32_t* d_chunk_first = nullptr;
   int32_t* d_lean_chunk_first = nullptr;   // mixed plans: chunk table of the lean launch
+  int32_t* d_f32_chunk_first = nullptr;    // lean launch with float output: its own (longer) chunks
   double* d_tlist = nullptr;
   void* d_scratch = nullptr;   // wfk_plan_run_host output buffer
   size_t scratch_bytes = 0;
@@ -154,9 +155,10 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   const size_t b_po = h.pool.size() * sizeof(double);
   const size_t b_cf = h.chunk_first.size() * sizeof(int32_t);
   const size_t b_lf = h.lean_chunk_first.size() * sizeof(int32_t);
+  const size_t b_ff = h.f32_chunk_first.size() * sizeof(int32_t);
   const size_t o_ch = 0, o_pc = align256(o_ch + b_ch), o_pa = align256(o_pc + b_pc),
                o_po = align256(o_pa + b_pa), o_cf = align256(o_po + b_po),
-               o_lf = align256(o_cf + b_cf), o_tl = align256(o_lf + b_lf);
+               o_lf = align256(o_cf + b_cf), o_ff = align256(o_lf + b_lf), o_tl = align256(o_ff + b_ff);
   const size_t b_tl = tlist ? (size_t)h.n * sizeof(double) : 0;
   const size_t total = align256(o_tl + b_tl) + 256;
   HIP_TRY(dev_cache().get(total, &p->d_tables, &p->tables_cap, &p->dev));
@@ -167,6 +169,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   p->d_pool = reinterpret_cast<double*>(base + o_po);
   p->d_chunk_first = reinterpret_cast<int32_t*>(base + o_cf);
   p->d_lean_chunk_first = reinterpret_cast<int32_t*>(base + o_lf);
+  p->d_f32_chunk_first = reinterpret_cast<int32_t*>(base + o_ff);
   p->d_tlist = tlist ? reinterpret_cast<double*>(base + o_tl) : nullptr;
   // the small tables travel in ONE copy; the time axis (as large as the output) on its own
   std::vector<char> stage(o_tl);
@@ -176,6 +179,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   if (b_po) std::memcpy(stage.data() + o_po, h.pool.data(), b_po);
   if (b_cf) std::memcpy(stage.data() + o_cf, h.chunk_first.data(), b_cf);
   if (b_lf) std::memcpy(stage.data() + o_lf, h.lean_chunk_first.data(), b_lf);
+  if (b_ff) std::memcpy(stage.data() + o_ff, h.f32_chunk_first.data(), b_ff);
   if (o_tl) HIP_TRY(hipMemcpy(base, stage.data(), o_tl, hipMemcpyHostToDevice));
   if (b_tl) HIP_TRY(hipMemcpy(base + o_tl, tlist, b_tl, hipMemcpyHostToDevice));
   p->on_device = true;
@@ -331,6 +335,17 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   a.lean_par = p->h.lean_par;
   a.lean_ops = p->h.lean_ops;
   a.corr = p->h.n_corr > 0 ? 1 : 0;
+  a.reseed = WFK_LEAN_RESEED;
+  // float outputs of the lean launch: longer chunks, rarer exact reseeds (HostPlan::f32_*)
+  const bool f32_lean = (out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64) && p->h.f32_tiles_per_chunk > 0;
+  auto use_f32_chunks = [&](KArgs& k) {
+    k.chunk_first = p->d_f32_chunk_first;
+    k.chunks_per_ch = p->h.f32_chunks_per_ch;
+    k.n_chunks = p->h.f32_chunks_per_ch * p->h.n_channels;
+    k.tiles_per_chunk = p->h.f32_tiles_per_chunk;
+    k.reseed = WFK_LEAN_RESEED_F32;
+  };
+  if (f32_lean && p->h.lean) use_f32_chunks(a);
   if (hip_stream) p->async_launch = true;
   std::string err;
   int rc = WFK_OK;
@@ -342,6 +357,7 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
     l.chunks_per_ch = p->h.lean_chunks_per_ch;
     l.n_chunks = p->h.lean_chunks_per_ch * p->h.n_channels;
     l.tiles_per_chunk = p->h.lean_tiles_per_chunk;
+    if (f32_lean) use_f32_chunks(l);
     rc = wfk_launch_sampler(l, p->h.n_channels, out_kind, false, p->h.ns, true, false, false, hip_stream, err);
     if (rc) return fail(rc, err);
     a.mixed = 1;   // ... then the pieces with generic terms

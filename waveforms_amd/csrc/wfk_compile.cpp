@@ -989,7 +989,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
   H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
   auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
-                      std::vector<int32_t>& chunk_first) {
+                      std::vector<int32_t>& chunk_first, int lean_cap = 8) {
     // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
     // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
     tile = (lean_geom ? 64 : WFK_WG) * H.ns;
@@ -1000,7 +1000,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // any moment compact, which is what the HBM write rate depends on:
     // measured best at 8 tiles (= one seed per chunk) on the headline config, 4 on C2.
     const int64_t tpc = total_tiles / (lean_geom ? 2048 : 8192);
-    tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? 8 : 16, std::max<int64_t>(1, tpc));
+    tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? lean_cap : 16, std::max<int64_t>(1, tpc));
     if (const char* e = std::getenv("WFK_TPC")) {   // tuning override
       int v = std::atoi(e);
       if (v >= 1 && v <= 64) tiles_per_chunk = v;
@@ -1019,6 +1019,20 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   };
   chunking(H.lean, H.tile, H.tiles_per_chunk, H.chunks_per_ch, H.chunk_first);
   if (H.mixed) chunking(true, H.lean_tile, H.lean_tiles_per_chunk, H.lean_chunks_per_ch, H.lean_chunk_first);
+  if ((H.lean || H.mixed) && ns_override == 0) {
+    // the lean launch's chunking for float outputs (longer chunks, see HostPlan)
+    int32_t tile32 = 0;
+    int cap32 = WFK_LEAN_TPC_F32;
+    if (const char* e = std::getenv("WFK_TPC_F32")) {   // tuning override
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 64) cap32 = v;
+    }
+    chunking(true, tile32, H.f32_tiles_per_chunk, H.f32_chunks_per_ch, H.f32_chunk_first, cap32);
+    if (H.f32_tiles_per_chunk == (H.mixed ? H.lean_tiles_per_chunk : H.tiles_per_chunk)) {
+      H.f32_chunk_first.clear();      // nothing to gain: the double table serves
+      H.f32_tiles_per_chunk = 0;
+    }
+  }
   if (H.pool.empty()) H.pool.push_back(0.0);
   if (H.params.empty()) H.params.push_back(0.0);
   return WFK_OK;

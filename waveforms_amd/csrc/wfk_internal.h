@@ -96,7 +96,13 @@
 #endif
 #define WFK_CHAIN_PAR 2048    // sampler inside the FIR transform: largest parameter block (doubles); it is staged
                               // in the transform's exchange array (18.5 KB in the float kernel)
-#define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles
+#ifndef WFK_LEAN_RESEED
+#define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles (fp64 outputs: drift 9e-13 over 128 steps)
+#endif
+#define WFK_LEAN_RESEED_F32 32 // ... float outputs
+#define WFK_LEAN_TPC_F32 20    // ... whose lean launches take up to this many tiles per chunk (8 for double);
+                              // same box, cap 8 / 12 / 16 / 20 / 24 / 32: fp32 256 x 1e7 1.99 / 1.91 / 1.88 / 1.88 /
+                              // 1.91 / 1.87 ms, C3 0.211 / 0.207 / 0.201 / 0.197 / 0.199 / 0.201 ms
 
 #define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)
 #define WFK_PF_LEAN 2         // piece is one block of <= WFK_LEAN_OPS fused ops (lean kernel can take it)
@@ -134,6 +140,7 @@ struct KArgs {
   int32_t has_last, pad;
   int32_t lean_par, lean_ops;  // lean kernel: doubles of parameter block / units (128 doubles) of op state to reserve in LDS
   int32_t corr;                // plan holds carriers that need the grid-rounding correction (lean kernel variant)
+  int32_t reseed;              // lean kernel: tiles between exact (libm) reseeds of the carried op state
   int32_t mixed;               // mixed plan: the lean kernel skips the pieces without WFK_PF_LEAN, the general
                                // kernel skips the lean and the zero pieces (two launches, one output)
 };
@@ -165,6 +172,12 @@ struct HostPlan {
   int32_t lean_tile = 0, lean_tiles_per_chunk = 1;   // mixed: the lean launch's own chunking
   int64_t lean_chunks_per_ch = 0;
   std::vector<int32_t> lean_chunk_first;
+  // float outputs of the lean kernel: longer chunks and exact reseeds every WFK_LEAN_RESEED_F32 tiles (the
+  // carried state is double whatever the output: its drift over 512 steps, 1e-11, is far below float's
+  // resolution).  Same-box A/B on 256 x 1e7 fp32: 1.99 -> 1.88 ms, C3 0.211 -> 0.197 ms.
+  int32_t f32_tiles_per_chunk = 0;
+  int64_t f32_chunks_per_ch = 0;
+  std::vector<int32_t> f32_chunk_first;
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most state units (128 doubles) of a piece
 };
 

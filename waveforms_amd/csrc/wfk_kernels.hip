@@ -956,7 +956,7 @@ wfk_sample_lean(const KArgs a) {
         const int nops = uni((int)s_par[1]);
         double x = grid_time(a, j0);
         if (C.tshift != 0.0) x = x - C.tshift;
-        const bool carried = state_piece == q && state_w0 == w0 && since_seed < WFK_LEAN_RESEED;
+        const bool carried = state_piece == q && state_w0 == w0 && since_seed < a.reseed;
         if (!carried) {
           // seed phase: libm, nothing else live
           for (int op = 0; op < nops; ++op) {
