@@ -92,6 +92,7 @@ struct FceGroup {
   double W = 0, sref = 0;
   long double psi_ref = 0;
   bool has_env = false, env32 = false, has_lin = false;
+  bool has_exp = false;         // the envelope is exp(sigma * (t - sg)) (sigma = rate, sg = reference time), not a Gaussian
   double sigma = 0, sg = 0, slin = 0;
   long double A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
   int deg = 0, nterms = 0;
@@ -458,6 +459,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const char* nofuse_env = std::getenv("WFK_DISABLE_FUSE");
   const bool can_fuse = !H.tlist && !nofast && !(nofuse_env && nofuse_env[0] == '1');
 
+  const char* noexp_env = std::getenv("WFK_DISABLE_EXPFUSE");
+  const bool expfuse = ns_override == 0 && !(noexp_env && noexp_env[0] == '1');   // (the chain kernel seeds Gaussians only)
   const char* noerf_env = std::getenv("WFK_DISABLE_ERFMUL");
   const bool erfmod = can_fuse && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
 
@@ -472,6 +475,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     double slin = 0, sigma = 0, sg = 0;
     double first_cos_shift = 0;
     struct Car { long double c, W, Psi; };   // c * cos(W t' - Psi),  t' = t - tshift
+    struct ExpV { long double c, a, b; };    // c * exp(a t' + b): EXP factors, COSH / SINH as two of them
+    std::vector<ExpV> evs = {{1.0L, 0.0L, 0.0L}};
+    bool has_expf = false;
     struct CosF { double w, sh, thmax; };    // reference COS factors of the term (|w|, shift, largest |phase|)
     std::vector<CosF> cosf;
     bool has_drag = false;
@@ -520,6 +526,26 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           if (!times({{1.0L, (long double)a[0], (long double)a[0] * sh}})) return false;
           const double ua = (ax.at(s0) - tshift) - sh, ub = (ax.at(s1 - 1) - tshift) - sh;
           cosf.push_back({std::fabs(a[0]), sh, std::fabs(a[0]) * std::max(std::fabs(ua), std::fabs(ub))});
+          break;
+        }
+        case WFK_EXP: {
+          // exp(alpha u)^p = exp(p alpha t' - p alpha shift)
+          if (!expfuse || !std::isfinite(a[0]) || !std::isfinite(pw) || !std::isfinite(sh)) return false;
+          for (ExpV& e : evs) { e.a += (long double)pw * a[0]; e.b -= (long double)pw * a[0] * sh; }
+          has_expf = true;
+          break;
+        }
+        case WFK_COSH: case WFK_SINH: {
+          // (e^{w u} +- e^{-w u}) / 2
+          if (!expfuse || pw != 1.0 || !std::isfinite(a[0]) || !std::isfinite(sh) || evs.size() > 2) return false;
+          const long double sgn = P->fc_type[f] == WFK_COSH ? 1.0L : -1.0L;
+          std::vector<ExpV> nx;
+          for (const ExpV& e : evs) {
+            nx.push_back({e.c / 2, e.a + a[0], e.b - (long double)a[0] * sh});
+            nx.push_back({sgn * e.c / 2, e.a - a[0], e.b + (long double)a[0] * sh});
+          }
+          evs.swap(nx);
+          has_expf = true;
           break;
         }
         case WFK_DRAG: {
@@ -575,8 +601,43 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       for (size_t i = 0; i < cosf.size(); ++i)         // the other factors' own phase noise must not matter
         if (i != im && 2.3e-16 * cosf[i].thmax * weight > WFK_JITTER_TOL) return false;
     }
+    // Exponential factors: under a Gaussian they only move its centre and scale it,
+    //   exp(-((t'-sg)/s)^2 + a t' + b) = exp(b + a sg + a^2 s^2 / 4) exp(-((t' - sg - a s^2 / 2)/s)^2);
+    // alone they are an envelope of their own, exp(a (t' - ref)) with the reference time in the piece
+    // (state g = exp(a (x - ref)), constant ratio exp(a D): the Gaussian recurrence with q = 1).
+    struct EnvV { long double amp; bool has_env, env32, has_exp; double sigma, sg; };
+    std::vector<EnvV> envs;
+    for (const ExpV& e : evs) {
+      EnvV v{e.c, has_env, env32, false, sigma, sg};
+      if (has_expf && e.a != 0.0L) {
+        if (has_env) {
+          const long double lg = e.b + e.a * sg + e.a * e.a * (long double)sigma * sigma / 4;
+          const double sg2 = (double)((long double)sg + e.a * (long double)sigma * sigma / 2);
+          bool ok64, ok32;
+          gauss_range(sigma, sg2, tshift, s0, s1, ok64, ok32);
+          if (!(fabsl(lg) <= 600.0L) || !std::isfinite(sg2) || !ok64) return false;
+          v.amp *= expl(lg); v.sg = sg2; v.env32 = ok32;
+        } else {
+          const double ref = 0.5 * (ax.at(s0) + ax.at(s1 - 1)) - tshift;
+          const double half = 0.5 * std::fabs(ax.at(s1 - 1) - ax.at(s0)) + (NS + 1) * dstride;   // + a tile of overhang
+          const long double lg = e.a * ref + e.b;
+          const double ar = (double)e.a;
+          if (!std::isfinite(ref) || !(fabsl(lg) <= 600.0L) || !(std::fabs(ar) * half <= 600.0) || !rate_safe(ar, s0, s1))
+            return false;
+          v.amp *= expl(lg); v.has_env = true; v.has_exp = true; v.sigma = ar; v.sg = ref;
+          v.env32 = std::fabs(ar) * half <= 80.0;
+        }
+      } else if (has_expf) {
+        if (!(fabsl(e.b) <= 600.0L)) return false;
+        v.amp *= expl(e.b);                                  // (rates cancelled: a constant)
+      }
+      envs.push_back(v);
+    }
+    for (const EnvV& ev : envs) {
+    const bool has_env = ev.has_env, env32 = ev.env32, has_exp = ev.has_exp;   // (shadow the term-level ones)
+    const double sigma = ev.sigma, sg = ev.sg;
     for (int part = 0; part < 2; ++part) {
-    const long double amp_part = part == 0 ? (long double)P->tm_amp_re[k] : (long double)P->tm_amp_im[k];
+    const long double amp_part = (part == 0 ? (long double)P->tm_amp_re[k] : (long double)P->tm_amp_im[k]) * ev.amp;
     if (amp_part == 0.0L) continue;                 // nothing in this part
     const bool imag = part == 1;
     for (Car q : cars) {
@@ -590,7 +651,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       for (const CosF& cf : cosf) thm = std::max(thm, cf.thmax);
       const bool heavy = 2.3e-16 * thm * weight > WFK_JITTER_TOL;   // its own phase rounding must be mimicked
       for (FceGroup& g : staged)
-        if (g.W == W && g.imag == imag && g.has_env == has_env &&
+        if (g.W == W && g.imag == imag && g.has_env == has_env && g.has_exp == has_exp &&
             (!has_env || (g.sigma == sigma && g.sg == sg))) {
           // a corrected group mimics ONE reference factor: a heavy term with another factor founds
           // its own group (same carrier, own op) instead of joining
@@ -601,7 +662,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       if (!G) {
         staged.emplace_back();
         G = &staged.back();
-        G->W = W; G->has_env = has_env; G->sigma = sigma; G->sg = sg; G->env32 = env32;
+        G->W = W; G->has_env = has_env; G->has_exp = has_exp; G->sigma = sigma; G->sg = sg; G->env32 = env32;
         G->imag = imag;
         G->corr = W != 0.0 && !rate_safe(W, s0, s1);
         G->wm = wm; G->sm = sm;
@@ -648,6 +709,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       }
       if (p > G->deg) G->deg = p;
       ++G->nterms;
+    }
     }
     }
     groups.swap(staged);
@@ -706,7 +768,13 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     for (int i = 1; i < 4; ++i) { rec[WFK_FCE_A + i] = (double)G.A[i]; rec[WFK_FCE_B + i] = (double)G.B[i]; }
     rec[WFK_FCE_WM] = G.wm;     // (slots 13 / 21 carried redundant copies of the packed word before)
     rec[WFK_FCE_SM] = G.sm;
-    if (G.has_env) {
+    if (G.has_exp) {
+      // exp(alpha (t - ref)): the seeds are exp(alpha (x - ref)) and the constant ratio exp(alpha D)
+      rec[WFK_FCE_DEG] += (double)WFK_FCE_EXPENV;
+      rec[WFK_FCE_SIGMA] = G.sigma; rec[WFK_FCE_SG] = G.sg;
+      rec[WFK_FCE_H] = G.sigma * dstride; rec[WFK_FCE_Q] = 1.0;
+      rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
+    } else if (G.has_env) {
       double Hh = dstride / G.sigma;
       rec[WFK_FCE_SIGMA] = G.sigma; rec[WFK_FCE_SG] = G.sg;
       rec[WFK_FCE_H] = Hh; rec[WFK_FCE_Q] = std::exp(-2.0 * Hh * Hh);
@@ -867,7 +935,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             for (size_t j = 0; j < groups.size() && twin[i] < 0; ++j) {
               const FceGroup& g = groups[j];
               if (std::find(twin.begin(), twin.end(), (int)j) != twin.end()) continue;
-              if (g.W != m.W || g.imag != m.imag || g.has_env != m.has_env || g.sigma != m.sigma || g.sg != m.sg ||
+              if (g.W != m.W || g.imag != m.imag || g.has_env != m.has_env || g.has_exp != m.has_exp || g.sigma != m.sigma || g.sg != m.sg ||
                   g.sref != m.sref || g.psi_ref != m.psi_ref || g.has_lin != m.has_lin || g.slin != m.slin ||
                   g.deg != m.deg || g.corr != m.corr || g.wm != m.wm || g.sm != m.sm)
                 continue;
@@ -904,7 +972,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         if (groups.size() >= 4 && !mod_on) {
           bool shared = true, e32 = true;
           for (const FceGroup& g : groups) {
-            shared = shared && g.has_env && g.sigma == groups[0].sigma && g.sg == groups[0].sg;
+            shared = shared && g.has_env && !g.has_exp && g.sigma == groups[0].sigma && g.sg == groups[0].sg;
             e32 = e32 && g.env32;
           }
           if (shared) {

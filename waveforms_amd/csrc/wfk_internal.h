@@ -50,12 +50,13 @@
                               // deg (bits 0-1) | carrier << 2 | imag << 3 | env << 4 (2 bits) | f32ok << 6 |
                               // corr << 7 (per-sample grid-rounding correction of the carrier) | table offset << 8
                               // (11 bits) | state offset << 19 (6 bits, units of 128 doubles of the lean kernel's
-                              // per-lane state) | has (c, s) state << 25 | has (g, r) state << 26
+                              // per-lane state) | has (c, s) state << 25 | has (g, r) state << 26 | exp envelope << 27
 #define WFK_FCE_PACK(deg, carrier, imag, env, f32ok) ((deg) | ((carrier) << 2) | ((imag) << 3) | ((env) << 4) | ((f32ok) << 6))
 #define WFK_FCE_TABOFF(fl) (((fl) >> 8) & 0x7FF)
 #define WFK_FCE_STOFF(fl) ((((fl) >> 19) & 63) * 128)
 #define WFK_FCE_HAS_CS (1 << 25)
 #define WFK_FCE_HAS_GR (1 << 26)
+#define WFK_FCE_EXPENV (1 << 27)   // the envelope is exp(alpha (t - ref)): SIGMA = alpha, SG = ref, H = alpha * D, Q = 1
 #define WFK_FCE_A 5           // A0..A3
 #define WFK_FCE_B 9           // B0..B3
 #define WFK_FCE_WM 13         // corr ops: |w| of the reference COS factor whose rounded phase is mimicked

@@ -693,6 +693,7 @@ __device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x, in
     const double vm = v + 0.5 * Hh;
     return fce_seeds(v, 0.0, -(vm * vm), -Hh * (2.0 * vm + Hh), 2, 1);
   }
+  if (fl & WFK_FCE_EXPENV) v = 0.0;   // (exponential envelope: the seed exponents are linear, see below)
   const double sref = r[WFK_FCE_SREF], W = r[WFK_FCE_W];
   const double d = x - sref;
   const double th = W * d;
@@ -702,6 +703,8 @@ __device__ __forceinline__ FceSeeds fce_make_seeds(const double* r, double x, in
     const double ed = (x - (d - bb)) + (-sref - bb);
     lo = fma(W, ed, fma(W, d, -th));
   }
+  if (fl & WFK_FCE_EXPENV)   // g = exp(alpha (x - ref)), ratio exp(alpha D) (q = 1): SIGMA = alpha, SG = ref, H = alpha D
+    return fce_seeds(th, lo, r[WFK_FCE_SIGMA] * (x - r[WFK_FCE_SG]), Hh, (fl >> 2) & 1, (fl >> 4) & 3);
   return fce_seeds(th, lo, -(v * v), -Hh * (2.0 * v + Hh), (fl >> 2) & 1, (fl >> 4) & 3);
 }
 
