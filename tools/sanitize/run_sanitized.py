@@ -99,6 +99,34 @@ def drive(n_scripts):
         prog = _flatten.flatten(chans)
         assert compile_(prog, grid=_flatten.grid_from_desc(gd)) in (0, -2)
         done += 1
+    # oversampled grids: erf edges as closing multiplier ops (twins, several tones, overlapping edges),
+    # exponential envelopes (EXP / COSH / SINH, alone and under Gaussians), multi-tone pieces at the
+    # lean kernel's op limit -- the host paths added late in round 2
+    def tones(nt):
+        out = None
+        for _ in range(nt):
+            t = rng.uniform(0.05, 0.3) * wf.cos(2 * np.pi * rng.uniform(-3e8, 3e8), rng.uniform(0, 6))
+            out = t if out is None else out + t
+        return out
+    W = 40e-9
+    fine = [wf.square(W, edge=5e-9) >> 60e-9,
+            (wf.square(W, edge=5e-9) >> 60e-9) * tones(10),
+            (wf.square(W, edge=5e-9) >> 60e-9) * tones(14) * (0.3 - 0.4j),
+            (wf.square(6e-9, edge=5e-9) >> 60e-9) * tones(3),
+            wf.mixing(wf.square(W, edge=6e-9) >> 60e-9, freq=1.3e8, phase=0.2, DRAGScaling=2e-10)[0],
+            (wf.square(W, edge=5e-9) * wf.gaussian(2 * W) * tones(2)) >> 60e-9,
+            wf.coshPulse(W, eps=3.0, plateau=10e-9) >> 60e-9,
+            (wf.square(W) >> 60e-9) * (wf.exp(-3e7) >> 20e-9) * tones(2),
+            (wf.gaussian(W) >> 60e-9) * (wf.exp(4e7) >> 60e-9) * (wf.sinh(1e7) >> 50e-9),
+            (wf.square(W) >> 60e-9) * wf.exp(1e11),
+            (wf.gaussian(W) >> 60e-9) * tones(16)]
+    for gd in (('linspace', 0.0, 120e-9, 400001, False), ('linspace', 1e-3, 1e-3 + 120e-9, 300000, True),
+               ('linspace', 0.0, 120e-9, 2001, False)):
+        g = _flatten.grid_from_desc(gd)
+        for k in range(0, len(fine), 3):
+            prog = _flatten.flatten([c >> gd[1] for c in fine[k:k + 3]])
+            assert compile_(prog, grid=g) == 0, err.value
+            done += 1
     # multi-channel programs (chunk tables across channels) and the edge grids
     chans = [cases.random_channel(wf, rng)[0] for _ in range(9)]
     prog = _flatten.flatten(chans)
