@@ -65,6 +65,7 @@ def const_expr(c):
 
 
 ONE = const_expr(1.0)
+_UNIT_KEYS = (_UNIT_TERM, )
 HALF = const_expr(1 / 2)
 
 
@@ -122,11 +123,46 @@ def add(x, y):
     return tuple(keys), tuple(vals)
 
 
+def _ascending(keys) -> bool:
+    n = len(keys)
+    if n < 2:
+        return True
+    try:
+        return all(keys[i] < keys[i + 1] for i in range(n - 1))
+    except TypeError:               # (malformed operands: take the long way, fail where the reference fails)
+        return False
+
+
+def _scaled(keys, amps, c, amps_first):
+    """(keys, amps * c) without the zero products; amps_first: the product is amp * c, else c * amp
+    (the operand order of the reference's loop, which matters for complex / float rounding)."""
+    out_k, out_v = [], []
+    for k, a in zip(keys, amps):
+        v = a * c if amps_first else c * a
+        if v == 0:
+            continue
+        out_k.append(k)
+        out_v.append(v)
+    if len(out_k) == len(keys):
+        return keys, tuple(out_v)
+    return tuple(out_k), tuple(out_v)
+
+
 def mul(x, y):
     """Product of two expressions, distributing over terms
     (reference: _waveform.pyx:68-79)."""
-    if type(x[0]) is tuple and type(y[0]) is tuple and (not x[0] or not y[0]):
-        return ZERO                 # a zero operand: no term survives
+    kx, ky = x[0], y[0]
+    if type(kx) is tuple and type(ky) is tuple:
+        if not kx or not ky:
+            return ZERO             # a zero operand: no term survives
+        # A constant operand (one unit term) scales the other's amplitudes: every product term is the
+        # other operand's own term object (add() with the empty term returns it), and with ascending
+        # keys every insertion lands at the end of the window -- the loop below would rebuild the same
+        # tuples.  Zero products drop out, as there.
+        if kx == _UNIT_KEYS and _ascending(ky):
+            return _scaled(ky, y[1], x[1][0], False)
+        if ky == _UNIT_KEYS and _ascending(kx):
+            return _scaled(kx, x[1], y[1][0], True)
     keys, vals = [], []
     lo = hi = 0
     for (tx, ty), (ax, ay) in zip(itertools.product(x[0], y[0]),
@@ -171,8 +207,29 @@ def combine_pieces(b1, s1, b2, s2, oper):
     """Pointwise `oper` of two piecewise expressions; adjacent equal pieces are
     fused (reference: _waveform.pyx:216-235)."""
     bounds, seq = [], []
-    i = j = 0
     n1, n2 = len(b1), len(b2)
+    # one operand is a single piece up to +inf (a constant, a carrier): the other's bounds survive
+    if n2 == 1 and b2[0] == math.inf and n1 >= 1 and b1[-1] == math.inf:
+        e2 = s2[0]
+        for b, e1 in zip(b1, s1):
+            e = oper(e1, e2)
+            if seq and e == seq[-1]:
+                bounds[-1] = b
+            else:
+                bounds.append(b)
+                seq.append(e)
+        return tuple(bounds), tuple(seq)
+    if n1 == 1 and b1[0] == math.inf and n2 >= 1 and b2[-1] == math.inf:
+        e1 = s1[0]
+        for b, e2 in zip(b2, s2):
+            e = oper(e1, e2)
+            if seq and e == seq[-1]:
+                bounds[-1] = b
+            else:
+                bounds.append(b)
+                seq.append(e)
+        return tuple(bounds), tuple(seq)
+    i = j = 0
     while i < n1 or j < n2:
         e = oper(s1[i], s2[j])
         b = min(b1[i], b2[j])

@@ -332,13 +332,31 @@ class Waveform:
     def __radd__(self, v):
         return const(v) + self
 
+    def _scaled(self, v, wave_first):
+        """self * const(v) (wave_first) or const(v) * self: the one-piece constant operand of
+        combine_pieces, without building it (same products, same fusion of equal neighbours)."""
+        cw = const(v)
+        if len(cw.seq) != 1 or self.bounds[-1] != inf:
+            return self._comb(cw, _ir.mul) if wave_first else cw._comb(self, _ir.mul)
+        ce = cw.seq[0]
+        bounds, seq = [], []
+        mul = _ir.mul
+        for b, e in zip(self.bounds, self.seq):
+            e = mul(e, ce) if wave_first else mul(ce, e)
+            if seq and e == seq[-1]:
+                bounds[-1] = b
+            else:
+                bounds.append(b)
+                seq.append(e)
+        return Waveform(tuple(bounds), tuple(seq))
+
     def __mul__(self, other):
         if isinstance(other, Waveform):
             return self._comb(other, _ir.mul)
-        return self * const(other)
+        return self._scaled(other, True)
 
     def __rmul__(self, v):
-        return const(v) * self
+        return self._scaled(v, False)
 
     def __truediv__(self, other):
         if isinstance(other, Waveform):
@@ -832,10 +850,17 @@ def mixing(I: Waveform, Q: Waveform | None = None, *, phase: float = 0.0,
     """SSB (freq != 0) or envelope mixing of an I/Q pair, with optional DRAG
     correction built from the symbolic derivative
     (reference: waveforms/waveform.py:1487-1527)."""
-    if Q is None:
-        Q = zero()
     w = 2 * pi * freq
-    if freq != 0.0:
+    if Q is None:
+        # (the reference multiplies a zero waveform through and adds it: products with ZERO are ZERO
+        #  and adding the zero waveform changes neither bounds nor pieces -- skipped here)
+        if freq != 0.0:
+            Iout = I * cos(w, -phase)
+            Qout = -I * sin(w, -phase + phaseDiff)
+        else:
+            Iout = I * np.cos(-phase)
+            Qout = -I * np.sin(-phase)
+    elif freq != 0.0:
         Iout = I * cos(w, -phase) + Q * sin(w, -phase)
         Qout = -I * sin(w, -phase + phaseDiff) + Q * cos(w, -phase + phaseDiff)
     else:
