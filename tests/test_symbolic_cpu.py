@@ -167,3 +167,18 @@ def test_marker_mask_or_and_match_reference():
         for key, got in (('marker', w.marker), ('mask0', w.mask()), ('mask_e', w.mask(0.37)),
                          ('or', w | other), ('and', w & other)):
             assert got.tolist() == [golden_io.dec(x) for x in v[key]], (name, key)
+
+
+def test_zero_and_one_are_fresh_objects():
+    """callers set .start / .stop / .sample_rate / .min / .max on the waveforms they get: what zero()
+    and one() return must not be shared (the reference hands out module-level singletons,
+    waveform.py:886-896 -- attributes set on one then show up on every later zero())"""
+    import waveforms_amd as wf
+    z = wf.zero()
+    z.start, z.stop, z.sample_rate, z.max = 0.0, 1.0, 10.0, 0.5
+    z2 = wf.zero()
+    assert z2 is not z and z2.start is None and z2.sample_rate is None and z2.max == float('inf')
+    o = wf.one()
+    o.min = 0.25
+    assert wf.one().min == -float('inf')
+    assert wf.zero().tolist() == z2.tolist() and (wf.zero() + wf.one()).seq == wf.one().seq

@@ -553,16 +553,13 @@ class WaveVStack(Waveform):
 # --------------------------------------------------------------------------
 # constructors (reference: waveforms/waveform.py:886-896, 1055-1527)
 # --------------------------------------------------------------------------
-_ZERO_WF = Waveform()
-_ONE_WF = Waveform(seq=(ONE, ))
-
-
 def zero():
-    return _ZERO_WF
+    # (a fresh object per call: callers set .start / .stop / .sample_rate / .min / .max on what they get)
+    return Waveform()
 
 
 def one():
-    return _ONE_WF
+    return Waveform(seq=(ONE, ))
 
 
 def const(c):
