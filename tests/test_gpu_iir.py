@@ -308,3 +308,57 @@ def test_single_pass_chained_scan(nsec, n, rows):
     finally:
         del os.environ['WFK_IIR_ONEPASS']
     assert np.max(np.abs(three - got)) <= 1e-12 * pk and np.max(np.abs(zf3 - zf)) <= 1e-12 * max(1.0, np.abs(zf).max())
+
+
+@pytest.mark.parametrize('nsec,n,rows', [(1, 70001, 3), (2, 200003, 2), (3, 65536, 5), (4, 1_000_001, 4), (4, 3_000_017, 1)])
+def test_first_order_cascades(nsec, n, rows):
+    """Cascades of up to four FIRST-order sections -- the exponential corrections of a flux-line
+    predistortion (reference distortion.py:298-321: lfilter per (b, a)) -- take the single-pass form
+    too (state dimension <= 4).  Against scipy.signal.lfilter applied section by section, with
+    initial state, final state, DC offset, float32; both forms through the module fixture."""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(31 * nsec + n)
+    secs = []
+    for k in range(nsec):
+        tau = rng.uniform(20, 4000)                       # samples
+        amp = rng.uniform(-0.08, 0.08)
+        a1 = -np.exp(-1.0 / tau)
+        b0 = 1.0 + amp
+        b1 = a1 * (1.0 + amp * (1 - np.exp(-1.0 / tau)) * 0 ) - amp * 0 + a1 * 0
+        b1 = a1 - amp * (1 + a1) * 0.3
+        secs.append((np.array([b0, b1]), np.array([1.0, a1])))
+    x = rng.normal(size=(rows, n))
+    zi = rng.normal(size=(rows, nsec, 1)) * 0.1
+    want = np.empty_like(x)
+    zfw = np.empty_like(zi)
+    for r in range(rows):
+        y = x[r] - 0.25
+        for k, (b, a) in enumerate(secs):
+            y, zf_k = lfilter(b, a, y, zi=zi[r, k])
+            zfw[r, k] = zf_k
+        want[r] = y + 0.25
+
+    def run(dtype):
+        plan = _engine.IirPlan(secs, n, rows, dtype)
+        assert plan.state_dim == nsec
+        es = np.dtype(dtype).itemsize
+        dx, dy = _engine.DeviceBuffer(rows * n * es), _engine.DeviceBuffer(rows * n * es)
+        dzi, dzf = _engine.DeviceBuffer(zi.nbytes), _engine.DeviceBuffer(zi.nbytes)
+        dx.upload(x.astype(dtype))
+        dzi.upload(zi)
+        for _ in range(2):
+            plan.apply(dx.ptr, n, dy.ptr, n, dzi.ptr, dzf.ptr, 0.25)
+            _engine.sync()
+        got = dy.download((rows, n), dtype)
+        zf = dzf.download(zi.shape, np.float64)
+        for b_ in (dx, dy, dzi, dzf):
+            b_.close()
+        plan.close()
+        return got, zf
+
+    got, zf = run(np.float64)
+    pk = max(1.0, np.abs(want).max())
+    assert np.max(np.abs(got - want)) <= 1e-11 * pk
+    assert np.max(np.abs(zf - zfw)) <= 1e-11 * max(1.0, np.abs(zfw).max())
+    g32, _ = run(np.float32)
+    assert np.max(np.abs(g32 - want)) <= 2e-5 * pk

@@ -382,7 +382,7 @@ __device__ __forceinline__ void matvec_add_plain(double (&v)[IIR_MAXD], const do
   }
 }
 
-template <typename T, int NSEC, bool PLAIN>
+template <typename T, int NSEC, int ORD, bool PLAIN>
 __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, const T* __restrict__ in, int64_t in_stride,
                                                   T* __restrict__ out, int64_t out_stride,
                                                   unsigned* __restrict__ status, double* __restrict__ aggbuf,
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
                                                   const double* __restrict__ lanepU, const double* __restrict__ zi,
                                                   double* __restrict__ zf, int64_t n, int64_t nchunks, int rows,
                                                   unsigned epoch, double pre_sub, double post_add, int persist) {
-  constexpr int DD = 2 * NSEC;
+  constexpr int DD = NSEC * ORD;       // state dimension (<= 4)
   __shared__ T tile[64][OP_LB + 1];
   const int lane = threadIdx.x;
   // one ticket counter per row (64 B apart): a single counter for all rows serialises 3e5 atomics on
@@ -444,11 +444,11 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
   if (whole) {
 #pragma unroll
-    for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, 2>(c, xr[i], z);
+    for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, ORD>(c, xr[i], z);
   } else {
 #pragma unroll
     for (int i = 0; i < OP_LB; ++i)
-      if (i < cnt) (void)iir_step_t<NSEC, 2>(c, xr[i], z);
+      if (i < cnt) (void)iir_step_t<NSEC, ORD>(c, xr[i], z);
   }
   // (a block past the end of the row leaves its state alone: T1^0; the scan below still multiplies
   //  by T1 per block, which only matters AFTER the last sample -- nothing there is used)
@@ -583,11 +583,11 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   const double bad = poisoned ? __builtin_nan("") : 0.0;
   if (whole) {
 #pragma unroll
-    for (int i = 0; i < OP_LB; ++i) tile[lane][i] = (T)(iir_step_t<NSEC, 2>(c, xr[i], z) + post_add + bad);
+    for (int i = 0; i < OP_LB; ++i) tile[lane][i] = (T)(iir_step_t<NSEC, ORD>(c, xr[i], z) + post_add + bad);
   } else {
 #pragma unroll
     for (int i = 0; i < OP_LB; ++i)
-      if (i < cnt) tile[lane][i] = (T)(iir_step_t<NSEC, 2>(c, xr[i], z) + post_add + bad);
+      if (i < cnt) tile[lane][i] = (T)(iir_step_t<NSEC, ORD>(c, xr[i], z) + post_add + bad);
   }
   // final state of the row: the block that holds its last sample
   if (zf && chunk == nchunks - 1) {
@@ -871,8 +871,10 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
   }
   // single-pass form: one or two biquads (state dimension <= 4), rows long enough to chain
   {
-    bool biq = n_sections <= 2;
-    for (int s2 = 0; s2 < n_sections; ++s2) biq = biq && orders[s2] == 2;
+    // shapes: one or two biquads, or up to four FIRST-order sections -- the cascade of exponential
+    // corrections a flux-line predistortion is usually made of (state dimension <= 4)
+    bool biq = n_sections >= 1 && (orders[0] == 1 || orders[0] == 2) && n_sections * orders[0] <= 4;
+    for (int s2 = 0; s2 < n_sections; ++s2) biq = biq && orders[s2] == orders[0];
     // The default for these shapes since its loads are issued in one batch and the look-back no
     // longer chains on the nearest prefix (tools/iir_sweep.py, fp64, 1 / 2 biquads, three-launch vs
     // single pass): 1024 x 1e6 4.65 / 4.71 vs 3.08 / 3.44 ms (66 / 60 % of the HBM peak on 16 B/sample),
@@ -1026,19 +1028,28 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
         persist = 1;
       }
     }
-#define OP_LAUNCH(TT, NS)                                                                                     \
+#define OP_LAUNCH(TT, NS, OR)                                                                                     \
     if (p->op_plain)                                                                                          \
-    hipLaunchKernelGGL((iir_onepass<TT, NS, true>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
+    hipLaunchKernelGGL((iir_onepass<TT, NS, OR, true>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
                        (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
                        p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
                        initial, post, persist);                                                                         \
     else                                                                                                       \
-    hipLaunchKernelGGL((iir_onepass<TT, NS, false>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
+    hipLaunchKernelGGL((iir_onepass<TT, NS, OR, false>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
                        (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
                        p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
                        initial, post, persist)
-    if (p->kind == WFK_OUT_F32) { if (p->c.nsec == 1) OP_LAUNCH(float, 1); else OP_LAUNCH(float, 2); }
-    else { if (p->c.nsec == 1) OP_LAUNCH(double, 1); else OP_LAUNCH(double, 2); }
+#define OP_SHAPES(TT)                                                                              \
+    do {                                                                                           \
+      const int ns_ = p->c.nsec, or_ = p->c.ord[0];                                                \
+      if (or_ == 2) { if (ns_ == 1) { OP_LAUNCH(TT, 1, 2); } else { OP_LAUNCH(TT, 2, 2); } }       \
+      else if (ns_ == 1) { OP_LAUNCH(TT, 1, 1); }                                                  \
+      else if (ns_ == 2) { OP_LAUNCH(TT, 2, 1); }                                                  \
+      else if (ns_ == 3) { OP_LAUNCH(TT, 3, 1); }                                                  \
+      else { OP_LAUNCH(TT, 4, 1); }                                                                \
+    } while (0)
+    if (p->kind == WFK_OUT_F32) OP_SHAPES(float); else OP_SHAPES(double);
+#undef OP_SHAPES
 #undef OP_LAUNCH
     if (hipGetLastError() != hipSuccess) return iir_fail(WFK_EHIP, "IIR kernel launch failed");
     return WFK_OK;
