@@ -743,9 +743,17 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
       delete p;
       return iir_fail(WFK_EUNSUP, "a single IIR section of order > 16 (factor it into a cascade)");
     }
-    bool all_biquads = true;
-    for (int s = 0; s < n_sections; ++s) all_biquads = all_biquads && orders[s] == 2;
-    const bool split = n_sections > IIR_MAXSEC || Dtot > IIR_MAXD || (all_biquads && n_sections > 4);
+    // Register-resident kernels exist for runs of EQUAL order: up to four first-order sections or
+    // four biquads, single sections of order 3..8; anything else (mixed orders in one pass, two
+    // sections of order 3, ...) would take the runtime-shaped kernel with its state in scratch
+    // (34-68 ms per pass on 64 x 1e7 against ~3).  So the cascade is cut into such runs.
+    auto run_cap = [](int order) { return order == 1 || order == 2 ? 4 : 1; };
+    bool one_run = n_sections <= 1;
+    if (n_sections > 1) {
+      one_run = n_sections <= run_cap(orders[0]);
+      for (int s = 1; s < n_sections; ++s) one_run = one_run && orders[s] == orders[0];
+    }
+    const bool split = n_sections > IIR_MAXSEC || Dtot > IIR_MAXD || !one_run;
     if (split) {
       int ndev = 0;
       if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -758,12 +766,12 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
       if (n == 0) { *out = p; return WFK_OK; }
       int s0 = 0, pos0 = 0, doff = 0;
       while (s0 < n_sections) {
-        // greedy run: <= 4 biquads (register-resident kernels), else <= IIR_MAXSEC sections / IIR_MAXD states
+        // greedy run of equal orders, as long as a register-resident kernel takes it
         int cnt = 0, dd = 0, pp = 0;
         while (s0 + cnt < n_sections) {
           const int o = orders[s0 + cnt];
-          const int cap_sec = all_biquads ? 4 : IIR_MAXSEC;
-          if (cnt >= cap_sec || dd + o > IIR_MAXD) break;
+          if (cnt > 0 && (o != orders[s0] || cnt >= run_cap(o))) break;
+          if (dd + o > IIR_MAXD) break;
           dd += o; pp += o + 1; ++cnt;
         }
         wfk_iir_plan* q = nullptr;
