@@ -492,8 +492,32 @@ def run_rank(args):
             'note': 'C4 (BASELINE configs[3]) = predistort(wav(t), ker 1024 taps): sampler fused into the '
                     'LDS-FFT FIR kernel; frac = 8 B/sample (output only) / kernel time / 8 TB/s'}
         chn.close()
-        del out2
         fst.close()
+        # IIR stages of sample(filters=) / predistort(filters=) on the same 256 x 1e7 block (SURVEY 8(f)
+        # N1): a two-biquad sosfilt cascade and four first-order (exponential-correction) sections;
+        # 16 B/sample algorithmic (read + write), kernel time by HIP events
+        try:
+            from scipy.signal import butter
+            from waveforms_amd import _engine
+            stream = torch.cuda.current_stream().cuda_stream
+            iir = {}
+            shapes = {'two_biquads': [(s_[:3], s_[3:]) for s_ in butter(4, 0.1, output='sos')],
+                      'four_first_order': [(np.array([1.02, -np.exp(-1 / t_) * 1.01]), np.array([1.0, -np.exp(-1 / t_)]))
+                                           for t_ in (50.0, 400.0, 3000.0, 20000.0)]}
+            for sname, secs in shapes.items():
+                ip = _engine.IirPlan(secs, bs.n, bs.n_channels, dtype)
+                zi = torch.zeros((bs.n_channels, ip.state_dim), dtype=torch.float64, device='cuda')
+                zf = torch.empty_like(zi)
+                ms = timed(lambda: ip.apply(out.data_ptr(), bs.n, out2.data_ptr(), bs.n, zi.data_ptr(),
+                                            zf.data_ptr(), 0.0, stream), 5, 2)
+                iir[sname] = {'ms': ms, 'msamples_per_s': bs.n_channels * bs.n / (ms * 1e-3) / 1e6,
+                              'frac_16B_per_sample': 2 * algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                ip.close()
+            iir['note'] = 'iir_onepass (single-pass chained scan, x read once); WFK_IIR_ONEPASS=0: three launches'
+            also['iir'] = iir
+        except Exception as e:      # (the stage is outside the headline path: report, do not fail the line)
+            also['iir'] = {'error': repr(e)}
+        del out2
         # BASELINE configs[1] and [2] in the same line (kernel time by HIP events, frac of 8 TB/s)
         for wname in ('c2', 'c3'):
             wch, wpts = default_shape(wname)
