@@ -190,3 +190,29 @@ def test_fused_equals_unfused_bitwise_structure_and_linearity():
     imp[4] = 1.0
     y = c_oracle.eval_grid(_flatten.flatten(chans), _flatten.grid_from_desc(grid))
     assert np.max(np.abs(SampledFir(chans, grid, imp).to_host() - y)) <= 1e-12
+
+
+def test_erf_and_exponential_channels_take_the_two_kernel_path():
+    """erf edges and exponential envelopes are fused ops of the SAMPLER only: a chain over such channels
+    says so and runs sampler + FIR as two kernels, bit-identical to calling them one after the other"""
+    import torch
+    from waveforms_amd._sampling import BatchSampler
+    from waveforms_amd.distortion import FirStage, SampledFir
+    ch = [(wf.square(30e-9, edge=4e-9) >> 50e-9) * wf.cos(2 * np.pi * 1e8), wf.coshPulse(40e-9, eps=2.0) >> 60e-9,
+          (wf.gaussian(30e-9) >> 50e-9) * wf.cos(2 * np.pi * 2e8, 0.4)]
+    grid = ('linspace', 0.0, 120e-9, 400001, False)
+    ker = np.hanning(257)
+    ker /= ker.sum()
+    sf = SampledFir(ch, grid, ker)
+    assert not sf.fused and 'not fully fused' in sf.why_not
+    out = torch.empty((3, sf.n), dtype=torch.float64, device='cuda')
+    sf.launch_torch(out)
+    bs = BatchSampler(ch, grid)
+    raw = torch.empty_like(out)
+    bs.launch_torch(raw)
+    fir = FirStage(ker, bs.n, 3)
+    ref = torch.empty_like(out)
+    fir.apply_torch(raw, ref)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert SampledFir(ch[2:], grid, ker).fused            # the Gaussian channel alone still fuses

@@ -479,7 +479,7 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
   else if (!fir_fused || nseg != 1) p->why = "FIR kernel longer than one on-chip transform";
   else if (prog->n_channels > 65535) p->why = "more than 65535 channels";
   else if (wfk_compile_geom(prog, grid, 256, 16 + p->hopb, H, err) != WFK_OK) p->why = "geometry compile: " + err;
-  else if (!H.lean) p->why = "plan is not fully fused (generic / direct terms, or more than 10 ops per piece)";
+  else if (!H.lean) p->why = "plan is not fully fused (generic / direct terms -- erf edges and exponential envelopes included, which this kernel does not evaluate -- or too many ops per piece)";
   else {
     for (const DevChannel& c : H.channels)
       if (c.do_clip) p->why = "clip (min/max) on a channel";
