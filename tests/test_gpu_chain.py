@@ -192,27 +192,40 @@ def test_fused_equals_unfused_bitwise_structure_and_linearity():
     assert np.max(np.abs(SampledFir(chans, grid, imp).to_host() - y)) <= 1e-12
 
 
-def test_erf_and_exponential_channels_take_the_two_kernel_path():
-    """erf edges and exponential envelopes are fused ops of the SAMPLER only: a chain over such channels
-    says so and runs sampler + FIR as two kernels, bit-identical to calling them one after the other"""
+def test_erf_channels_take_the_two_kernel_path_and_exponentials_fuse():
+    """erf edges are a fused op of the SAMPLER only: a chain over such channels says so and runs
+    sampler + FIR as two kernels, bit-identical to calling them one after the other.  Exponential
+    envelopes (coshPulse, decays) are seeded by the chain kernel too and stay fused."""
     import torch
     from waveforms_amd._sampling import BatchSampler
     from waveforms_amd.distortion import FirStage, SampledFir
-    ch = [(wf.square(30e-9, edge=4e-9) >> 50e-9) * wf.cos(2 * np.pi * 1e8), wf.coshPulse(40e-9, eps=2.0) >> 60e-9,
-          (wf.gaussian(30e-9) >> 50e-9) * wf.cos(2 * np.pi * 2e8, 0.4)]
+    erf_ch = (wf.square(30e-9, edge=4e-9) >> 50e-9) * wf.cos(2 * np.pi * 1e8)
+    exp_ch = [wf.coshPulse(40e-9, eps=2.0) >> 60e-9,
+              (wf.square(50e-9) >> 60e-9) * (wf.exp(-4e7) >> 30e-9) * wf.cos(2 * np.pi * 1.5e8, 0.2),
+              (wf.gaussian(30e-9) >> 50e-9) * wf.cos(2 * np.pi * 2e8, 0.4)]
     grid = ('linspace', 0.0, 120e-9, 400001, False)
     ker = np.hanning(257)
     ker /= ker.sum()
-    sf = SampledFir(ch, grid, ker)
+
+    def two_kernels(ch):
+        bs = BatchSampler(ch, grid)
+        raw = torch.empty((len(ch), bs.n), dtype=torch.float64, device='cuda')
+        bs.launch_torch(raw)
+        fir = FirStage(ker, bs.n, len(ch))
+        ref = torch.empty_like(raw)
+        fir.apply_torch(raw, ref)
+        torch.cuda.synchronize()
+        return ref
+
+    sf = SampledFir([erf_ch] + exp_ch, grid, ker)
     assert not sf.fused and 'not fully fused' in sf.why_not
-    out = torch.empty((3, sf.n), dtype=torch.float64, device='cuda')
+    out = torch.empty((4, sf.n), dtype=torch.float64, device='cuda')
     sf.launch_torch(out)
-    bs = BatchSampler(ch, grid)
-    raw = torch.empty_like(out)
-    bs.launch_torch(raw)
-    fir = FirStage(ker, bs.n, 3)
-    ref = torch.empty_like(out)
-    fir.apply_torch(raw, ref)
     torch.cuda.synchronize()
-    assert torch.equal(out, ref)
-    assert SampledFir(ch[2:], grid, ker).fused            # the Gaussian channel alone still fuses
+    assert torch.equal(out, two_kernels([erf_ch] + exp_ch))
+    sx = SampledFir(exp_ch, grid, ker)
+    assert sx.fused, sx.why_not
+    out = torch.empty((3, sx.n), dtype=torch.float64, device='cuda')
+    sx.launch_torch(out)
+    torch.cuda.synchronize()
+    assert float((out - two_kernels(exp_ch)).abs().max()) <= 1e-12

@@ -460,7 +460,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool can_fuse = !H.tlist && !nofast && !(nofuse_env && nofuse_env[0] == '1');
 
   const char* noexp_env = std::getenv("WFK_DISABLE_EXPFUSE");
-  const bool expfuse = ns_override == 0 && !(noexp_env && noexp_env[0] == '1');   // (the chain kernel seeds Gaussians only)
+  const bool expfuse = !(noexp_env && noexp_env[0] == '1');
   const char* noerf_env = std::getenv("WFK_DISABLE_ERFMUL");
   const bool erfmod = can_fuse && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
 

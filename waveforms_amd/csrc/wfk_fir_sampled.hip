@@ -222,6 +222,9 @@ __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, 
 
 __device__ __forceinline__ ChSeeds chain_make_seeds(const double* r, double x, int fl) {
   const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA], Hh = r[WFK_FCE_H];
+  if (fl & WFK_FCE_EXPENV)   // exponential envelope: g = exp(alpha (x - ref)), constant ratio exp(alpha D) (q = 1)
+    return chain_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), r[WFK_FCE_SIGMA] * (x - r[WFK_FCE_SG]), Hh,
+                       (fl >> 2) & 1, true);
   return chain_seeds(r[WFK_FCE_W] * (x - r[WFK_FCE_SREF]), -(v * v), -Hh * (2.0 * v + Hh), (fl >> 2) & 1,
                      ((fl >> 4) & 3) != 0);
 }
