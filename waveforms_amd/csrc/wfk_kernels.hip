@@ -504,63 +504,6 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
 // no error growth); the (C,S) table entries are wave-wide LDS broadcasts.
 struct FceSeeds { double c, s, g, r; };
 
-// Seed arithmetic without libm's generality (the polynomials of wfk_fir_sampled.hip's seed kernels):
-// sin / cos of pi r for an already reduced |r| <= 1/2 (Taylor through t^17 / t^18 on |t| <= pi/4 after
-// the quarter fold: truncation < 1e-19), exp by n = rint(x log2 e), a two-word ln 2, Taylor through
-// r^14 on |r| <= ln2 / 2, ldexp (< 5e-18).  About half the instructions of sincospi + 2 exp, and one
-// seed phase per chunk is 7-8 % of the sampler kernels' time.  -DWFK_SEED_LIBM: libm.
-__device__ __forceinline__ void sincospi_seed(double r, double* sn, double* cs) {
-  const double a = fabs(r);
-  const bool swap = a > 0.25;
-  const double z = swap ? 0.5 - a : a;                    // exact
-  const double t = z * 3.141592653589793116 + z * 1.2246467991473532e-16;
-  const double t2 = t * t;
-  double ps = -2.8114572543455206e-15;                    // -1/17!
-  ps = fma(ps, t2, 7.6471637318198164e-13);
-  ps = fma(ps, t2, -1.6059043836821613e-10);
-  ps = fma(ps, t2, 2.5052108385441720e-08);
-  ps = fma(ps, t2, -2.7557319223985893e-06);
-  ps = fma(ps, t2, 1.9841269841269841e-04);
-  ps = fma(ps, t2, -8.3333333333333332e-03);
-  ps = fma(ps, t2, 1.6666666666666666e-01);
-  const double s = fma(-t * t2, ps, t);
-  double pc = 1.5619206968586226e-16;                     //  1/18!
-  pc = fma(pc, t2, -4.7794773323873853e-14);
-  pc = fma(pc, t2, 1.1470745597729725e-11);
-  pc = fma(pc, t2, -2.0876756987868099e-09);
-  pc = fma(pc, t2, 2.7557319223985888e-07);
-  pc = fma(pc, t2, -2.4801587301587302e-05);
-  pc = fma(pc, t2, 1.3888888888888889e-03);
-  pc = fma(pc, t2, -4.1666666666666664e-02);
-  pc = fma(pc, t2, 0.5);
-  const double c = fma(-t2, pc, 1.0);
-  const double ss = swap ? c : s, cc = swap ? s : c;
-  *sn = r < 0.0 ? -ss : ss;
-  *cs = cc;
-}
-
-__device__ __forceinline__ double exp_seed_poly(double x) {
-  const double n = rint(x * 1.4426950408889634);
-  double r = fma(-n, 6.93147180369123816490e-01, x);      // ln2 high word (low 11 bits zero: n * hi exact)
-  r = fma(-n, 1.90821492927058770002e-10, r);             // ln2 low word
-  double p = 1.1470745597729725e-11;                      // 1/14!
-  p = fma(p, r, 1.6059043836821613e-10);
-  p = fma(p, r, 2.0876756987868099e-09);
-  p = fma(p, r, 2.5052108385441720e-08);
-  p = fma(p, r, 2.7557319223985888e-07);
-  p = fma(p, r, 2.7557319223985893e-06);
-  p = fma(p, r, 2.4801587301587302e-05);
-  p = fma(p, r, 1.9841269841269841e-04);
-  p = fma(p, r, 1.3888888888888889e-03);
-  p = fma(p, r, 8.3333333333333332e-03);
-  p = fma(p, r, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
-}
-
 // All libm work of one fused op in ONE out-of-line routine: the three polynomial chains
 // (sincospi, exp, exp) are independent, so the scheduler interleaves them, and their
 // constants are not live across the sampling loops.
@@ -577,24 +520,15 @@ __device__ __attribute__((noinline)) FceSeeds fce_seeds(double theta, double the
     const double xl = fma(theta, IPI_HI, -xh) + fma(theta, IPI_LO, theta_lo * IPI_HI);
     const double n = rint(xh);
     double ss, cc;
-#ifdef WFK_SEED_LIBM
     sincospi((xh - n) + xl, &ss, &cc);
-#else
-    sincospi_seed((xh - n) + xl, &ss, &cc);
-#endif
     const bool odd = ((long long)n) & 1;
     o.s = odd ? -ss : ss;
     o.c = odd ? -cc : cc;
   }
   if (carrier == 2) o.c = erf(theta);   // closing erf multiplier: the running value E = erf(v)
   if (env) {
-#ifdef WFK_SEED_LIBM
     o.g = exp(ea);
     o.r = exp(eb);
-#else
-    o.g = exp_seed_poly(ea);
-    o.r = exp_seed_poly(eb);
-#endif
   }
   return o;
 }
