@@ -440,8 +440,12 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     size_t tab_off = WFK_BLK_HDR + B.body.size();
     if (tab_off & 1) ++tab_off;  // 16-byte aligned tables
     for (auto& r : B.table_refs) B.body[r.first] = (double)(tab_off + (size_t)r.second * 2 * (NS + 1));
-    for (size_t at : B.fce_ats)   // the table offset also travels in the packed op word
+    for (size_t at : B.fce_ats) {   // the table offset also travels in the packed op word ...
       B.body[at + WFK_FCE_DEG] += 256.0 * B.body[at + WFK_FCE_TAB];
+      // ... which the device reads as a 32-bit integer (WFK_FCE_WORD): low half of the slot
+      const uint64_t word = (uint32_t)(int64_t)B.body[at + WFK_FCE_DEG];
+      std::memcpy(&B.body[at + WFK_FCE_DEG], &word, sizeof word);
+    }
     size_t len = tab_off + B.tables.size();
     H.params.push_back((double)len);
     H.params.push_back((double)B.n_terms);

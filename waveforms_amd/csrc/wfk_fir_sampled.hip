@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
       }
       for (int op = 0; op < nops; ++op) {
         const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
-        const int fl = cuni((int)rec[WFK_FCE_DEG]);
+        const int fl = cuni(WFK_FCE_WORD(rec));
         const int env = (fl >> 4) & 3, carrier = (fl >> 2) & 1;
         ChSeeds sd, nx;
         if (carried && op == 0) sd = car[0];

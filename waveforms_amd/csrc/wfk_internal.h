@@ -52,6 +52,10 @@
                               // (11 bits) | state offset << 19 (6 bits, units of 128 doubles of the lean kernel's
                               // per-lane state) | has (c, s) state << 25 | has (g, r) state << 26 | exp envelope << 27
 #define WFK_FCE_PACK(deg, carrier, imag, env, f32ok) ((deg) | ((carrier) << 2) | ((imag) << 3) | ((env) << 4) | ((f32ok) << 6))
+// The word travels as a 32-bit INTEGER in the low half of its slot (the host converts when it closes a
+// block): the device reads it with one 32-bit load and decodes it on the scalar unit -- as a double it
+// had to go through v_cvt_i32_f64, and every flag test after it became a VALU compare + vcc branch.
+#define WFK_FCE_WORD(rec) (reinterpret_cast<const int*>(rec)[2 * WFK_FCE_DEG])
 #define WFK_FCE_TABOFF(fl) (((fl) >> 8) & 0x7FF)
 #define WFK_FCE_STOFF(fl) ((((fl) >> 19) & 63) * 128)
 #define WFK_FCE_HAS_CS (1 << 25)

@@ -792,7 +792,7 @@ __device__ __forceinline__ void apply_fce(const double* blk, const double* r, co
                                           double tshift, int64_t j0, T (&acc)[NS]) {
   double x = grid_time(a, j0);
   if (tshift != 0.0) x = x - tshift;
-  const int fl = uni((int)r[WFK_FCE_DEG]);
+  const int fl = uni(WFK_FCE_WORD(r));
   FceSeeds sd = fce_make_seeds(r, x, fl);
   fce_eval<T, NS>(blk, r, sd, x, false, acc, fl);
 }
@@ -964,7 +964,7 @@ wfk_sample_lean(const KArgs a) {
           // seed phase: libm, nothing else live
           for (int op = 0; op < nops; ++op) {
             const double* srec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
-            const int sfl = uni((int)srec[WFK_FCE_DEG]);
+            const int sfl = uni(WFK_FCE_WORD(srec));
             const FceSeeds sd = fce_make_seeds<CORR>(srec, x, sfl);
             double* st = s_st + WFK_FCE_STOFF(sfl) + lane;
             if (sfl & WFK_FCE_HAS_CS) {
@@ -996,7 +996,7 @@ wfk_sample_lean(const KArgs a) {
           const double* rec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
           // an op of the imaginary part (complex amplitudes) adds into acci; a real-output
           // launch of such a channel keeps the real part only, like WaveVStack's `.real`
-          const int fl = uni((int)rec[WFK_FCE_DEG]);     // packed op word: one read for all flags
+          const int fl = uni(WFK_FCE_WORD(rec));        // packed op word: one 32-bit read for all flags
           // per-lane state: (c, s) and / or (g, r), 64 doubles each, only what the op has
           double* const st = s_st + WFK_FCE_STOFF(fl) + lane;
           double* const stg = st + ((fl & (WFK_FCE_HAS_CS | WFK_FCE_HAS_GR)) == (WFK_FCE_HAS_CS | WFK_FCE_HAS_GR) ? 128 : 0);
@@ -1100,7 +1100,7 @@ __global__ void __launch_bounds__(WFK_WG) wfk_sample(const KArgs a) {
           for (int k = 0; k < nops; ++k) {
             const int kind = uni((int)s_par[pos]);
             if (!TLIST && kind == WFK_OP_FCE) {
-              const int fl = uni((int)s_par[pos + WFK_FCE_DEG]);
+              const int fl = uni(WFK_FCE_WORD(s_par + pos));
               if (((fl >> 4) & 3) == 3) {
                 double x = grid_time(a, j0);
                 if (C.tshift != 0.0) x = x - C.tshift;
