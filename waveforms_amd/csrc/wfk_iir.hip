@@ -747,7 +747,12 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     // four biquads, single sections of order 3..8; anything else (mixed orders in one pass, two
     // sections of order 3, ...) would take the runtime-shaped kernel with its state in scratch
     // (34-68 ms per pass on 64 x 1e7 against ~3).  So the cascade is cut into such runs.
-    auto run_cap = [](int order) { return order == 1 || order == 2 ? 4 : 1; };
+    // three or four biquads: one three-launch pass (64 x 1e7: 3.1-3.2 ms; as two single passes 5.7-6.3),
+    // except on small problems, where the three launches cost 0.4-0.6 ms whatever the size (64 x 1e5,
+    // four biquads: 0.62 ms against 0.12 ms as two single passes)
+    int biq_cap = (double)batch * (double)n <= 3e7 ? 2 : 4;
+    if (const char* e = getenv("WFK_IIR_BIQ_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 4) biq_cap = v; }
+    auto run_cap = [biq_cap](int order) { return order == 1 ? 4 : (order == 2 ? biq_cap : 1); };
     bool one_run = n_sections <= 1;
     if (n_sections > 1) {
       one_run = n_sections <= run_cap(orders[0]);
