@@ -1061,7 +1061,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
   H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
   auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
-                      std::vector<int32_t>& chunk_first, int lean_cap = 8) {
+                      std::vector<int32_t>& chunk_first, int lean_cap = 8, int64_t lean_div = 2048) {
     // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
     // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
     tile = (lean_geom ? 64 : WFK_WG) * H.ns;
@@ -1071,7 +1071,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
     // any moment compact, which is what the HBM write rate depends on:
     // measured best at 8 tiles (= one seed per chunk) on the headline config, 4 on C2.
-    const int64_t tpc = total_tiles / (lean_geom ? 2048 : 8192);
+    const int64_t tpc = total_tiles / (lean_geom ? lean_div : 8192);
     tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? lean_cap : 16, std::max<int64_t>(1, tpc));
     if (const char* e = std::getenv("WFK_TPC")) {   // tuning override
       int v = std::atoi(e);
@@ -1099,8 +1099,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       const int v = std::atoi(e);
       if (v >= 1 && v <= 64) cap32 = v;
     }
-    chunking(true, tile32, H.f32_tiles_per_chunk, H.f32_chunks_per_ch, H.f32_chunk_first, cap32);
-    if (H.f32_tiles_per_chunk == (H.mixed ? H.lean_tiles_per_chunk : H.tiles_per_chunk)) {
+    // (beyond the double table's 8 tiles only where at least ~8 chunks per resident wave remain: C3's
+    //  250 k tiles run best at 8-10 tiles per chunk -- 0.201 ms against 0.219 at 20 -- the 2.5 M tiles of
+    //  256 x 1e7 at 16-20)
+    chunking(true, tile32, H.f32_tiles_per_chunk, H.f32_chunks_per_ch, H.f32_chunk_first, cap32, 24576);
+    if (H.f32_tiles_per_chunk <= (H.mixed ? H.lean_tiles_per_chunk : H.tiles_per_chunk)) {
       H.f32_chunk_first.clear();      // nothing to gain: the double table serves
       H.f32_tiles_per_chunk = 0;
     }
