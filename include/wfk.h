@@ -213,7 +213,12 @@ int wfk_chain_plan_destroy(wfk_chain_plan* plan);
  * coefficients each (a[0] of a section need not be 1).  State layout == scipy's zi:
  * sections back to back, orders[s] values each (total wfk_iir_state_dim()).
  * apply: out = F(in - initial) + initial; zi_dev/zf_dev: optional [batch][state_dim]
- * device arrays (initial state in, final state out; NULL = zeros / not wanted).       */
+ * device arrays (initial state in, final state out; NULL = zeros / not wanted).
+ * Execution form, chosen per plan: one or two biquads and cascades of up to four first-order
+ * sections (state dimension <= 4) run as ONE kernel that reads x once (chained scan with decoupled
+ * look-back); other shapes as a block scan in three launches; cascades of mixed orders or beyond
+ * those sizes as consecutive passes.  A plan owns scratch state for its launches: use one plan per
+ * concurrent stream.  In place (out_dev == in_dev) is allowed in every form.           */
 typedef struct wfk_iir_plan wfk_iir_plan;
 int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double* b,
                         const double* a, int64_t n, int32_t batch,
