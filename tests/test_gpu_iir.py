@@ -144,7 +144,12 @@ def test_iir_batch_shapes_and_properties():
         shapes.append([(r[:3], r[3:]) for r in sos])
     b1, a1 = butter(1, 0.1)
     b3, a3 = butter(3, 0.2)
-    shapes.append([(b1, a1), (b3, a3)])          # mixed orders -> generic kernel
+    shapes.append([(b1, a1), (b3, a3)])          # mixed orders: cut into runs of equal order
+    firsts = [(np.array([1.0 + 0.01 * k, -0.9 - 0.01 * k]), np.array([1.0, -0.95 + 0.02 * k])) for k in range(6)]
+    shapes.append(firsts)                         # six first-order sections: runs of 4 + 2
+    sos2 = butter(4, 0.1, output='sos')
+    shapes.append(firsts[:3] + [(r[:3], r[3:]) for r in sos2])   # orders 1,1,1,2,2
+    shapes.append([(b3, a3), (b3, a3)])          # two order-3 sections: one pass each
     for n in (1, 63, 2048, 2049, 150_001):
         for sec in shapes:
             batch = 3
