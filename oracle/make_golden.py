@@ -104,6 +104,29 @@ def make_c4_full(ref, gold):
     np.savez_compressed(os.path.join(gold, 'c4_full.npz'), **full)
 
 
+def make_late(ref, gold):
+    """tests/cases.py LATE_CASES (oversampled grids: fused erf edges, exponential envelopes), evaluated
+    by the reference at full length; stored: strided subset + the samples around every piece edge."""
+    import cases
+    from waveforms_amd import workloads as wl
+    from waveforms.waveform import WaveVStack
+    late = {}
+    for name, (build, grid) in cases.LATE_CASES.items():
+        w = build(ref)
+        t = wl.make_grid(grid)
+        y = np.asarray(w(t))
+        if isinstance(w, WaveVStack):
+            edges = np.unique(np.concatenate([np.searchsorted(t - w.shift if w.shift != 0 else t, b) for b, _ in w.wlist]))
+        else:
+            edges = np.searchsorted(t, w.bounds)
+        near = np.unique(np.clip((edges[:, None] + np.arange(-3, 4)[None, :]).ravel(), 0, len(t) - 1))
+        pick = np.unique(np.concatenate([np.arange(0, len(t), 211), near]))
+        late[name + '.pick'] = pick
+        late[name + '.y'] = y[pick]
+        late[name + '.sum'] = np.array([y.sum(), np.abs(y).sum(), np.abs(y).max()])
+    np.savez_compressed(os.path.join(gold, 'late.npz'), **late)
+
+
 def main():
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -116,6 +139,9 @@ def main():
     os.makedirs(gold, exist_ok=True)
     if sys.argv[1:] == ['c4_full']:        # regenerate this fixture only
         make_c4_full(ref, gold)
+        return
+    if sys.argv[1:] == ['late']:           # regenerate this fixture only
+        make_late(ref, gold)
         return
 
     # ---- filter-design helpers of distortion.py (host-side, no sampling) ----------
@@ -315,6 +341,7 @@ def main():
         spec[f'{i}.shift'] = dist.shift(sig, 3.3 / fs * (1 if i % 2 else -1), 1 / fs)
     spec['zker'] = dist.zDistortKernel(1e-9, [(50e-9, 0.02), (400e-9, -0.01)])
     np.savez_compressed(os.path.join(gold, 'spectral.npz'), **spec)
+    make_late(ref, gold)
     for f in sorted(os.listdir(gold)):
         print(f, os.path.getsize(os.path.join(gold, f)))
 

@@ -543,3 +543,80 @@ def user_sample_case(ns):
 
 def uf_tanh_edge(t, s):
     return np.tanh(t / s)
+
+
+# ---- oversampled grids: what the late round-2 fusions evaluate (erf edges as closing ops,
+# exponential envelopes).  Evaluated by the real reference into tests/golden/late.npz
+# (oracle/make_golden.py late): strided subset + the samples around every piece edge + sums.
+def _late_tones(ns, seed, nt, lo=-300e6, hi=300e6, cplx=False):
+    rng = np.random.default_rng(seed)
+    out = None
+    for _ in range(nt):
+        t = rng.uniform(0.05, 0.3) * ns.cos(2 * pi * rng.uniform(lo, hi), rng.uniform(0, 6))
+        if cplx:
+            t = t * complex(rng.uniform(-1, 1), rng.uniform(-1, 1))
+        out = t if out is None else out + t
+    return out
+
+
+def _late_flat_tops(ns):
+    w = ns.zero()
+    for k in range(4):
+        w = w + 0.7 * (ns.square(30e-9, edge=4e-9) >> (20e-9 + k * 50e-9))
+    return w
+
+
+def _late_readout(ns, nt, seed, cplx=False):
+    w = ns.zero()
+    tones = _late_tones(ns, seed, nt, cplx=cplx)
+    for k in range(4):
+        w = w + ((ns.square(30e-9, edge=4e-9) >> ((k + 0.5) * 55e-9 + 1.3e-9)) * tones)
+    return w
+
+
+def _late_mixing(ns):
+    env = ns.square(40e-9, edge=6e-9) >> 60e-9
+    I, Q = ns.mixing(env, freq=137e6, phase=0.4, DRAGScaling=3e-10)
+    return I + 0.3 * Q
+
+
+def _late_flat_gauss_stack(ns):
+    a = (ns.square(30e-9, edge=5e-9) * ns.gaussian(60e-9) * _late_tones(ns, 3, 2)) >> 50e-9
+    b = (ns.gaussian(20e-9) >> 36e-9) * ns.cos(2 * pi * 80e6)
+    return ns.WaveVStack([a, b]) + 0.05
+
+
+def _late_cosh(ns):
+    p = ns.coshPulse(60e-9, eps=3.0, plateau=25e-9) >> 110e-9
+    I, _ = ns.mixing(p, freq=140e6, phase=0.7, DRAGScaling=2e-10)
+    return I + 0.5 * (ns.coshPulse(40e-9, eps=1.0) >> 40e-9)
+
+
+def _late_exp(ns):
+    decay = (ns.square(80e-9) >> 50e-9) * (ns.exp(-1 / 30e-9) >> 10e-9)
+    g = (ns.gaussian(40e-9) >> 150e-9) * (ns.exp(2e7) >> 150e-9) * ns.cos(2 * pi * 210e6)
+    s = (ns.square(40e-9) >> 190e-9) * (ns.sinh(3e7) >> 190e-9) * (ns.exp(-1e7) >> 180e-9)
+    return decay - 2 * g + s
+
+
+def _late_far(ns):
+    t0 = 1.0e-3
+    w = ns.zero()
+    tones = _late_tones(ns, 21, 3, 250e6, 350e6)
+    for k in range(3):
+        w = w + ((ns.square(30e-9, edge=4e-9) >> (t0 + (k + 0.5) * 60e-9)) * tones)
+    return w
+
+
+LATE_GRID = ('linspace', 0.0, 220e-9, 800_003, False)
+LATE_CASES = {
+    'flat_tops': (_late_flat_tops, LATE_GRID),
+    'readout3': (lambda ns: _late_readout(ns, 3, 8), LATE_GRID),
+    'readout10': (lambda ns: _late_readout(ns, 10, 15), LATE_GRID),
+    'readout_cplx': (lambda ns: _late_readout(ns, 3, 9, cplx=True), LATE_GRID),
+    'mixing_flat_drag': (_late_mixing, LATE_GRID),
+    'flat_gauss_stack': (_late_flat_gauss_stack, LATE_GRID),
+    'cosh': (_late_cosh, LATE_GRID),
+    'exp': (_late_exp, LATE_GRID),
+    'far_flat': (_late_far, ('linspace', 1.0e-3, 1.0e-3 + 180e-9, 600_000, False)),
+}

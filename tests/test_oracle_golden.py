@@ -150,3 +150,24 @@ def test_oracles_match_reference_far_from_origin(seed):
         want = FUZZ[f'far{seed}.{c}']
         close(np.asarray(np_oracle.call(w, t)).real.astype(np.float64), want, rel=1e-13)
         close(c_oracle.eval_grid(_flatten.flatten([w]), g)[0], want, rel=1e-11)
+
+
+@pytest.mark.parametrize('name', sorted(cases.LATE_CASES))
+def test_oracles_match_reference_on_oversampled_grids(name):
+    """tests/golden/late.npz: flat tops with erf edges, multi-tone readout, cosh pulses, exponential
+    factors on 600 k - 800 k point grids, evaluated by the real reference (strided subset + every piece
+    edge).  These are the shapes the late round-2 fusions evaluate on the device; both oracles are
+    pinned on them here."""
+    late = golden_io.npz('late.npz')
+    build, grid = cases.LATE_CASES[name]
+    w = build(wf)
+    t = wl.make_grid(grid)
+    pick, want = late[name + '.pick'], late[name + '.y']
+    pk = max(1.0, float(np.abs(want).max()))
+    got_np = np.asarray(np_oracle.call(w, t[pick]))
+    assert np.max(np.abs(got_np - want)) <= 1e-13 * pk
+    prog = _flatten.flatten([w])
+    cplx = np.iscomplexobj(want)
+    got_c = c_oracle.eval_tlist(prog, t[pick], cplx)[0]
+    far = abs(grid[1]) > 1e-5
+    assert np.max(np.abs(got_c - want)) <= (1e-9 if far else 1e-12) * pk
