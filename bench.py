@@ -518,8 +518,18 @@ def run_rank(args):
         except Exception as e:      # (the stage is outside the headline path: report, do not fail the line)
             also['iir'] = {'error': repr(e)}
         del out2
-        # BASELINE configs[1] and [2] in the same line (kernel time by HIP events, frac of 8 TB/s)
-        for wname in ('c2', 'c3'):
+        # the same 256 x 1e7 plan launched into a float buffer (4 B/sample)
+        if dtype == np.float64:
+            o32 = torch.empty((bs.n_channels, bs.n), device='cuda', dtype=torch.float32)
+            ms = timed(lambda: bs.launch_torch(o32), 10, 3)
+            also['f32'] = {'workload': 'sampler256, float output', 'kernel': bs.plan.kernel_name(np.float32),
+                           'kernel_ms': ms, 'msamples_per_s': bs.n_channels * bs.n / (ms * 1e-3) / 1e6,
+                           'algorithmic_bytes_per_launch': algo_bytes // 2,
+                           'frac': algo_bytes / 2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'dtype': 'f32'}
+            del o32
+        # BASELINE configs[1] and [2], and the far-from-origin sequence, in the same line (kernel time
+        # by HIP events, frac of 8 TB/s)
+        for wname in ('c2', 'c3', 'far'):
             wch, wpts = default_shape(wname)
             mk, g, dt_, d_ = workload(wname, wch, wpts)
             b2 = BatchSampler([mk(c) for c in range(wch)], g)
