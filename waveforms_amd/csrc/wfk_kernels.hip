@@ -590,6 +590,15 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
   const T A2 = DEG > 1 ? (T)r[WFK_FCE_A + 2] : (T)0, A3 = DEG > 1 ? (T)r[WFK_FCE_A + 3] : (T)0;
   const T B2 = DEG > 1 ? (T)r[WFK_FCE_B + 2] : (T)0, B3 = DEG > 1 ? (T)r[WFK_FCE_B + 3] : (T)0;
   const T ac = A0 * c0, as = A0 * s0;  // DEG == 0
+  // DEG >= 1 without the rounding correction: the seed phasor folds into the polynomials once per
+  // tile -- A(u) ck + B(u) sk with ck = c0 C - s0 S, sk = s0 C + c0 S is C P(u) + S Q(u) with
+  // P_i = A_i c0 + B_i s0, Q_i = B_i c0 - A_i s0: per sample two Horner chains and two products
+  // instead of the polynomials, the phasor rotation AND the combination (degree 1: 4 instead of 8).
+  const bool fold = CARRIER && !CORR && DEG > 0;
+  const T P0 = fold ? A0 * c0 + B0 * s0 : (T)0, P1 = fold ? A1 * c0 + B1 * s0 : (T)0;
+  const T Q0 = fold ? B0 * c0 - A0 * s0 : (T)0, Q1 = fold ? B1 * c0 - A1 * s0 : (T)0;
+  const T P2 = fold && DEG > 1 ? A2 * c0 + B2 * s0 : (T)0, P3 = fold && DEG > 1 ? A3 * c0 + B3 * s0 : (T)0;
+  const T Q2 = fold && DEG > 1 ? B2 * c0 - A2 * s0 : (T)0, Q3 = fold && DEG > 1 ? B3 * c0 - A3 * s0 : (T)0;
   const double D = r[WFK_FCE_D];
   S g = (S)sd.g, rr = (S)sd.r;
   const S q = (S)r[WFK_FCE_Q];
@@ -623,6 +632,18 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
         } else {
           val = A0;
         }
+      } else if constexpr (CARRIER && !CORR) {
+        const double2 cs = tb[kb & 1][kk];
+        T pp, qq;
+        if (DEG == 1) {
+          pp = P1 * u + P0;
+          qq = Q1 * u + Q0;
+        } else {
+          pp = ((P3 * u + P2) * u + P1) * u + P0;
+          qq = ((Q3 * u + Q2) * u + Q1) * u + Q0;
+        }
+        u += Dt;
+        val = pp * (T)cs.x + qq * (T)cs.y;
       } else {
         T pa, pb;
         if (DEG == 1) {
