@@ -1061,7 +1061,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
   H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
   auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
-                      std::vector<int32_t>& chunk_first, int lean_cap = 8, int64_t lean_div = 2048) {
+                      std::vector<int32_t>& chunk_first, int lean_cap = WFK_LEAN_TPC, int64_t lean_div = 2048) {
     // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
     // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
     tile = (lean_geom ? 64 : WFK_WG) * H.ns;
@@ -1070,7 +1070,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves.  Longer
     // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
     // any moment compact, which is what the HBM write rate depends on:
-    // measured best at 8 tiles (= one seed per chunk) on the headline config, 4 on C2.
+    // measured best at 8 tiles (= one seed per chunk) on the headline config while a degree-1 op cost
+    // 12 instructions per sample, at 5 since the phasor fold (8: same box 3.19 / 6: 3.11 / 5: 3.07 / 4: 3.16 ms);
+    // 4 on C2.
     const int64_t tpc = total_tiles / (lean_geom ? lean_div : 8192);
     tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? lean_cap : 16, std::max<int64_t>(1, tpc));
     if (const char* e = std::getenv("WFK_TPC")) {   // tuning override

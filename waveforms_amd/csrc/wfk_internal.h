@@ -105,6 +105,7 @@
 #define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles (fp64 outputs: drift 9e-13 over 128 steps)
 #endif
 #define WFK_LEAN_RESEED_F32 32 // ... float outputs
+#define WFK_LEAN_TPC 5         // tiles per chunk of a double lean launch (upper limit; WFK_TPC overrides)
 #define WFK_LEAN_TPC_F32 20    // ... whose lean launches take up to this many tiles per chunk (8 for double), as
                               // long as ~8 chunks per resident wave remain (total tiles / 24576: C3 gets 10);
                               // same box, cap 8 / 12 / 16 / 20 / 24 / 32: fp32 256 x 1e7 1.99 / 1.91 / 1.88 / 1.88 /
