@@ -186,6 +186,12 @@ __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, 
   const T c0 = (T)sd.c, s0 = (T)sd.s;
   const T A0 = (T)r[WFK_FCE_A], A1 = (T)r[WFK_FCE_A + 1], A2 = (T)r[WFK_FCE_A + 2], A3 = (T)r[WFK_FCE_A + 3];
   const T B0 = (T)r[WFK_FCE_B], B1 = (T)r[WFK_FCE_B + 1], B2 = (T)r[WFK_FCE_B + 2], B3 = (T)r[WFK_FCE_B + 3];
+  // A(u) ck + B(u) sk with ck = c0 C - s0 S, sk = s0 C + c0 S  ==  C P(u) + S Q(u), P_i = A_i c0 + B_i s0,
+  // Q_i = B_i c0 - A_i s0: for the degree-1 variant (every op of the BASELINE chain) four products per op
+  // and thread replace four per sample.  (The cubic variant keeps the explicit rotation: folded, its
+  // eight coefficients pushed fir_sampled<double,12> to 20 spilled VGPRs, 10.70 -> 10.83 ms.)
+  const T P0 = DEG1 ? A0 * c0 + B0 * s0 : (T)0, P1 = DEG1 ? A1 * c0 + B1 * s0 : (T)0;
+  const T Q0 = DEG1 ? B0 * c0 - A0 * s0 : (T)0, Q1 = DEG1 ? B1 * c0 - A1 * s0 : (T)0;
   double g = sd.g, rr = sd.r;
   T u = (T)u0;
   const T Dt = (T)r[WFK_FCE_D];
@@ -200,12 +206,20 @@ __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, 
                                                           // was measured slower: 13.0 vs 11.9 ms, spills)
     CH_EACH(SB, kk)
       constexpr int k = kb * SB + kk;
-      const T pa = DEG1 ? A1 * u + A0 : ((A3 * u + A2) * u + A1) * u + A0;
-      const T pb = DEG1 ? B1 * u + B0 : ((B3 * u + B2) * u + B1) * u + B0;
-      u += Dt;
-      const T ck = c0 * (T)tb[kk].x - s0 * (T)tb[kk].y;
-      const T sk = s0 * (T)tb[kk].x + c0 * (T)tb[kk].y;
-      const T val = (pa * ck + pb * sk) * (T)g;
+      T val;
+      if constexpr (DEG1) {
+        // degree <= 1: the seed phasor is folded into the polynomials (C P(u) + S Q(u), see chain_loop's head)
+        const T pp = P1 * u + P0, qq = Q1 * u + Q0;
+        u += Dt;
+        val = (pp * (T)tb[kk].x + qq * (T)tb[kk].y) * (T)g;
+      } else {
+        const T pa = ((A3 * u + A2) * u + A1) * u + A0;
+        const T pb = ((B3 * u + B2) * u + B1) * u + B0;
+        u += Dt;
+        const T ck = c0 * (T)tb[kk].x - s0 * (T)tb[kk].y;
+        const T sk = s0 * (T)tb[kk].x + c0 * (T)tb[kk].y;
+        val = (pa * ck + pb * sk) * (T)g;
+      }
       if constexpr (k == KC) {
         nx.g = g;
         nx.r = rr;
