@@ -214,8 +214,8 @@ int wfk_chain_plan_destroy(wfk_chain_plan* plan);
  * sections back to back, orders[s] values each (total wfk_iir_state_dim()).
  * apply: out = F(in - initial) + initial; zi_dev/zf_dev: optional [batch][state_dim]
  * device arrays (initial state in, final state out; NULL = zeros / not wanted).
- * Execution form, chosen per plan: one or two biquads and cascades of up to four first-order
- * sections (state dimension <= 4) run as ONE kernel that reads x once (chained scan with decoupled
+ * Execution form, chosen per plan: equal-order cascades of state dimension <= 4 (one or two biquads, up to
+ * four first-order sections, one section of order 3 or 4) run as ONE kernel that reads x once (chained scan with decoupled
  * look-back); other shapes as a block scan in three launches; cascades of mixed orders or beyond
  * those sizes as consecutive passes.  A plan owns scratch state for its launches: use one plan per
  * concurrent stream.  In place (out_dev == in_dev) is allowed in every form.           */

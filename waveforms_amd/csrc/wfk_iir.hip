@@ -886,7 +886,8 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
   {
     // shapes: one or two biquads, or up to four FIRST-order sections -- the cascade of exponential
     // corrections a flux-line predistortion is usually made of (state dimension <= 4)
-    bool biq = n_sections >= 1 && (orders[0] == 1 || orders[0] == 2) && n_sections * orders[0] <= 4;
+    // (and single sections of order 3 or 4: a combined lfilter of three or four first-order filters)
+    bool biq = n_sections >= 1 && orders[0] >= 1 && n_sections * orders[0] <= 4;
     for (int s2 = 0; s2 < n_sections; ++s2) biq = biq && orders[s2] == orders[0];
     // The default for these shapes since its loads are issued in one batch and the look-back no
     // longer chains on the nearest prefix (tools/iir_sweep.py, fp64, 1 / 2 biquads, three-launch vs
@@ -1056,6 +1057,8 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
     do {                                                                                           \
       const int ns_ = p->c.nsec, or_ = p->c.ord[0];                                                \
       if (or_ == 2) { if (ns_ == 1) { OP_LAUNCH(TT, 1, 2); } else { OP_LAUNCH(TT, 2, 2); } }       \
+      else if (or_ == 3) { OP_LAUNCH(TT, 1, 3); }                                                  \
+      else if (or_ == 4) { OP_LAUNCH(TT, 1, 4); }                                                  \
       else if (ns_ == 1) { OP_LAUNCH(TT, 1, 1); }                                                  \
       else if (ns_ == 2) { OP_LAUNCH(TT, 2, 1); }                                                  \
       else if (ns_ == 3) { OP_LAUNCH(TT, 3, 1); }                                                  \
