@@ -367,3 +367,45 @@ def test_first_order_cascades(nsec, n, rows):
     assert np.max(np.abs(zf - zfw)) <= 1e-11 * max(1.0, np.abs(zfw).max())
     g32, _ = run(np.float32)
     assert np.max(np.abs(g32 - want)) <= 2e-5 * pk
+
+
+@pytest.mark.parametrize('rows,n,first', [(64, 200_003, False), (130, 150_001, True)])
+def test_single_pass_persistent_waves(rows, n, first):
+    """From 64 rows on the single pass runs as a bounded set of persistent waves per row walking the
+    ticket counter (more chunks per row than waves per row): sosfilt / lfilter per row, in place,
+    twice in a row (epochs), against the three-launch form."""
+    import os
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(rows)
+    if first:
+        secs = [(np.array([1.0 + 0.01 * k, -0.9 - 0.01 * k]), np.array([1.0, -0.95 + 0.02 * k])) for k in range(3)]
+    else:
+        secs = [(r[:3], r[3:]) for r in butter(4, 0.07, output='sos')]
+    x = rng.normal(size=(rows, n))
+    want = np.empty_like(x)
+    for r in range(rows):
+        y = x[r] - 0.1
+        for b, a in secs:
+            y = lfilter(b, a, y)
+        want[r] = y + 0.1
+
+    def run():
+        plan = _engine.IirPlan(secs, n, rows, np.float64)
+        dx = _engine.DeviceBuffer(rows * n * 8)
+        for _ in range(2):
+            dx.upload(x)
+            plan.apply(dx.ptr, n, dx.ptr, n, None, None, 0.1)     # in place
+            _engine.sync()
+        got = dx.download((rows, n), np.float64)
+        dx.close()
+        plan.close()
+        return got
+
+    got = run()
+    pk = max(1.0, np.abs(want).max())
+    assert np.max(np.abs(got - want)) <= 1e-11 * pk
+    os.environ['WFK_IIR_ONEPASS'] = '0'
+    try:
+        assert np.max(np.abs(run() - got)) <= 1e-12 * pk
+    finally:
+        os.environ.pop('WFK_IIR_ONEPASS', None)
