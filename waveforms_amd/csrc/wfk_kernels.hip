@@ -1063,7 +1063,7 @@ template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
 // (the build with direct primitives inlines all of device libm's shapes: left alone it takes 280 VGPRs = ONE
 // workgroup per CU, one wave per SIMD walking serial libm chains; capped at 256 it runs two: direct tier 1.8x.
 // The tlist builds (no fused code, 8 samples per lane) fit three at 168: 4.80 -> 3.45 ms on 64 x 2e6 times.)
-__global__ void __launch_bounds__(WFK_WG, TLIST ? 3 : (DIRECT ? 2 : 1)) wfk_sample(const KArgs a) {
+__global__ void __launch_bounds__(WFK_WG, TLIST ? 3 : ((DIRECT || (GENERIC && CPLX)) ? 2 : 1)) wfk_sample(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
   __shared__ double s_val[DIRECT ? NS * WFK_WG : 1];   // direct-factor values (apply_factor)
   constexpr int WT = 64 * NS;
