@@ -13,3 +13,5 @@ python tools/fir_bench.py 256 1e7 1024 f32 2>/dev/null
 python tools/stream_ceiling.py 2>/dev/null
 python tools/multitone_bench.py 10 2>/dev/null
 python tools/readout_bench.py 2>/dev/null
+python tools/direct_tier_bench.py 2>/dev/null
+python tools/tlist_bench.py 2>/dev/null
