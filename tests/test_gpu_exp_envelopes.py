@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GRID = ('linspace', 0.0, 120e-9, 400_001, False)
 
 
-def _check(chans, grid=GRID, cplx=False, tol64=1e-12, tol32=3e-5, fused=True):
+def _check(chans, grid=GRID, cplx=False, tol64=1e-12, tol32=3e-5, fused=True, exp_ab=True):
     prog = _flatten.flatten(chans)
     g = _flatten.grid_from_desc(grid)
     want = c_oracle.eval_grid(prog, g, True) if cplx else c_oracle.eval_grid(prog, g)
@@ -30,7 +30,7 @@ def _check(chans, grid=GRID, cplx=False, tol64=1e-12, tol32=3e-5, fused=True):
     os.environ['WFK_DISABLE_EXPFUSE'] = '1'          # A/B: the same program on the per-sample libm path
     try:
         ref = _engine.Plan(prog, grid=g)
-        assert ref.info.n_generic > 0
+        assert ref.info.n_generic > 0 or not exp_ab
         assert np.max(np.abs(ref.run_host(np.complex128 if cplx else np.float64) - want)) <= 1e-11 * pk
     finally:
         del os.environ['WFK_DISABLE_EXPFUSE']
@@ -93,3 +93,28 @@ def test_out_of_range_exponentials_stay_on_libm():
     fin = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), fin)
     assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))) <= 1e-11
+
+
+@pytest.mark.parametrize('d', [1, 2, 3])
+def test_gaussian_derivatives_fuse(d):
+    """gaussian(width, d=n) = (-1/s)^n H_n(u/s) exp(-(u/s)^2) (D_GAUSSIAN, reference _waveform.pyx:298-300):
+    a polynomial of degree n times the Gaussian envelope -- one fused op; alone, under a carrier,
+    times t, through mixing(); d = 4 stays on libm"""
+    W = 40e-9
+    g = wf.gaussian(W, d=d) >> 60e-9
+    scale = (W / 3.33) ** d                       # bring the derivative back to O(1)
+    I, Q = wf.mixing(scale * g, freq=120e6, phase=0.3, DRAGScaling=1e-10 if d < 3 else None)
+    chans = [scale * g, scale * g * wf.cos(2 * np.pi * 150e6, 0.5), I, Q]
+    if d < 3:
+        chans.append(scale * g * (wf.poly([0.0, 1e8]) >> 60e-9))
+    _check(chans, exp_ab=False)        # (no exponential factor here: the EXPFUSE switch changes nothing)
+
+
+def test_high_gaussian_derivative_stays_on_libm():
+    g = (40e-9 / 3.33) ** 4 * (wf.gaussian(40e-9, d=4) >> 60e-9)
+    prog = _flatten.flatten([g])
+    gr = _flatten.grid_from_desc(GRID)
+    plan = _engine.Plan(prog, grid=gr)
+    assert plan.info.n_generic > 0
+    want = c_oracle.eval_grid(prog, gr)
+    assert np.max(np.abs(plan.run_host(np.float64) - want)) <= 1e-11 * max(1.0, np.abs(want).max())

@@ -475,6 +475,18 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // marked `imag` (their op accumulates into the imaginary accumulators)
     const int32_t f0 = P->tm_factor_off[k], f1 = P->tm_factor_off[k + 1];
     int p = 0, ncos = 0;
+    // the term's polynomial factor in u = t' - slin: LINEAR powers shift it up, a Gaussian derivative
+    // (D_GAUSSIAN) multiplies it by its Hermite polynomial
+    long double tp[4] = {1.0L, 0.0L, 0.0L, 0.0L};
+    auto poly_times = [&](const long double (&c)[4]) -> bool {   // tp *= c(u), degree <= 3
+      long double out[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[i + j] += tp[i] * c[j];
+      for (int i = 4; i < 7; ++i)
+        if (out[i] != 0.0L) return false;
+      for (int i = 0; i < 4; ++i) tp[i] = out[i];
+      return true;
+    };
     bool has_lin = false, has_env = false, env32 = false;
     double slin = 0, sigma = 0, sg = 0;
     double first_cos_shift = 0;
@@ -513,6 +525,32 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           const double um = std::max(std::fabs(ua), std::fabs(ub));
           if (!(um > 0.0) || !rate_safe(pw / um, s0, s1)) return false;   // grid jitter vs |u|
           has_lin = true; slin = sh; p += (int)pw;
+          long double mono[4] = {0, 0, 0, 0};
+          mono[(int)pw] = 1.0L;
+          if (!poly_times(mono)) return false;
+          break;
+        }
+        case WFK_D_GAUSSIAN: {
+          // (-1/s)^n H_n(u/s) exp(-(u/s)^2), n <= 3: a polynomial times the Gaussian envelope
+          // (reference _waveform.pyx:298-300; what gaussian(width, d=n) and second derivatives make)
+          const double sgm = a[0];
+          const int n = (int)a[1];
+          if (pw != 1.0 || has_env || n < 0 || n > 3 || !std::isfinite(sgm) || sgm == 0.0) return false;
+          if (has_lin && sh != slin) return false;
+          bool ok64;
+          gauss_range(sgm, sh, tshift, s0, s1, ok64, env32);
+          if (!ok64 || !rate_safe(2.0 * (n + 1) / sgm, s0, s1)) return false;
+          has_env = true; sigma = sgm; sg = sh;
+          if (n > 0) {
+            const long double s2 = (long double)sgm * sgm;
+            long double h[4] = {0, 0, 0, 0};
+            if (n == 1) { h[1] = -2.0L / s2; }
+            else if (n == 2) { h[0] = -2.0L / s2; h[2] = 4.0L / (s2 * s2); }
+            else { h[1] = 12.0L / (s2 * s2); h[3] = -8.0L / (s2 * s2 * s2); }
+            if (!has_lin) { has_lin = true; slin = sh; }
+            p += n;
+            if (!poly_times(h)) return false;
+          }
           break;
         }
         case WFK_GAUSSIAN: {
@@ -706,10 +744,13 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         d = (long double)G->slin - slin;
       }
       static const int binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
-      for (int i = 0; i <= p; ++i) {
-        long double f = binom[p][i] * powl(d, p - i);
-        G->A[i] += ca * f;
-        G->B[i] += cb * f;
+      for (int m = 0; m <= p; ++m) {           // every monomial tp[m] (u_group + d)^m of the term's polynomial
+        if (tp[m] == 0.0L) continue;
+        for (int i = 0; i <= m; ++i) {
+          long double f = tp[m] * binom[m][i] * powl(d, m - i);
+          G->A[i] += ca * f;
+          G->B[i] += cb * f;
+        }
       }
       if (p > G->deg) G->deg = p;
       ++G->nterms;
