@@ -275,6 +275,38 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
     return Program(arrays, counts, any_complex)
 
 
+def tile_program(prog: Program, reps: int) -> Program:
+    """`prog` with its channel list repeated `reps` times (every copy owns its rows of every
+    table: the device tables of a big synthetic batch are as large as those of distinct channels)."""
+    if reps <= 1:
+        return prog
+    a, s = prog.arrays, prog.struct
+
+    def offs(name, total):
+        o = a[name]
+        body = o[1:].astype(np.int64)
+        return np.ascontiguousarray(np.concatenate(
+            [o[:1].astype(np.int64)] + [body + r * total for r in range(reps)]), dtype=o.dtype)
+
+    def rep(name, count):
+        return np.ascontiguousarray(np.tile(a[name][:count], reps)) if count else a[name]
+    arrays = dict(
+        ch_member_off=offs('ch_member_off', s.n_members), ch_offset=rep('ch_offset', s.n_channels),
+        ch_tshift=rep('ch_tshift', s.n_channels), ch_clip_lo=rep('ch_clip_lo', s.n_channels),
+        ch_clip_hi=rep('ch_clip_hi', s.n_channels), mb_piece_off=offs('mb_piece_off', s.n_pieces),
+        pc_bound=rep('pc_bound', s.n_pieces), pc_term_off=offs('pc_term_off', s.n_terms),
+        tm_amp_re=rep('tm_amp_re', s.n_terms), tm_amp_im=rep('tm_amp_im', s.n_terms),
+        tm_factor_off=offs('tm_factor_off', s.n_factors), fc_type=rep('fc_type', s.n_factors),
+        fc_power=rep('fc_power', s.n_factors), fc_shift=rep('fc_shift', s.n_factors),
+        fc_arg_off=offs('fc_arg_off', s.n_pool), pool=rep('pool', s.n_pool))
+    counts = dict(n_channels=s.n_channels * reps, n_members=s.n_members * reps,
+                  n_pieces=s.n_pieces * reps, n_terms=s.n_terms * reps,
+                  n_factors=s.n_factors * reps, n_pool=s.n_pool * reps)
+    if max(counts['n_pieces'], counts['n_terms'], counts['n_factors']) >= 2**31:
+        raise ValueError('tiled program exceeds the 32-bit table indices')
+    return Program(arrays, counts, prog.complex_amp)
+
+
 def grid_linspace(a, b, n, endpoint=True) -> wfk_grid:
     """np.linspace(a, b, n, endpoint): step = (b-a)/div; t[i] = fl(fl(i*step)+a),
     last element overridden by b when endpoint."""

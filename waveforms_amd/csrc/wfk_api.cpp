@@ -132,6 +132,8 @@ struct wfk_plan {
   int32_t* d_lean_chunk_first = nullptr;   // mixed plans: chunk table of the lean launch
   int32_t* d_f32_chunk_first = nullptr;    // lean launch with float output: its own (longer) chunks
   double* d_tlist = nullptr;
+  ShortUnit* d_units = nullptr;            // short plans (wfk_short.hip): wave units and lane slots
+  uint64_t* d_slots = nullptr;
   void* d_scratch = nullptr;   // wfk_plan_run_host output buffer
   size_t scratch_bytes = 0;
   size_t scratch_cap = 0;
@@ -150,15 +152,17 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   }
   const HostPlan& h = p->h;
   const size_t b_ch = h.channels.size() * sizeof(DevChannel);
-  const size_t b_pc = h.pieces.size() * sizeof(DevPiece);
+  const size_t b_pc = h.shortp ? 0 : h.pieces.size() * sizeof(DevPiece);   // (the short kernel walks units, not pieces)
   const size_t b_pa = h.params.size() * sizeof(double);
   const size_t b_po = h.pool.size() * sizeof(double);
   const size_t b_cf = h.chunk_first.size() * sizeof(int32_t);
   const size_t b_lf = h.lean_chunk_first.size() * sizeof(int32_t);
   const size_t b_ff = h.f32_chunk_first.size() * sizeof(int32_t);
+  const size_t b_un = h.s_units.size() * sizeof(ShortUnit), b_sl = h.s_slots.size() * sizeof(uint64_t);
   const size_t o_ch = 0, o_pc = align256(o_ch + b_ch), o_pa = align256(o_pc + b_pc),
                o_po = align256(o_pa + b_pa), o_cf = align256(o_po + b_po),
-               o_lf = align256(o_cf + b_cf), o_ff = align256(o_lf + b_lf), o_tl = align256(o_ff + b_ff);
+               o_lf = align256(o_cf + b_cf), o_ff = align256(o_lf + b_lf), o_un = align256(o_ff + b_ff),
+               o_sl = align256(o_un + b_un), o_tl = align256(o_sl + b_sl);
   const size_t b_tl = tlist ? (size_t)h.n * sizeof(double) : 0;
   const size_t total = align256(o_tl + b_tl) + 256;
   HIP_TRY(dev_cache().get(total, &p->d_tables, &p->tables_cap, &p->dev));
@@ -170,6 +174,8 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   p->d_chunk_first = reinterpret_cast<int32_t*>(base + o_cf);
   p->d_lean_chunk_first = reinterpret_cast<int32_t*>(base + o_lf);
   p->d_f32_chunk_first = reinterpret_cast<int32_t*>(base + o_ff);
+  p->d_units = reinterpret_cast<ShortUnit*>(base + o_un);
+  p->d_slots = reinterpret_cast<uint64_t*>(base + o_sl);
   p->d_tlist = tlist ? reinterpret_cast<double*>(base + o_tl) : nullptr;
   // the small tables travel in ONE copy; the time axis (as large as the output) on its own
   std::vector<char> stage(o_tl);
@@ -180,6 +186,8 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   if (b_cf) std::memcpy(stage.data() + o_cf, h.chunk_first.data(), b_cf);
   if (b_lf) std::memcpy(stage.data() + o_lf, h.lean_chunk_first.data(), b_lf);
   if (b_ff) std::memcpy(stage.data() + o_ff, h.f32_chunk_first.data(), b_ff);
+  if (b_un) std::memcpy(stage.data() + o_un, h.s_units.data(), b_un);
+  if (b_sl) std::memcpy(stage.data() + o_sl, h.s_slots.data(), b_sl);
   if (o_tl) HIP_TRY(hipMemcpy(base, stage.data(), o_tl, hipMemcpyHostToDevice));
   if (b_tl) HIP_TRY(hipMemcpy(base + o_tl, tlist, b_tl, hipMemcpyHostToDevice));
   p->on_device = true;
@@ -264,7 +272,7 @@ int wfk_plan_get_info(const wfk_plan* p, wfk_plan_info* info) {
   info->n_channels = p->h.n_channels;
   info->n = p->h.n;
   info->tile = p->h.tile;
-  info->n_tiles = p->h.chunks_per_ch * p->h.n_channels;
+  info->n_tiles = p->h.shortp ? (int64_t)p->h.s_units.size() : p->h.chunks_per_ch * p->h.n_channels;
   info->n_pieces = (int32_t)p->h.pieces.size();
   info->param_doubles = (int64_t)p->h.params.size();
   info->n_fast = p->h.n_fast;
@@ -293,6 +301,10 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   const char* T = (out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64) ? "float" : "double";
   const char* cplx = (out_kind == WFK_OUT_C128 || out_kind == WFK_OUT_C64) ? "true" : "false";
   const HostPlan& h = p->h;
+  if (h.shortp) {
+    name = std::string("wfk_sample_short<") + T + "," + cplx + "," + std::to_string(WFK_SH_R) + ">";
+    return name.c_str();
+  }
   const std::string lean_name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +
       (h.n_corr > 0 && out_kind != WFK_OUT_F32 && out_kind != WFK_OUT_C64 ? ",true>" : ",false>");
   if (!h.tlist && h.lean) {
@@ -314,6 +326,25 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
     return fail(WFK_EHIP, "plan has no device tables (no HIP device was visible at plan creation)");
   if (ch_stride < p->h.n) return fail(WFK_EINVAL, "ch_stride smaller than samples per channel");
   if (p->h.n == 0 || p->h.n_channels == 0) return WFK_OK;
+  if (p->h.shortp) {
+    SArgs sa{};
+    sa.channels = p->d_channels;
+    sa.units = p->d_units;
+    sa.slots = p->d_slots;
+    sa.recs = p->d_params;
+    sa.out = out_dev;
+    sa.ch_stride = ch_stride;
+    sa.n_units = (int64_t)p->h.s_units.size();
+    sa.units_per_chunk = p->h.s_units_per_chunk;
+    sa.n_chunks = (sa.n_units + sa.units_per_chunk - 1) / sa.units_per_chunk;
+    sa.accumulate = (flags & WFK_ACCUMULATE) ? 1 : 0;
+    sa.lds_samples = p->h.s_lds_samples;
+    sa.step = p->h.step;
+    if (hip_stream) p->async_launch = true;
+    std::string serr;
+    const int src = wfk_launch_short(sa, out_kind, hip_stream, serr);
+    return src ? fail(src, serr) : WFK_OK;
+  }
   KArgs a{};
   a.channels = p->d_channels;
   a.pieces = p->d_pieces;

@@ -117,9 +117,12 @@ struct BlockBuilder {
 
 }  // namespace
 
+// want_short: -1 = decide from the mean live piece length (grid plans), 0 = never.  Returns
+// WFK_RETRY_STD when the short geometry was chosen but some piece cannot run in it.
+#define WFK_RETRY_STD 1
 static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
                         int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr,
-                        int lane_stride = 64, int ns_override = 0);
+                        int lane_stride = 64, int ns_override = 0, int want_short = 0);
 
 // Grid plan for another evaluation geometry: lanes `lane_stride` samples apart, `ns` samples per
 // lane (the sampler fused into the FIR transform walks a window with stride 256, wfk_fir_sampled.hip).
@@ -135,14 +138,18 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   // Carriers whose phase is sensitive to NumPy's grid rounding (far from t = 0) stay fused with a
   // first-order per-sample correction, which only the lean kernel implements.  A plan that turns
   // out not to be lean is compiled again with such carriers on the exact (libm) path.
-  int rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
-  if (rc == WFK_OK && H.n_corr > 0 && !H.lean && !H.mixed) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
+  // Plans whose live pieces are short (AWG sample rates: tens to hundreds of samples per pulse) are
+  // compiled for the contiguous-lane geometry of wfk_short.hip first; a piece that tier cannot take
+  // (generic terms, erf edges, corrected carriers) sends the whole plan back to the standard tiers.
+  int rc = compile_impl(P, grid, tlist, n_tlist, H, err, true, 64, 0, -1);
+  if (rc == WFK_RETRY_STD) rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
+  if (rc == WFK_OK && !H.shortp && H.n_corr > 0 && !H.lean && !H.mixed) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
   return rc;
 }
 
 static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
                         int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr,
-                        int lane_stride, int ns_override) {
+                        int lane_stride, int ns_override, int want_short) {
   if (!P || (!grid && !tlist && n_tlist != 0)) { err = "null program or time axis"; return WFK_EINVAL; }
   if (P->n_channels < 0 || P->n_members < 0) { err = "negative counts"; return WFK_EINVAL; }
   TimeAxis ax{grid, tlist, grid ? grid->n : n_tlist};
@@ -158,8 +165,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.ns = H.tlist ? (ax.n < WFK_TLIST_SMALL_N ? WFK_NS_TLIST_SMALL : WFK_NS_TLIST) : WFK_NS_GRID;
   if (ns_override > 0 && !H.tlist) H.ns = ns_override;
   H.tile = WFK_WG * H.ns;
-  const int NS = H.ns;
-  const double dstride = grid ? (double)lane_stride * grid->step : 0.0;  // time between a lane's samples
+  int NS = H.ns;
+  double dstride = grid ? (double)lane_stride * grid->step : 0.0;  // time between a lane's samples
+  bool shortm = false;          // contiguous-lane geometry of the short tier (decided after the piece search)
   const int lean_par_cap = ns_override > 0 ? WFK_CHAIN_PAR : WFK_LEAN_PAR;
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
@@ -238,6 +246,31 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         idx.push_back(ax.search_left(P->ch_tshift[c], P->pc_bound[p]));
     }
 
+  // ---- geometry: short tier? ---------------------------------------------------------------------
+  // Mean length of the live member pieces (samples).  Below WFK_SH_MAXLEN the plan is compiled for
+  // the contiguous-lane geometry: lane stride = one sample, WFK_SH_R samples per lane.
+  if (want_short != 0 && grid && !H.tlist && !nofast && ns_override == 0 && ax.n > 0) {
+    const char* e = std::getenv("WFK_SHORT");          // 0: never, 1: whatever the piece length
+    const int mode = e ? std::atoi(e) : -1;
+    int64_t live = 0, live_samples = 0;
+    for (int32_t m = 0; m < P->n_members; ++m) {
+      const auto& idx = H.member_idx[m];
+      int64_t prev = 0;
+      for (size_t k = 0; k < idx.size(); ++k) {
+        const int32_t p = P->mb_piece_off[m] + (int32_t)k;
+        if (idx[k] > prev && P->pc_term_off[p + 1] > P->pc_term_off[p]) { ++live; live_samples += idx[k] - prev; }
+        prev = std::max(prev, idx[k]);
+      }
+    }
+    int64_t maxlen = 1536;                              // tools/short_crossover.py
+    if (const char* m = std::getenv("WFK_SHORT_MAXLEN")) maxlen = std::atoll(m);
+    if (mode != 0 && live > 0 && (mode == 1 || live_samples < maxlen * live)) {
+      shortm = true;
+      NS = WFK_SH_R;
+      dstride = grid->step;
+    }
+  }
+
   // phasor table (C[k], S[k]) = (cos, sin)(k * dphase), k < NS, shared per block
   auto table_for = [&](BlockBuilder& B, double dphase) -> int {
     auto it = B.table_of_w.find(dphase);
@@ -298,7 +331,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // after the correction is d^2 / 2.  (fl(x - s_m) is not exact when the carrier is referenced to
   // t = 0, as mixing()'s is: what the subtraction rounds away is recovered with a TwoSum.)
   const char* nocorr_env = std::getenv("WFK_DISABLE_CORR");
-  const bool corr_enabled = allow_corr && !(nocorr_env && nocorr_env[0] == '1');
+  const bool corr_enabled = allow_corr && !shortm && !(nocorr_env && nocorr_env[0] == '1');
   bool piece_corr_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
   auto corr_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {
     const double x = std::fabs(rate) * grid_jitter(s0, s1);
@@ -466,7 +499,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const char* noexp_env = std::getenv("WFK_DISABLE_EXPFUSE");
   const bool expfuse = !(noexp_env && noexp_env[0] == '1');
   const char* noerf_env = std::getenv("WFK_DISABLE_ERFMUL");
-  const bool erfmod = can_fuse && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
+  const bool erfmod = can_fuse && ns_override == 0 && !shortm && !(noerf_env && noerf_env[0] == '1');
 
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
                        int64_t s1, int32_t skip = -1) -> bool {   // skip: a factor handled by the caller
@@ -842,6 +875,62 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (G.W != 0.0) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
   };
 
+  // ---- short tier: compact op records (WFK_SH_*), referenced to the first sample of each stretch ----
+  // The group stands for  E(t') (A(u) cos th + B(u) sin th),  th = W t' - psi_ref,  u = t' - s_lin.
+  // Everything a lane needs to seed the op `koff` samples after the reference sample x_ref:
+  //   th/pi = th0p + koff dthp,  u = u0 + koff dt,  Gaussian v = v0 + koff H  (exp: alpha t'' = v0 + koff H)
+  auto emit_short_piece = [&](const std::vector<FceGroup>& groups, double tshift, int64_t s0, int64_t s1,
+                              int32_t& n_rec) -> int32_t {
+    const long double PIl = 3.141592653589793238462643383279502884L;
+    int32_t rec_len = 0;
+    for (const FceGroup& G : groups) rec_len += G.deg > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
+    n_rec = 0;
+    for (int64_t r0 = s0; r0 < s1; r0 += WFK_SH_SUB, ++n_rec) {
+      double x = ax.at(r0);
+      if (tshift != 0.0) x = x - tshift;                 // fl(x - shift), as the reference forms it
+      const long double x0 = x;
+      const size_t at = H.params.size();
+      H.params.resize(at + (size_t)rec_len, 0.0);
+      double* rec = H.params.data() + at;
+      double* o = rec;
+      for (const FceGroup& G : groups) {
+        const int env = G.has_exp ? 2 : (G.has_env ? 1 : 0);
+        const uint64_t word = (uint64_t)(uint32_t)((G.deg & 3) | ((G.W != 0.0 ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (env << 4) |
+                                                   (&G == &groups.back() ? WFK_SH_LAST : 0));
+        std::memcpy(&o[0], &word, sizeof word);
+        if (G.W != 0.0) {
+          const long double th0 = (long double)G.W * x0 - G.psi_ref;
+          o[1] = (double)remainderl(th0 / PIl, 2.0L);
+          const long double dth = (long double)G.W * (long double)grid->step;
+          o[2] = (double)(dth / PIl);
+          o[3] = (double)cosl(dth);
+          o[4] = (double)sinl(dth);
+        } else {
+          o[1] = 0.0; o[2] = 0.0; o[3] = 1.0; o[4] = 0.0;
+        }
+        o[5] = (double)(x0 - (long double)(G.has_lin ? G.slin : 0.0));
+        o[8] = 1.0;
+        if (env == 1) {
+          const long double Hh = (long double)grid->step / G.sigma;
+          o[6] = (double)((x0 - (long double)G.sg) / G.sigma);
+          o[7] = (double)Hh;
+          o[8] = (double)expl(-2.0L * Hh * Hh);
+        } else if (env == 2) {
+          o[6] = (double)((long double)G.sigma * (x0 - (long double)G.sg));
+          o[7] = (double)((long double)G.sigma * (long double)grid->step);
+        }
+        o[9] = (double)G.A[0]; o[10] = (double)G.A[1]; o[11] = (double)G.B[0]; o[12] = (double)G.B[1];
+        if (G.deg > 1) {
+          o[14] = (double)G.A[2]; o[15] = (double)G.A[3]; o[16] = (double)G.B[2]; o[17] = (double)G.B[3];
+          o += WFK_SH_OP3;
+        } else {
+          o += WFK_SH_OP1;
+        }
+      }
+    }
+    return rec_len;
+  };
+
   // ---- merge members into disjoint device pieces -----------------------------
   bool lean_ok = can_fuse;
   int64_t n_lean_pieces = 0;
@@ -1014,7 +1103,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // pulse), the envelope is factored out: the ops run without envelope and one closing
         // pseudo-op multiplies the accumulators by it -- 2 instead of 5 FMAs per sample and tone.
         // (From four carriers on: the extra op costs a pair of pieces what it saves them.)
-        if (groups.size() >= 4 && !mod_on) {
+        if (groups.size() >= 4 && !mod_on && !shortm) {
           bool shared = true, e32 = true;
           for (const FceGroup& g : groups) {
             shared = shared && g.has_env && !g.has_exp && g.sigma == groups[0].sigma && g.sg == groups[0].sg;
@@ -1026,6 +1115,16 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             for (FceGroup& g : groups) g.has_env = false;
             groups.push_back(E);
           }
+        }
+        if (shortm) {
+          // compact records of the short tier (WFK_SH_*): one per <= WFK_SH_SUB samples of the piece
+          if (!generic.empty() || groups.empty() || groups.size() > 255) return WFK_RETRY_STD;
+          for (const FceGroup& G : groups)
+            if (G.corr || G.erfmul || G.envmul) return WFK_RETRY_STD;
+          const int32_t first = emit_short_piece(groups, C.tshift, s0, s1, D.n_blk);
+          D.first_len = first;
+          D.flags |= WFK_PF_SHORT;
+          break;
         }
         piece_lean = generic.empty() && !groups.empty() && groups.size() <= WFK_LEAN_OPS;
         const int32_t piece_ops = (int32_t)groups.size();
@@ -1087,6 +1186,80 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       }
     }
     C.piece_end = (int32_t)H.pieces.size();
+  }
+
+  // ---- short tier: wave units and lane slots ------------------------------------
+  if (shortm) {
+    H.shortp = true;
+    H.tile = 64 * WFK_SH_R;
+    for (int32_t c = 0; c < P->n_channels; ++c) {
+      ShortUnit U{};
+      auto fresh = [&](int64_t j0) {
+        U = ShortUnit{};
+        U.ch = c; U.j0 = j0; U.slot0 = (int32_t)H.s_slots.size();
+        U.offset = H.channels[c].offset; U.clip_lo = H.channels[c].clip_lo; U.clip_hi = H.channels[c].clip_hi;
+        U.do_clip = H.channels[c].do_clip;
+      };
+      fresh(0);
+      auto close = [&](int64_t next_j0) {
+        if (U.n_samples > 0) {
+          if (U.n_slots > 0) H.s_lds_samples = std::max(H.s_lds_samples, U.n_samples);
+          H.s_units.push_back(U);
+        }
+        fresh(next_j0);
+      };
+      for (int32_t pi = H.channels[c].piece_begin; pi < H.channels[c].piece_end; ++pi) {
+        const DevPiece& D = H.pieces[pi];
+        if (D.n_blk == 0) {
+          // zero stretch: rides in the current unit's range while it fits, long ones as pure-fill units
+          int64_t z0 = D.start, left = D.stop - D.start;
+          if (U.n_slots > 0) {
+            const int64_t take = std::min<int64_t>(left, WFK_SH_LCAP - U.n_samples);
+            U.n_samples += (int32_t)take; U.gaps = 1;
+            z0 += take; left -= take;
+            if (left > 0) close(z0);
+          }
+          while (left >= WFK_SH_LCAP / 2) {
+            const int64_t take = std::min<int64_t>(left, WFK_SH_FILL);
+            if (U.n_samples > 0) close(z0);
+            U.n_samples = (int32_t)take;
+            z0 += take; left -= take;
+            close(z0);
+          }
+          if (left > 0) { U.n_samples += (int32_t)left; U.gaps = 1; }
+          continue;
+        }
+        int32_t rec = 0;
+        for (int64_t r0 = D.start; r0 < D.stop; r0 += WFK_SH_SUB, ++rec) {
+          const int64_t len = std::min<int64_t>(WFK_SH_SUB, D.stop - r0);
+          const int64_t nseg = (len + WFK_SH_R - 1) / WFK_SH_R, base = len / nseg, rem = len % nseg;
+          const uint64_t rec16 = (uint64_t)(D.par_off + (int64_t)rec * D.first_len) / 2;
+          if (rec16 > 0xffffffffULL) { err = "short tier: record table too large"; return WFK_EINVAL; }
+          int64_t k0 = 0;
+          for (int64_t sgi = 0; sgi < nseg; ++sgi) {
+            const int64_t sl = base + (sgi < rem ? 1 : 0);
+            if (U.n_slots == 64 || U.n_samples + sl > WFK_SH_LCAP) close(r0 + k0);
+            H.s_slots.push_back(WFK_SH_SLOT(rec16, U.n_samples, sl, k0));
+            ++U.n_slots;
+            U.n_samples += (int32_t)sl;
+            k0 += sl;
+          }
+        }
+      }
+      close(ax.n);
+    }
+    if (H.s_slots.empty()) H.s_slots.push_back(0);
+    // workgroup = one wave walking `units_per_chunk` consecutive units
+    const int64_t nu = (int64_t)H.s_units.size();
+    H.s_units_per_chunk = (int32_t)std::min<int64_t>(8, std::max<int64_t>(1, nu / 8192));
+    if (const char* e = std::getenv("WFK_SH_UPC")) {   // tuning override
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 64) H.s_units_per_chunk = v;
+    }
+    H.chunks_per_ch = 0;
+    if (H.pool.empty()) H.pool.push_back(0.0);
+    H.params.resize(H.params.size() + 8, 0.0);   // (the kernel may read one op record past the last real one)
+    return WFK_OK;
   }
 
   // ---- workgroup chunking ------------------------------------------------------

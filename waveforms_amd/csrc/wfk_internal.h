@@ -114,6 +114,53 @@
 #define WFK_PF_HAS_TERMS 1    // piece is "evaluated": clip applies (pyx:161-163)
 #define WFK_PF_LEAN 2         // piece is one block of <= WFK_LEAN_OPS fused ops (lean kernel can take it)
 
+// ---- "short" plans: pieces of tens to hundreds of samples (AWG sample rates) ------------------
+// The reference's users sample at 1-5 GS/s (Waveform.sample, waveforms/waveform.py:173-207): a
+// 20 ns pulse is 20-100 samples, far below the lean kernel's wave tile of 1024 in which a lane
+// strides 64 samples.  The short tier turns the geometry round (wfk_short.hip):
+//   * a LANE owns one SEGMENT: <= WFK_SH_R CONSECUTIVE samples of ONE piece, so the Gaussian /
+//     phasor recurrences step by dt (H = dt / sigma is always admissible) and the one exact seed
+//     per (lane, op) is amortised over the lane's run;
+//   * a wave owns one UNIT: <= 64 segments (+ the zero gaps between them) covering a contiguous
+//     sample range of <= WFK_SH_LCAP samples; results are transposed through LDS so that the wave
+//     still writes whole 128-B lines;
+//   * pieces carry COMPACT op records (16 or 20 doubles per op instead of 22 + a 34-double
+//     phasor table): at 60 samples per piece the tables are no longer negligible traffic.
+// Host tables: ShortUnit[] (one per wave unit), uint64 slots[] (one per segment), records in
+// `params`.  Record of a piece (or of each <= WFK_SH_SUB-sample stretch of a long piece): its ops
+// back to back, 16-B aligned, WFK_SH_OP1 doubles each (WFK_SH_OP3 when deg > 1):
+//     [0] word (int, low half): deg | carrier << 2 | imag << 3 | env << 4 (0 none, 1 Gaussian, 2 exp) |
+//         last op of the record << 6
+//     [1] th0/pi at the record's reference sample, reduced to [-1, 1]    [2] W dt / pi
+//     [3] cos(W dt)  [4] sin(W dt)   [5] u0 = x_ref - s_lin
+//     [6] Gaussian: v0 = (x_ref - s_g) / sigma; exp: alpha (x_ref - ref)
+//     [7] Gaussian: H = dt / sigma; exp: alpha dt        [8] q = exp(-2 H^2) (exp / none: 1)
+//     [9] A0 [10] A1 [11] B0 [12] B1 [13] -   ([14] A2 [15] A3 [16] B2 [17] B3)
+#define WFK_SH_R 16           // samples per lane segment
+#define WFK_SH_LCAP 2048      // samples a unit may span (LDS staging: 8 B each + 1/16 padding)
+#define WFK_SH_SUB 4096       // samples per record of a long piece (slot.koff has 12 bits)
+#define WFK_SH_FILL 8192      // samples per pure-fill unit (long zero stretches: no slots, no LDS)
+#define WFK_SH_OP1 14
+#define WFK_SH_OP3 18
+#define WFK_SH_LAST 64        // op word: last op of its record
+#define WFK_PF_SHORT 4        // piece carries compact records (par_off, n_blk = #records, first_len = doubles each)
+// slot word: record offset in 16-B units (32 bits) | sample offset in the unit << 32 (12 bits) |
+//            segment length << 44 (6 bits) | offset from the record's reference sample << 50 (12 bits)
+#define WFK_SH_SLOT(rec16, o, len, koff) \
+  ((uint64_t)(uint32_t)(rec16) | ((uint64_t)(o) << 32) | ((uint64_t)(len) << 44) | ((uint64_t)(koff) << 50))
+
+struct ShortUnit {            // 64 B: everything a wave needs about its unit in one scalar load
+  int64_t j0;                 // first sample of the unit in its channel
+  int32_t ch;
+  int32_t n_samples;          // samples covered (mixed units: <= WFK_SH_LCAP)
+  int32_t slot0;              // first slot
+  int32_t n_slots;            // 0: pure fill (`offset` everywhere)
+  int32_t gaps;               // the slots do not cover the range: LDS is pre-filled with `offset`
+  int32_t do_clip;            // channel constants, copied here: no dependent second load
+  double offset, clip_lo, clip_hi;
+  double pad;
+};
+
 struct DevPiece {
   int64_t start, stop;        // sample range [start, stop)
   int64_t par_off;            // first parameter block (doubles into params[])
@@ -127,6 +174,22 @@ struct DevChannel {
   double offset, tshift, clip_lo, clip_hi;
   int32_t piece_begin, piece_end;
   int32_t do_clip, pad;
+};
+
+struct SArgs {                // short-tier launch (wfk_short.hip)
+  const DevChannel* channels;
+  const ShortUnit* units;
+  const uint64_t* slots;
+  const double* recs;         // == the plan's `params`
+  void* out;
+  int64_t ch_stride;          // elements
+  int64_t n_units;
+  int64_t n_chunks;           // workgroups with work; the grid is rounded up to a multiple of 8
+  int32_t units_per_chunk;
+  int32_t accumulate;
+  int32_t lds_samples;        // largest n_samples of a unit with slots
+  int32_t pad;
+  double step;
 };
 
 struct KArgs {
@@ -186,6 +249,11 @@ struct HostPlan {
   int64_t f32_chunks_per_ch = 0;
   std::vector<int32_t> f32_chunk_first;
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most state units (128 doubles) of a piece
+  // short tier (WFK_SH_*): `params` then holds the compact records
+  bool shortp = false;
+  std::vector<ShortUnit> s_units;
+  std::vector<uint64_t> s_slots;
+  int32_t s_lds_samples = 0, s_units_per_chunk = 1;
 };
 
 // host compiler: flattened program + time axis -> device tables.  Returns 0 or a
@@ -200,4 +268,5 @@ int wfk_compile_geom(const wfk_program* prog, const wfk_grid* grid, int lane_str
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns,
                        bool lean, bool generic, bool direct, void* stream, std::string& err);
 // (a.corr selects the lean kernel variant with the per-sample grid-rounding correction)
+int wfk_launch_short(const SArgs& a, int out_kind, void* stream, std::string& err);
 #endif

@@ -1,0 +1,390 @@
+// wfk_short.hip -- gfx950 sampler for SHORT pieces: the regime Waveform.sample() is used in.
+//
+// Reference path: calc_parts / _calc / _fill_parts (waveforms/_waveform.pyx:134-169,
+// waveforms/waveform.py:524-527) on the grid of Waveform.sample (waveform.py:190:
+// np.arange(start, stop, 1 / sample_rate)) at AWG rates: 1-5 GS/s, pulses of 20-40 ns, i.e.
+// pieces of 20-200 samples.  The lean kernel (wfk_kernels.hip) strides a lane by 64 samples and
+// carries op state from tile to tile; with pieces shorter than its 1024-sample wave tile every
+// piece entry costs a libm seed per lane for 1-5 samples of use, and the Gaussian recurrence at
+// stride 64 dt is not even admissible (64 dt / sigma > 2).
+//
+// Geometry here (see WFK_SH_* in wfk_internal.h; the host builds the tables, wfk_compile.cpp):
+//   lane  -> one SEGMENT = <= R CONSECUTIVE samples of ONE piece.  The recurrences step by dt
+//            (H = dt / sigma ~ 0.08: always admissible); one exact seed per (lane, op) -- short
+//            straight-line sin/cos(pi r) and exp kernels, no libm call -- serves the whole run.
+//            Lanes of a wave sit in DIFFERENT pieces: every op parameter is per lane, read from
+//            the piece's compact record (16 doubles for a Gaussian + DRAG pulse).
+//   wave  -> one UNIT = <= 64 segments plus the zero stretches between them, a contiguous range
+//            of <= WFK_SH_LCAP samples of one channel.  Results go through LDS (lane l writes its
+//            run at its offset, stride-17 swizzle => no bank conflicts), then the wave stores the
+//            range row by row: 64 consecutive samples per store instruction, rows aligned to
+//            128-B lines.  Long zero stretches are pure-fill units (no slots, no LDS).
+//   workgroup = one wave, walking `units_per_chunk` consecutive units; chunks are dealt to the
+//            XCDs in contiguous eighths (same map as the lean kernel).
+// All arithmetic is fp64 whatever the output type (the fp32 VALU rate of this part is the fp64
+// rate unless packed); T only sets the width of the LDS staging and of the stores.
+// Bound: HBM writes (8 / 4 / 16 B per sample) + the record and slot tables
+// ((128 B + 8 B x segments) per piece: +30 % at 60 samples per piece).  No contraction => no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <type_traits>
+#include <utility>
+
+#include "wfk.h"
+#include "wfk_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+#define WFK_CONST __attribute__((address_space(4)))
+template <typename V>
+__device__ __forceinline__ V cload(const void* base, int64_t byte_off) {
+  return *reinterpret_cast<const WFK_CONST V*>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+template <typename P>
+__device__ __forceinline__ P* uniptr(P* p) {
+  using G = __attribute__((address_space(1))) P*;
+  return (P*)reinterpret_cast<G>(uni64(reinterpret_cast<int64_t>(p)));
+}
+
+template <int... K, typename F>
+__device__ __forceinline__ void sh_for_impl(std::integer_sequence<int, K...>, F&& f) {
+  (f(std::integral_constant<int, K>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void sh_for(F&& f) {
+  sh_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+#define SH_EACH(N, k) sh_for<N>([&](auto k##_) __attribute__((always_inline)) { constexpr int k = decltype(k##_)::value;
+#define SH_END });
+
+// polynomial coefficient pinned to an SGPR pair at its use (see wfk_fir_sampled.hip: left alone the
+// compiler hoists all of them into VGPRs that stay live across the sample loops)
+__device__ __forceinline__ double kc(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// sin(pi r), cos(pi r) for |r| <= 1/2: fold to z in [0, 1/4], Taylor in t = pi z (truncation < 5e-18)
+__device__ __forceinline__ void sincospi_small(double r, double* sn, double* cs) {
+  const double a = fabs(r);
+  const bool swap = a > 0.25;
+  const double z = swap ? 0.5 - a : a;                    // exact
+  const double t = z * 3.141592653589793116 + z * 1.2246467991473532e-16;
+  const double t2 = t * t;
+  double ps = kc(-2.8114572543455206e-15);                    // -1/17!
+  ps = fma(ps, t2, kc(7.6471637318198164e-13));
+  ps = fma(ps, t2, kc(-1.6059043836821613e-10));
+  ps = fma(ps, t2, kc(2.5052108385441720e-08));
+  ps = fma(ps, t2, kc(-2.7557319223985893e-06));
+  ps = fma(ps, t2, kc(1.9841269841269841e-04));
+  ps = fma(ps, t2, kc(-8.3333333333333332e-03));
+  ps = fma(ps, t2, kc(1.6666666666666666e-01));
+  const double s = fma(-t * t2, ps, t);
+  double pc = kc(1.5619206968586226e-16);                     //  1/18!
+  pc = fma(pc, t2, kc(-4.7794773323873853e-14));
+  pc = fma(pc, t2, kc(1.1470745597729725e-11));
+  pc = fma(pc, t2, kc(-2.0876756987868099e-09));
+  pc = fma(pc, t2, kc(2.7557319223985888e-07));
+  pc = fma(pc, t2, kc(-2.4801587301587302e-05));
+  pc = fma(pc, t2, kc(1.3888888888888889e-03));
+  pc = fma(pc, t2, kc(-4.1666666666666664e-02));
+  pc = fma(pc, t2, kc(0.5));
+  const double c = fma(-t2, pc, 1.0);
+  const double ss = swap ? c : s, cc = swap ? s : c;
+  *sn = r < 0.0 ? -ss : ss;
+  *cs = cc;
+}
+
+// exp(x), |x| < 700: Cody-Waite reduction, Taylor to r^14 on |r| <= ln2 / 2, ldexp
+__device__ __forceinline__ double exp_small(double x) {
+#pragma clang fp contract(off)   // the reduction's fma()s are explicit
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = kc(1.1470745597729725e-11);                      // 1/14!
+  p = fma(p, r, kc(1.6059043836821613e-10));
+  p = fma(p, r, kc(2.0876756987868099e-09));
+  p = fma(p, r, kc(2.5052108385441720e-08));
+  p = fma(p, r, kc(2.7557319223985888e-07));
+  p = fma(p, r, kc(2.7557319223985893e-06));
+  p = fma(p, r, kc(2.4801587301587302e-05));
+  p = fma(p, r, kc(1.9841269841269841e-04));
+  p = fma(p, r, kc(1.3888888888888889e-03));
+  p = fma(p, r, kc(8.3333333333333332e-03));
+  p = fma(p, r, kc(4.1666666666666664e-02));
+  p = fma(p, r, kc(1.6666666666666666e-01));
+  p = fma(p, r, kc(0.5));
+  p = fma(p, r, kc(1.0));
+  p = fma(p, r, kc(1.0));
+  return ldexp(p, (int)n);
+}
+
+template <typename T> struct ShOut;
+template <> struct ShOut<double> { using Cplx = double2; };
+template <> struct ShOut<float> { using Cplx = float2; };
+
+__device__ __forceinline__ int swz(int i) { return i + (i >> 4); }   // lane stride 16 -> 17 elements
+
+__device__ __forceinline__ double clip_np(double v, double lo, double hi) {
+  v = v < lo ? lo : v;       // np.clip: NaN propagates
+  v = v > hi ? hi : v;
+  return v;
+}
+
+// one op record in registers (the first op of the NEXT unit is fetched while this unit stores)
+struct OpRec {
+  double2 a, b, c, d, e, f, g;    // doubles 0..13 of the record
+};
+__device__ __forceinline__ OpRec load_op(const double* p) {
+  const double2* q = reinterpret_cast<const double2*>(p);
+  OpRec r;
+  r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4]; r.f = q[5]; r.g = q[6];
+  return r;
+}
+__device__ __forceinline__ int op_word(const OpRec& r) { return (int)__double2loint(r.a.x); }
+
+// one fused op over the lane's run: acc[k] += E_k (A(u_k) c_k + B(u_k) s_k), all state per lane
+template <int R, bool CUBIC, bool CPLX>
+__device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w, double kf, double step,
+                                         double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+  const int env = (w >> 4) & 3;
+  const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.y, q = o.e.x;
+  const double A0 = o.e.y, A1 = o.f.x, B0 = o.f.y, B1 = o.g.x;
+  double A2 = 0.0, A3 = 0.0, B2 = 0.0, B3 = 0.0;
+  if constexpr (CUBIC) {
+    if ((w & 3) > 1) { A2 = op[14]; A3 = op[15]; B2 = op[16]; B3 = op[17]; }
+  }
+  // exact seeds at the lane's first sample, `kf` samples after the record's reference sample
+  double c, s;
+  {
+    const double x = fma(kf, o.b.x, o.a.y);       // phase / pi
+    const double n = rint(x);
+    sincospi_small(x - n, &s, &c);
+    if (((int)n) & 1) { c = -c; s = -s; }
+  }
+  const double vv = fma(kf, Hh, o.d.x);
+  const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
+  const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
+  double g = exp_small(ea), r = exp_small(eb);
+  double u = fma(kf, step, o.c.y);
+  double mr = 1.0, mi = 0.0;
+  if constexpr (CPLX) {
+    if (w & 8) { mr = 0.0; mi = 1.0; }
+  }
+  SH_EACH(R, k)
+    double pa, pb;
+    if constexpr (CUBIC) {
+      pa = fma(fma(fma(A3, u, A2), u, A1), u, A0);
+      pb = fma(fma(fma(B3, u, B2), u, B1), u, B0);
+    } else {
+      pa = fma(A1, u, A0);
+      pb = fma(B1, u, B0);
+    }
+    const double val = fma(pa, c, pb * s);
+    if constexpr (CPLX) {
+      const double t = val * g;
+      acc[k] = fma(mr, t, acc[k]);
+      acci[k] = fma(mi, t, acci[k]);
+    } else {
+      acc[k] = fma(val, g, acc[k]);
+    }
+    if constexpr (k + 1 < R) {
+      g *= r;
+      r *= q;
+      const double cn = fma(c, C1, -(s * S1));
+      s = fma(s, C1, c * S1);
+      c = cn;
+      u += step;
+    }
+  SH_END
+}
+
+struct UnitDesc {
+  int64_t j0;
+  int ch, ns, slot0, nslots, gaps, do_clip;
+  double offset, clip_lo, clip_hi;
+};
+__device__ __forceinline__ UnitDesc load_unit(const ShortUnit* up) {
+  UnitDesc u;
+  u.j0 = cload<int64_t>(up, offsetof(ShortUnit, j0));
+  u.ch = cload<int32_t>(up, offsetof(ShortUnit, ch));
+  u.ns = cload<int32_t>(up, offsetof(ShortUnit, n_samples));
+  u.slot0 = cload<int32_t>(up, offsetof(ShortUnit, slot0));
+  u.nslots = cload<int32_t>(up, offsetof(ShortUnit, n_slots));
+  u.gaps = cload<int32_t>(up, offsetof(ShortUnit, gaps));
+  u.do_clip = cload<int32_t>(up, offsetof(ShortUnit, do_clip));
+  u.offset = cload<double>(up, offsetof(ShortUnit, offset));
+  u.clip_lo = cload<double>(up, offsetof(ShortUnit, clip_lo));
+  u.clip_hi = cload<double>(up, offsetof(ShortUnit, clip_hi));
+  return u;
+}
+
+template <typename E, bool CPLX>
+__device__ __forceinline__ void add_old(E& v, const E& old) {
+  if constexpr (CPLX) { v.x += old.x; v.y += old.y; } else { v += old; }
+}
+
+// Software pipeline over the units of a chunk (every stage of the chain unit -> slot -> op record is
+// a dependent memory round trip of 1-2 us, as long as the evaluation of a whole unit):
+//   at the top of unit u the wave holds  desc(u), desc(u+1), slot(u), first op record of u;
+//   it issues desc(u+2) and slot(u+1), evaluates u, issues the first record of u+1, then stages and
+//   stores u while that record is in flight.
+template <typename T, bool CPLX, int R>
+__global__ void __launch_bounds__(64, CPLX ? 2 : 4) wfk_sample_short(const SArgs a) {
+  using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  E* const s_out = reinterpret_cast<E*>(s_raw);
+  const int lane = threadIdx.x;
+  // XCD-aware chunk map (workgroup b runs on XCD b % 8): XCD x walks the x-th contiguous eighth
+  const int64_t b = blockIdx.x;
+  const int64_t per = (a.n_chunks + 7) >> 3;
+  const int64_t chunk = (b & 7) * per + (b >> 3);
+  if (chunk >= a.n_chunks) return;
+  const int64_t u0 = chunk * a.units_per_chunk;
+  const int64_t u1 = u0 + a.units_per_chunk < a.n_units ? u0 + a.units_per_chunk : a.n_units;
+  const int64_t ulast = a.n_units - 1;
+
+  auto slot_of = [&](const UnitDesc& d) -> uint64_t {
+    return lane < d.nslots ? a.slots[d.slot0 + lane] : 0;
+  };
+  auto rec_of = [&](uint64_t slot) -> const double* { return a.recs + 2 * (int64_t)(uint32_t)slot; };
+
+  UnitDesc cur = load_unit(a.units + u0);
+  UnitDesc nxt = load_unit(a.units + (u0 + 1 <= ulast ? u0 + 1 : ulast));
+  uint64_t slot = slot_of(cur);
+  OpRec first = load_op(rec_of(slot));
+
+  for (int64_t ui = u0; ui < u1; ++ui) {
+    // two units ahead: descriptor; one ahead: slot words
+    const UnitDesc nn = load_unit(a.units + (ui + 2 <= ulast ? ui + 2 : ulast));
+    const uint64_t nslot = slot_of(nxt);
+
+    E* const orow = uniptr(reinterpret_cast<E*>(a.out) + (int64_t)cur.ch * a.ch_stride + cur.j0);
+    const int head = (int)(cur.j0 & 15);     // rows start on 16-sample boundaries (whole 128-B lines for fp64)
+    const int ns = cur.ns;
+    E fillv;
+    if constexpr (CPLX) { fillv.x = (T)cur.offset; fillv.y = (T)0; } else { fillv = (T)cur.offset; }
+
+    if (cur.nslots == 0) {
+      // pure fill: a long zero stretch (skipped _zero pieces: no clip, waveforms/_waveform.pyx:160-163)
+      for (int i = lane - head; i < ns; i += 64)
+        if (i >= 0) {
+          E v = fillv;
+          if (a.accumulate) add_old<E, CPLX>(v, orow[i]);
+          orow[i] = v;
+        }
+    } else {
+      const int len = (int)((slot >> 44) & 63);
+      const int o = (int)((slot >> 32) & 0xfff);
+      const double kf = (double)(int)((slot >> 50) & 0xfff);
+
+      double acc[R], acci[CPLX ? R : 1];
+      SH_EACH(R, k) acc[k] = 0.0; SH_END
+      SH_EACH(CPLX ? R : 1, k) acci[k] = 0.0; SH_END
+
+      const double* op = rec_of(slot);
+      OpRec rec = first;
+      bool live = len > 0;
+      while (__any(live)) {
+        const int w = op_word(rec);
+        const bool mine = live && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
+        const bool cubic = __any(mine && (w & 3) > 1);
+        if (mine) {
+          if (cubic) short_op<R, true, CPLX>(rec, op, w, kf, a.step, acc, acci);
+          else short_op<R, false, CPLX>(rec, op, w, kf, a.step, acc, acci);
+        }
+        const bool more = live && !(w & WFK_SH_LAST);
+        op += (w & 3) > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
+        if (__any(more)) {
+          if (more) rec = load_op(op);
+        }
+        live = more;
+      }
+
+      // the next unit's first op record: in flight while this unit is staged and stored
+      first = load_op(rec_of(nslot));
+
+      __syncthreads();            // the previous unit's store phase is done with the staging array
+      if (cur.gaps) {
+        for (int i = lane; i < ns; i += 64) s_out[swz(i)] = fillv;
+        __syncthreads();
+      }
+      // clip (evaluated pieces only: every slot is one), + offset, into the staging array
+      SH_EACH(R, k)
+        if (k < len) {
+          double v = acc[k];
+          if (cur.do_clip) v = clip_np(v, cur.clip_lo, cur.clip_hi);
+          v += cur.offset;
+          if constexpr (CPLX) {
+            E e;
+            e.x = (T)v;
+            e.y = (T)acci[k];
+            s_out[swz(o + k)] = e;
+          } else {
+            s_out[swz(o + k)] = (T)v;
+          }
+        }
+      SH_END
+      __syncthreads();
+
+      // store the unit's range: 64 consecutive samples per instruction, eight rows in flight
+      for (int i0 = lane - head; i0 < ns; i0 += 64 * 8) {
+        E v[8];
+        SH_EACH(8, r)
+          const int i = i0 + 64 * r;
+          if (i >= 0 && i < ns) v[r] = s_out[swz(i)];
+        SH_END
+        if (a.accumulate) {
+          SH_EACH(8, r)
+            const int i = i0 + 64 * r;
+            if (i >= 0 && i < ns) add_old<E, CPLX>(v[r], orow[i]);
+          SH_END
+        }
+        SH_EACH(8, r)
+          const int i = i0 + 64 * r;
+          if (i >= 0 && i < ns) orow[i] = v[r];
+        SH_END
+      }
+    }
+    if (cur.nslots == 0) first = load_op(rec_of(nslot));
+    cur = nxt;
+    nxt = nn;
+    slot = nslot;
+  }
+}
+
+template <typename T, bool CPLX>
+int launch_short(const SArgs& a, hipStream_t s) {
+  using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
+  const int64_t blocks = ((a.n_chunks + 7) >> 3) << 3;
+  if (blocks == 0) return 0;
+  if (blocks > 0x7fffffffLL) return -2;
+  const int cap = a.lds_samples > 0 ? a.lds_samples : 1;
+  const size_t lds = (size_t)(cap + (cap >> 4) + 1) * sizeof(E);
+  hipLaunchKernelGGL((wfk_sample_short<T, CPLX, WFK_SH_R>), dim3((unsigned)blocks), dim3(64), lds, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+int wfk_launch_short(const SArgs& a, int out_kind, void* stream, std::string& err) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  switch (out_kind) {
+    case WFK_OUT_F64: rc = launch_short<double, false>(a, s); break;
+    case WFK_OUT_F32: rc = launch_short<float, false>(a, s); break;
+    case WFK_OUT_C128: rc = launch_short<double, true>(a, s); break;
+    case WFK_OUT_C64: rc = launch_short<float, true>(a, s); break;
+    default: err = "bad out_kind"; return WFK_EINVAL;
+  }
+  if (rc == -2) { err = "grid too large"; return WFK_EINVAL; }
+  if (rc) { err = std::string("short kernel launch failed: ") + hipGetErrorString(hipGetLastError()); return WFK_EHIP; }
+  return WFK_OK;
+}

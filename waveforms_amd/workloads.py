@@ -114,6 +114,22 @@ def c4_kernel(K=1024):
     return ker
 
 
+def awg_channel(ns, c, n_pts=100000, rate=2e9, duty30=False, seed0=7000):
+    """One channel at an AWG sample rate: `mixing(A * gaussian(20 ns), freq, phase, DRAGScaling)`
+    pulses back to back (spacing SPAN = 30 ns, 100 % duty) or 100 ns apart (30 % duty) over the
+    n_pts / rate seconds that `awg_grid` samples -- what `Waveform.sample()` is called with
+    (reference waveforms/waveform.py:173-207; README.md:50-53 samples at 1 GS/s).  At 2 GS/s a
+    pulse is 60 samples."""
+    spacing = 100e-9 if duty30 else SPAN
+    nseg = int(n_pts / rate / spacing)
+    return sum_channel(ns, nseg, seed0 + c, spacing)
+
+
+def awg_grid(n_pts=100000, rate=2e9):
+    """np.arange(0, n_pts / rate, 1 / rate): the grid of Waveform.sample (waveform.py:190)."""
+    return ('arange', 0.0, n_pts / rate, 1.0 / rate)
+
+
 def make_grid(desc):
     """Materialise a grid descriptor with NumPy (host reference grid)."""
     kind = desc[0]
