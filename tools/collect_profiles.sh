@@ -21,10 +21,12 @@ case "$WL" in
   iir) ARGS="tools/iir_bench.py" ;;
   readout) ARGS="tools/readout_bench.py" ;;
   multitone) ARGS="tools/multitone_bench.py 10" ;;
+  awg) ARGS="tools/awg_bench.py 2048 1e5 2" ;;
+  awg30) ARGS="tools/awg_bench.py 2048 1e5 2 1" ;;
 esac
 echo "== stats pass ($WL)"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/stats.log" 2>&1
-for grp in WRITE_SIZE FETCH_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
+for grp in WRITE_SIZE FETCH_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
     name=$(echo $grp | cut -d' ' -f1)
     echo "== pmc pass $name"
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o run -- python3 $ARGS > "$OUT/pmc_$name.log" 2>&1

@@ -302,7 +302,7 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   const char* cplx = (out_kind == WFK_OUT_C128 || out_kind == WFK_OUT_C64) ? "true" : "false";
   const HostPlan& h = p->h;
   if (h.shortp) {
-    name = std::string("wfk_sample_short<") + T + "," + cplx + "," + std::to_string(WFK_SH_R) + ">";
+    name = std::string("wfk_sample_short<") + T + "," + cplx + ",false," + std::to_string(WFK_SH_R) + ">";
     return name.c_str();
   }
   const std::string lean_name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +

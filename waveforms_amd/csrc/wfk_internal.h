@@ -137,9 +137,10 @@
 //     [7] Gaussian: H = dt / sigma; exp: alpha dt        [8] q = exp(-2 H^2) (exp / none: 1)
 //     [9] A0 [10] A1 [11] B0 [12] B1 [13] -   ([14] A2 [15] A3 [16] B2 [17] B3)
 #define WFK_SH_R 16           // samples per lane segment
-#define WFK_SH_LCAP 2048      // samples a unit may span (LDS staging: 8 B each + 1/16 padding)
+#define WFK_SH_LCAP 1008      // samples a unit may span: with <= 15 samples of row alignment that is <= 16 rows of 64
+                              // (the kernel stores a unit with a FIXED sequence of 16 masked row stores)
 #define WFK_SH_SUB 4096       // samples per record of a long piece (slot.koff has 12 bits)
-#define WFK_SH_FILL 8192      // samples per pure-fill unit (long zero stretches: no slots, no LDS)
+#define WFK_SH_FILL 1008      // samples per pure-fill unit (long zero stretches: no slots, no LDS; same 16 rows)
 #define WFK_SH_OP1 14
 #define WFK_SH_OP3 18
 #define WFK_SH_LAST 64        // op word: last op of its record

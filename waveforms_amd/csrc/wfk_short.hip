@@ -145,6 +145,10 @@ struct OpRec {
 __device__ __forceinline__ OpRec load_op(const double* p) {
   const double2* q = reinterpret_cast<const double2*>(p);
   OpRec r;
+#if defined(WFK_SH_EXP) && WFK_SH_EXP == 2
+  r.a = r.b = r.c = r.d = r.e = r.f = r.g = make_double2(1.0, 0.5);   // timing experiment: no record traffic
+  return r;
+#endif
   r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4]; r.f = q[5]; r.g = q[6];
   return r;
 }
@@ -206,6 +210,9 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
   SH_END
 }
 
+#ifndef WFK_SH_WAVES
+#define WFK_SH_WAVES 3
+#endif
 struct UnitDesc {
   int64_t j0;
   int ch, ns, slot0, nslots, gaps, do_clip;
@@ -226,21 +233,52 @@ __device__ __forceinline__ UnitDesc load_unit(const ShortUnit* up) {
   return u;
 }
 
+// Raw buffer resources: the hardware range check does the masking.  A lane whose byte offset is
+// >= num_records (or "negative": huge as unsigned) loads 0 / stores nothing, so masked row stores and
+// the slot load of a partly filled unit are straight-line code without exec-mask branches.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <typename E>
+__device__ __forceinline__ void buf_store(const E& v, __amdgpu_buffer_rsrc_t r, int byte_off) {
+  if constexpr (sizeof(E) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+  else if constexpr (sizeof(E) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, byte_off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
+template <typename E>
+__device__ __forceinline__ E buf_load(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  if constexpr (sizeof(E) == 4) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+  else if constexpr (sizeof(E) == 8) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+  else return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
 template <typename E, bool CPLX>
 __device__ __forceinline__ void add_old(E& v, const E& old) {
   if constexpr (CPLX) { v.x += old.x; v.y += old.y; } else { v += old; }
 }
 
-// Software pipeline over the units of a chunk (every stage of the chain unit -> slot -> op record is
-// a dependent memory round trip of 1-2 us, as long as the evaluation of a whole unit):
-//   at the top of unit u the wave holds  desc(u), desc(u+1), slot(u), first op record of u;
-//   it issues desc(u+2) and slot(u+1), evaluates u, issues the first record of u+1, then stages and
-//   stores u while that record is in flight.
-template <typename T, bool CPLX, int R>
-__global__ void __launch_bounds__(64, CPLX ? 2 : 4) wfk_sample_short(const SArgs a) {
+// elements of the staging array: the longest unit (WFK_SH_LCAP samples + 15 of row alignment = 16 rows
+// of 64) in the 17-per-16 swizzle, plus the overrun of a last partial row
+constexpr int kStage = 68 * 16 + 16;
+
+// Software pipeline over the units of a chunk.  Every stage of the chain unit -> slot -> op record
+// is a dependent memory round trip of 1-2 us, as long as the evaluation of a whole unit, and on this
+// ISA loads and stores share ONE in-order counter (vmcnt): waiting for a load also waits for every
+// store issued before it.  So:
+//   * at the top of unit u the wave holds desc(u), desc(u+1), the decoded slot of u and the first op
+//     record of u (issued BEFORE the stores of u-1: the wait for it leaves those stores in flight);
+//   * it issues desc(u+2) and slot(u+1), evaluates u, decodes slot(u+1), issues the first record of
+//     u+1, then stages and stores u;
+//   * a unit is stored by a FIXED sequence of 16 masked row stores (units span <= 16 rows, the host
+//     sees to that): with a variable row loop the compiler cannot count the stores behind a load and
+//     falls back to vmcnt(0) at the loop's back edge -- every wave then idles until its own stores
+//     have been acknowledged (measured: 6 us per unit).
+template <typename T, bool CPLX, bool ACC, int R>
+__global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(const SArgs a) {
   using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  E* const s_out = reinterpret_cast<E*>(s_raw);
+  __shared__ __attribute__((aligned(16))) E s_out[kStage];
   const int lane = threadIdx.x;
   // XCD-aware chunk map (workgroup b runs on XCD b % 8): XCD x walks the x-th contiguous eighth
   const int64_t b = blockIdx.x;
@@ -251,19 +289,33 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : 4) wfk_sample_short(const SArgs
   const int64_t u1 = u0 + a.units_per_chunk < a.n_units ? u0 + a.units_per_chunk : a.n_units;
   const int64_t ulast = a.n_units - 1;
 
-  auto slot_of = [&](const UnitDesc& d) -> uint64_t {
-    return lane < d.nslots ? a.slots[d.slot0 + lane] : 0;
+  auto slot_of = [&](const UnitDesc& d) -> uint64_t {     // lanes >= nslots read 0: no segment
+    return buf_load<uint64_t>(make_rsrc(a.slots + d.slot0, (unsigned)d.nslots * 8u), lane * 8);
   };
-  auto rec_of = [&](uint64_t slot) -> const double* { return a.recs + 2 * (int64_t)(uint32_t)slot; };
+  // (len, o, kf, record) of this lane's segment
+  struct Seg { int len, o; double kf; const double* rec; };
+  auto decode = [&](uint64_t slot) -> Seg {
+    Seg g;
+    g.len = (int)((slot >> 44) & 63);
+    g.o = (int)((slot >> 32) & 0xfff);
+    g.kf = (double)(int)((slot >> 50) & 0xfff);
+    g.rec = a.recs + 2 * (int64_t)(uint32_t)slot;
+    return g;
+  };
 
-  UnitDesc cur = load_unit(a.units + u0);
-  UnitDesc nxt = load_unit(a.units + (u0 + 1 <= ulast ? u0 + 1 : ulast));
-  uint64_t slot = slot_of(cur);
-  OpRec first = load_op(rec_of(slot));
+  // The pipeline fills INSIDE the loop: iteration u0 - 1 works on an empty unit (no slots, zero samples:
+  // the range check drops its stores).  With a separate prologue the compiler merges two histories at the
+  // loop header and waits for the record as if only the prologue's single load followed it (vmcnt(1):
+  // every store of the previous unit), instead of leaving the 16 stores and the slot load in flight.
+  UnitDesc cur{};
+  UnitDesc nxt = load_unit(a.units + u0);
+  Seg seg{0, 0, 0.0, a.recs};
+  OpRec first{};
 
-  for (int64_t ui = u0; ui < u1; ++ui) {
-    // two units ahead: descriptor; one ahead: slot words
+  for (int64_t ui = u0 - 1; ui < u1; ++ui) {
+    // two units ahead: descriptor; one ahead: slot words (none past the end of the chunk)
     const UnitDesc nn = load_unit(a.units + (ui + 2 <= ulast ? ui + 2 : ulast));
+    if (ui + 1 >= u1) { nxt.nslots = 0; nxt.ns = 0; }
     const uint64_t nslot = slot_of(nxt);
 
     E* const orow = uniptr(reinterpret_cast<E*>(a.out) + (int64_t)cur.ch * a.ch_stride + cur.j0);
@@ -271,104 +323,136 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : 4) wfk_sample_short(const SArgs
     const int ns = cur.ns;
     E fillv;
     if constexpr (CPLX) { fillv.x = (T)cur.offset; fillv.y = (T)0; } else { fillv = (T)cur.offset; }
+    const int l0 = lane - head;                 // this lane's sample in row 0 (negative: before the unit)
+    const int s0 = l0 + (l0 >> 4);              // swz(64 r + l0) = 68 r + s0 for every row r (arithmetic shift)
 
-    if (cur.nslots == 0) {
-      // pure fill: a long zero stretch (skipped _zero pieces: no clip, waveforms/_waveform.pyx:160-163)
-      for (int i = lane - head; i < ns; i += 64)
-        if (i >= 0) {
-          E v = fillv;
-          if (a.accumulate) add_old<E, CPLX>(v, orow[i]);
-          orow[i] = v;
-        }
-    } else {
-      const int len = (int)((slot >> 44) & 63);
-      const int o = (int)((slot >> 32) & 0xfff);
-      const double kf = (double)(int)((slot >> 50) & 0xfff);
+    double acc[R], acci[CPLX ? R : 1];
+    SH_EACH(R, k) acc[k] = 0.0; SH_END
+    SH_EACH(CPLX ? R : 1, k) acci[k] = 0.0; SH_END
 
-      double acc[R], acci[CPLX ? R : 1];
-      SH_EACH(R, k) acc[k] = 0.0; SH_END
-      SH_EACH(CPLX ? R : 1, k) acci[k] = 0.0; SH_END
-
-      const double* op = rec_of(slot);
+    if (cur.nslots != 0) {
+      const double kf = seg.kf;
+      const double* op = seg.rec;
       OpRec rec = first;
-      bool live = len > 0;
-      while (__any(live)) {
-        const int w = op_word(rec);
-        const bool mine = live && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
+      bool live = seg.len > 0;
+#if defined(WFK_SH_EXP) && (WFK_SH_EXP == 1 || WFK_SH_EXP == 2)
+      live = false;                       // timing experiment: no evaluation
+      acc[0] = rec.a.y + rec.g.x;
+#endif
+      // The first op is evaluated in straight-line code, further ops (multi-tone pieces) in a loop:
+      // a loop whose body reads registers loaded before it gets a vmcnt(0) in its preheader from the
+      // compiler (SIInsertWaitcnts' preheader flush), which here would wait for the slot load just
+      // issued and for every store of the previous unit.
+      auto eval = [&](const OpRec& rc, const double* opp, bool lv) -> bool {   // -> another op follows
+        // (the unused halves of the record stay "live" up to here: registers that die at the load are
+        //  handed out again as temporaries while the load is still in flight, and writing them means
+        //  waiting for it -- a vmcnt(3) right behind the prefetch)
+        asm volatile("" : : "v"(rc.a.x), "v"(rc.g.y));
+        const int w = op_word(rc);
+        const bool mine = lv && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
         const bool cubic = __any(mine && (w & 3) > 1);
         if (mine) {
-          if (cubic) short_op<R, true, CPLX>(rec, op, w, kf, a.step, acc, acci);
-          else short_op<R, false, CPLX>(rec, op, w, kf, a.step, acc, acci);
+          if (cubic) short_op<R, true, CPLX>(rc, opp, w, kf, a.step, acc, acci);
+          else short_op<R, false, CPLX>(rc, opp, w, kf, a.step, acc, acci);
         }
-        const bool more = live && !(w & WFK_SH_LAST);
-        op += (w & 3) > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
-        if (__any(more)) {
-          if (more) rec = load_op(op);
-        }
-        live = more;
-      }
-
-      // the next unit's first op record: in flight while this unit is staged and stored
-      first = load_op(rec_of(nslot));
-
-      __syncthreads();            // the previous unit's store phase is done with the staging array
-      if (cur.gaps) {
-        for (int i = lane; i < ns; i += 64) s_out[swz(i)] = fillv;
-        __syncthreads();
-      }
-      // clip (evaluated pieces only: every slot is one), + offset, into the staging array
-      SH_EACH(R, k)
-        if (k < len) {
-          double v = acc[k];
-          if (cur.do_clip) v = clip_np(v, cur.clip_lo, cur.clip_hi);
-          v += cur.offset;
-          if constexpr (CPLX) {
-            E e;
-            e.x = (T)v;
-            e.y = (T)acci[k];
-            s_out[swz(o + k)] = e;
-          } else {
-            s_out[swz(o + k)] = (T)v;
-          }
-        }
-      SH_END
-      __syncthreads();
-
-      // store the unit's range: 64 consecutive samples per instruction, eight rows in flight
-      for (int i0 = lane - head; i0 < ns; i0 += 64 * 8) {
-        E v[8];
-        SH_EACH(8, r)
-          const int i = i0 + 64 * r;
-          if (i >= 0 && i < ns) v[r] = s_out[swz(i)];
-        SH_END
-        if (a.accumulate) {
-          SH_EACH(8, r)
-            const int i = i0 + 64 * r;
-            if (i >= 0 && i < ns) add_old<E, CPLX>(v[r], orow[i]);
-          SH_END
-        }
-        SH_EACH(8, r)
-          const int i = i0 + 64 * r;
-          if (i >= 0 && i < ns) orow[i] = v[r];
-        SH_END
+        return lv && !(w & WFK_SH_LAST);
+      };
+      live = eval(rec, op, live);
+      while (__any(live)) {
+        op += (op_word(rec) & 3) > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
+        if (live) rec = load_op(op);
+        live = eval(rec, op, live);
       }
     }
-    if (cur.nslots == 0) first = load_op(rec_of(nslot));
+
+    // the next unit's segment and first op record: in flight while this unit is staged and stored
+    const Seg nseg = decode(nslot);
+    first = load_op(nseg.rec);
+
+    if (cur.nslots != 0) {
+      __syncthreads();            // the previous unit's store phase is done with the staging array
+      // Staging layout: sample i of the unit sits at element swz(i) = i + (i >> 4) (a lane's run of 16
+      // starts 17 elements after its neighbour's: no bank conflicts); row r, lane x: 68 r + swz(x).
+      if (cur.gaps) {
+        const int f0 = swz(lane);
+        SH_EACH(16, r)
+          if (64 * r < ns) s_out[f0 + 68 * r] = fillv;
+        SH_END
+        __syncthreads();
+      }
+      // clip (evaluated pieces only: every slot is one), + offset
+      if (cur.do_clip) {
+        SH_EACH(R, k) acc[k] = clip_np(acc[k], cur.clip_lo, cur.clip_hi); SH_END
+      }
+      {
+        // element o + k lands at swz(o) + k + [k >= 16 - (o & 15)]: two bases, immediate offsets
+        const int o = seg.o, len = seg.len;
+        const int t = 16 - (o & 15);
+        E* const b0 = s_out + swz(o);
+        SH_EACH(R, k)
+          if (k < len) {                      // (a masked LDS write needs no wait: the branch is cheap)
+            E* const at = (k >= t ? b0 + 1 : b0) + k;
+            const double v = acc[k] + cur.offset;
+            if constexpr (CPLX) {
+              E e;
+              e.x = (T)v;
+              e.y = (T)acci[k];
+              *at = e;
+            } else {
+              *at = (T)v;
+            }
+          }
+        SH_END
+      }
+      __syncthreads();
+    }
+
+    // store the unit's range: 64 consecutive samples per instruction, 16 masked rows in two batches of
+    // eight.  The LDS reads are unconditional (row 0's index clamped: lanes before the unit read element
+    // 0 and never store it); a pure-fill unit (a zero stretch: skipped _zero pieces, no clip,
+    // waveforms/_waveform.pyx:160-163) stores `offset`.
+    const __amdgpu_buffer_rsrc_t ores = make_rsrc(orow, (unsigned)ns * (unsigned)sizeof(E));
+    const int b0off = l0 * (int)sizeof(E);                  // row 0: "negative" for the lanes before the unit
+    const int b1off = (64 + l0) * (int)sizeof(E);           // rows >= 1: never negative
+    SH_EACH(2, hb)
+      E v[8];
+      SH_EACH(8, rr)
+        constexpr int r = hb * 8 + rr;
+        v[rr] = fillv;
+        if (cur.nslots != 0) v[rr] = s_out[r == 0 ? max(s0, 0) : s0 + 68 * r];
+      SH_END
+      if constexpr (ACC) {
+        SH_EACH(8, rr)
+          constexpr int r = hb * 8 + rr;
+          add_old<E, CPLX>(v[rr], buf_load<E>(ores, r == 0 ? b0off : b1off + 64 * (r - 1) * (int)sizeof(E)));
+        SH_END
+      }
+      SH_EACH(8, rr)
+        constexpr int r = hb * 8 + rr;
+#if defined(WFK_SH_EXP) && WFK_SH_EXP == 3
+        if (v[rr] == (E)1.2345e-300) buf_store<E>(v[rr], ores, b0off);                 // timing experiment: no stores
+#else
+        buf_store<E>(v[rr], ores, r == 0 ? b0off : b1off + 64 * (r - 1) * (int)sizeof(E));
+#endif
+      SH_END
+    SH_END
+
     cur = nxt;
     nxt = nn;
-    slot = nslot;
+    seg = nseg;
   }
 }
 
 template <typename T, bool CPLX>
 int launch_short(const SArgs& a, hipStream_t s) {
-  using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
   const int64_t blocks = ((a.n_chunks + 7) >> 3) << 3;
   if (blocks == 0) return 0;
   if (blocks > 0x7fffffffLL) return -2;
-  const int cap = a.lds_samples > 0 ? a.lds_samples : 1;
-  const size_t lds = (size_t)(cap + (cap >> 4) + 1) * sizeof(E);
-  hipLaunchKernelGGL((wfk_sample_short<T, CPLX, WFK_SH_R>), dim3((unsigned)blocks), dim3(64), lds, s, a);
+  if (a.lds_samples > WFK_SH_LCAP) return -3;
+  if (a.accumulate)
+    hipLaunchKernelGGL((wfk_sample_short<T, CPLX, true, WFK_SH_R>), dim3((unsigned)blocks), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL((wfk_sample_short<T, CPLX, false, WFK_SH_R>), dim3((unsigned)blocks), dim3(64), 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -385,6 +469,7 @@ int wfk_launch_short(const SArgs& a, int out_kind, void* stream, std::string& er
     default: err = "bad out_kind"; return WFK_EINVAL;
   }
   if (rc == -2) { err = "grid too large"; return WFK_EINVAL; }
+  if (rc == -3) { err = "short plan: unit longer than the staging array"; return WFK_EINVAL; }
   if (rc) { err = std::string("short kernel launch failed: ") + hipGetErrorString(hipGetLastError()); return WFK_EHIP; }
   return WFK_OK;
 }
