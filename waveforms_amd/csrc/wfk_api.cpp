@@ -133,7 +133,7 @@ struct wfk_plan {
   int32_t* d_f32_chunk_first = nullptr;    // lean launch with float output: its own (longer) chunks
   double* d_tlist = nullptr;
   ShortUnit* d_units = nullptr;            // short plans (wfk_short.hip): wave units and lane slots
-  uint64_t* d_slots = nullptr;
+  uint32_t* d_slots = nullptr;
   void* d_scratch = nullptr;   // wfk_plan_run_host output buffer
   size_t scratch_bytes = 0;
   size_t scratch_cap = 0;
@@ -158,7 +158,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   const size_t b_cf = h.chunk_first.size() * sizeof(int32_t);
   const size_t b_lf = h.lean_chunk_first.size() * sizeof(int32_t);
   const size_t b_ff = h.f32_chunk_first.size() * sizeof(int32_t);
-  const size_t b_un = h.s_units.size() * sizeof(ShortUnit), b_sl = h.s_slots.size() * sizeof(uint64_t);
+  const size_t b_un = h.s_units.size() * sizeof(ShortUnit), b_sl = h.s_slots.size() * sizeof(uint32_t);
   const size_t o_ch = 0, o_pc = align256(o_ch + b_ch), o_pa = align256(o_pc + b_pc),
                o_po = align256(o_pa + b_pa), o_cf = align256(o_po + b_po),
                o_lf = align256(o_cf + b_cf), o_ff = align256(o_lf + b_lf), o_un = align256(o_ff + b_ff),
@@ -175,7 +175,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   p->d_lean_chunk_first = reinterpret_cast<int32_t*>(base + o_lf);
   p->d_f32_chunk_first = reinterpret_cast<int32_t*>(base + o_ff);
   p->d_units = reinterpret_cast<ShortUnit*>(base + o_un);
-  p->d_slots = reinterpret_cast<uint64_t*>(base + o_sl);
+  p->d_slots = reinterpret_cast<uint32_t*>(base + o_sl);
   p->d_tlist = tlist ? reinterpret_cast<double*>(base + o_tl) : nullptr;
   // the small tables travel in ONE copy; the time axis (as large as the output) on its own
   std::vector<char> stage(o_tl);

@@ -878,7 +878,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // ---- short tier: compact op records (WFK_SH_*), referenced to the first sample of each stretch ----
   // The group stands for  E(t') (A(u) cos th + B(u) sin th),  th = W t' - psi_ref,  u = t' - s_lin.
   // Everything a lane needs to seed the op `koff` samples after the reference sample x_ref:
-  //   th/pi = th0p + koff dthp,  u = u0 + koff dt,  Gaussian v = v0 + koff H  (exp: alpha t'' = v0 + koff H)
+  //   th/pi = th0p + koff dthp,  u' = koff dt (polynomials re-centred on x_ref),
+  //   Gaussian v = v0 + koff H  (exp: alpha t'' = v0 + koff H)
   auto emit_short_piece = [&](const std::vector<FceGroup>& groups, double tshift, int64_t s0, int64_t s1,
                               int32_t& n_rec) -> int32_t {
     const long double PIl = 3.141592653589793238462643383279502884L;
@@ -891,12 +892,12 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       const long double x0 = x;
       const size_t at = H.params.size();
       H.params.resize(at + (size_t)rec_len, 0.0);
-      double* rec = H.params.data() + at;
-      double* o = rec;
+      double* o = H.params.data() + at;
       for (const FceGroup& G : groups) {
         const int env = G.has_exp ? 2 : (G.has_env ? 1 : 0);
         const uint64_t word = (uint64_t)(uint32_t)((G.deg & 3) | ((G.W != 0.0 ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (env << 4) |
-                                                   (&G == &groups.back() ? WFK_SH_LAST : 0));
+                                                   (&G == &groups.back() ? WFK_SH_LAST : 0)) |
+                              ((uint64_t)(uint32_t)r0 << 32);
         std::memcpy(&o[0], &word, sizeof word);
         if (G.W != 0.0) {
           const long double th0 = (long double)G.W * x0 - G.psi_ref;
@@ -906,22 +907,31 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           o[3] = (double)cosl(dth);
           o[4] = (double)sinl(dth);
         } else {
-          o[1] = 0.0; o[2] = 0.0; o[3] = 1.0; o[4] = 0.0;
+          o[3] = 1.0;
         }
-        o[5] = (double)(x0 - (long double)(G.has_lin ? G.slin : 0.0));
-        o[8] = 1.0;
+        o[7] = 1.0;
         if (env == 1) {
           const long double Hh = (long double)grid->step / G.sigma;
-          o[6] = (double)((x0 - (long double)G.sg) / G.sigma);
-          o[7] = (double)Hh;
-          o[8] = (double)expl(-2.0L * Hh * Hh);
+          o[5] = (double)((x0 - (long double)G.sg) / G.sigma);
+          o[6] = (double)Hh;
+          o[7] = (double)expl(-2.0L * Hh * Hh);
         } else if (env == 2) {
-          o[6] = (double)((long double)G.sigma * (x0 - (long double)G.sg));
-          o[7] = (double)((long double)G.sigma * (long double)grid->step);
+          o[5] = (double)((long double)G.sigma * (x0 - (long double)G.sg));
+          o[6] = (double)((long double)G.sigma * (long double)grid->step);
         }
-        o[9] = (double)G.A[0]; o[10] = (double)G.A[1]; o[11] = (double)G.B[0]; o[12] = (double)G.B[1];
+        // A(u), B(u) about u0 = x_ref - s_lin:  P(u0 + w) = sum_i w^i sum_{m >= i} C(m, i) P_m u0^(m - i)
+        const long double u0 = G.has_lin ? x0 - (long double)G.slin : 0.0L;
+        static const int binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+        long double Ar[4] = {0, 0, 0, 0}, Br[4] = {0, 0, 0, 0};
+        for (int m = 0; m <= 3; ++m)
+          for (int i = 0; i <= m; ++i) {
+            const long double f = binom[m][i] * powl(u0, m - i);
+            Ar[i] += G.A[m] * f;
+            Br[i] += G.B[m] * f;
+          }
+        o[8] = (double)Ar[0]; o[9] = (double)Ar[1]; o[10] = (double)Br[0]; o[11] = (double)Br[1];
         if (G.deg > 1) {
-          o[14] = (double)G.A[2]; o[15] = (double)G.A[3]; o[16] = (double)G.B[2]; o[17] = (double)G.B[3];
+          o[12] = (double)Ar[2]; o[13] = (double)Ar[3]; o[14] = (double)Br[2]; o[15] = (double)Br[3];
           o += WFK_SH_OP3;
         } else {
           o += WFK_SH_OP1;
@@ -1196,7 +1206,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       ShortUnit U{};
       auto fresh = [&](int64_t j0) {
         U = ShortUnit{};
-        U.ch = c; U.j0 = j0; U.slot0 = (int32_t)H.s_slots.size();
+        U.ch = c; U.j0 = j0; U.slot0 = (int32_t)H.s_slots.size(); U.rec0 = -1;
         U.offset = H.channels[c].offset; U.clip_lo = H.channels[c].clip_lo; U.clip_hi = H.channels[c].clip_hi;
         U.do_clip = H.channels[c].do_clip;
       };
@@ -1204,6 +1214,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       auto close = [&](int64_t next_j0) {
         if (U.n_samples > 0) {
           if (U.n_slots > 0) H.s_lds_samples = std::max(H.s_lds_samples, U.n_samples);
+          if (U.rec0 < 0) U.rec0 = 0;
           H.s_units.push_back(U);
         }
         fresh(next_j0);
@@ -1215,7 +1226,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           int64_t z0 = D.start, left = D.stop - D.start;
           if (U.n_slots > 0) {
             const int64_t take = std::min<int64_t>(left, WFK_SH_LCAP - U.n_samples);
-            U.n_samples += (int32_t)take; U.gaps = 1;
+            U.n_samples += (int32_t)take; U.gaps |= 1;
             z0 += take; left -= take;
             if (left > 0) close(z0);
           }
@@ -1226,20 +1237,21 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             z0 += take; left -= take;
             close(z0);
           }
-          if (left > 0) { U.n_samples += (int32_t)left; U.gaps = 1; }
+          if (left > 0) { U.n_samples += (int32_t)left; U.gaps |= 1; }
           continue;
         }
         int32_t rec = 0;
         for (int64_t r0 = D.start; r0 < D.stop; r0 += WFK_SH_SUB, ++rec) {
           const int64_t len = std::min<int64_t>(WFK_SH_SUB, D.stop - r0);
           const int64_t nseg = (len + WFK_SH_R - 1) / WFK_SH_R, base = len / nseg, rem = len % nseg;
-          const uint64_t rec16 = (uint64_t)(D.par_off + (int64_t)rec * D.first_len) / 2;
-          if (rec16 > 0xffffffffULL) { err = "short tier: record table too large"; return WFK_EINVAL; }
+          const int64_t rec16 = (D.par_off + (int64_t)rec * D.first_len) / 2;
           int64_t k0 = 0;
           for (int64_t sgi = 0; sgi < nseg; ++sgi) {
             const int64_t sl = base + (sgi < rem ? 1 : 0);
-            if (U.n_slots == 64 || U.n_samples + sl > WFK_SH_LCAP) close(r0 + k0);
-            H.s_slots.push_back(WFK_SH_SLOT(rec16, U.n_samples, sl, k0));
+            if (U.n_slots == 64 || U.n_samples + sl > WFK_SH_LCAP ||
+                (U.rec0 >= 0 && rec16 - U.rec0 > WFK_SH_DREC_MAX)) close(r0 + k0);
+            if (U.rec0 < 0) U.rec0 = rec16;
+            H.s_slots.push_back(WFK_SH_SLOT(rec16 - U.rec0, U.n_samples, sl));
             ++U.n_slots;
             U.n_samples += (int32_t)sl;
             k0 += sl;

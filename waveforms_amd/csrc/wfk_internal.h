@@ -126,40 +126,46 @@
 //     still writes whole 128-B lines;
 //   * pieces carry COMPACT op records (16 or 20 doubles per op instead of 22 + a 34-double
 //     phasor table): at 60 samples per piece the tables are no longer negligible traffic.
-// Host tables: ShortUnit[] (one per wave unit), uint64 slots[] (one per segment), records in
-// `params`.  Record of a piece (or of each <= WFK_SH_SUB-sample stretch of a long piece): its ops
-// back to back, 16-B aligned, WFK_SH_OP1 doubles each (WFK_SH_OP3 when deg > 1):
-//     [0] word (int, low half): deg | carrier << 2 | imag << 3 | env << 4 (0 none, 1 Gaussian, 2 exp) |
-//         last op of the record << 6
-//     [1] th0/pi at the record's reference sample, reduced to [-1, 1]    [2] W dt / pi
-//     [3] cos(W dt)  [4] sin(W dt)   [5] u0 = x_ref - s_lin
-//     [6] Gaussian: v0 = (x_ref - s_g) / sigma; exp: alpha (x_ref - ref)
-//     [7] Gaussian: H = dt / sigma; exp: alpha dt        [8] q = exp(-2 H^2) (exp / none: 1)
-//     [9] A0 [10] A1 [11] B0 [12] B1 [13] -   ([14] A2 [15] A3 [16] B2 [17] B3)
+// Host tables: ShortUnit[] (one per wave unit), uint32 slots[] (one per segment), records in
+// `params`.  At 60 samples per piece the tables are real traffic (output 480 B per piece), so they
+// are kept small: 96 B per op, 4 B per segment.  Record of a piece (or of each <= WFK_SH_SUB-sample
+// stretch of a long piece): its ops back to back, 16-B aligned, WFK_SH_OP1 doubles each
+// (WFK_SH_OP3 when deg > 1):
+//     [0] low half: deg | carrier << 2 | imag << 3 | env << 4 (0 none, 1 Gaussian, 2 exp) | last op << 6
+//         high half: the record's reference sample (index in the channel): a lane's segment starts
+//         koff = j0 + o - ref samples after it
+//     [1] th0/pi at the reference sample, reduced to [-1, 1]    [2] W dt / pi
+//     [3] cos(W dt)  [4] sin(W dt)
+//     [5] Gaussian: v0 = (x_ref - s_g) / sigma; exp: alpha (x_ref - ref)
+//     [6] Gaussian: H = dt / sigma; exp: alpha dt        [7] q = exp(-2 H^2) (exp / none: 1)
+//     [8] A0 [9] A1 [10] B0 [11] B1   ([12] A2 [13] A3 [14] B2 [15] B3): polynomials in u = t - x_ref
+// (Taking cos / sin(W dt) from [2] on the device instead -- 80-B records -- was measured: the extra
+//  sin/cos kernel per lane and op cost more than the 16 B saved: 0.415 -> 0.446 ms on the AWG workload.)
 #define WFK_SH_R 16           // samples per lane segment
 #define WFK_SH_LCAP 1008      // samples a unit may span: with <= 15 samples of row alignment that is <= 16 rows of 64
                               // (the kernel stores a unit with a FIXED sequence of 16 masked row stores)
-#define WFK_SH_SUB 4096       // samples per record of a long piece (slot.koff has 12 bits)
+#define WFK_SH_SUB 4096       // samples per record of a long piece (phase = th0 + koff dth: koff stays small)
 #define WFK_SH_FILL 1008      // samples per pure-fill unit (long zero stretches: no slots, no LDS; same 16 rows)
-#define WFK_SH_OP1 14
-#define WFK_SH_OP3 18
+#define WFK_SH_OP1 12
+#define WFK_SH_OP3 16
 #define WFK_SH_LAST 64        // op word: last op of its record
 #define WFK_PF_SHORT 4        // piece carries compact records (par_off, n_blk = #records, first_len = doubles each)
-// slot word: record offset in 16-B units (32 bits) | sample offset in the unit << 32 (12 bits) |
-//            segment length << 44 (6 bits) | offset from the record's reference sample << 50 (12 bits)
-#define WFK_SH_SLOT(rec16, o, len, koff) \
-  ((uint64_t)(uint32_t)(rec16) | ((uint64_t)(o) << 32) | ((uint64_t)(len) << 44) | ((uint64_t)(koff) << 50))
+// slot word: record offset from the unit's first record in 16-B units (16 bits) | sample offset in the
+//            unit << 16 (10 bits) | (segment length - 1) << 26 (4 bits) | valid << 31
+#define WFK_SH_SLOT(drec16, o, len) \
+  ((uint32_t)(drec16) | ((uint32_t)(o) << 16) | ((uint32_t)((len) - 1) << 26) | 0x80000000u)
+#define WFK_SH_DREC_MAX 0xffff
 
 struct ShortUnit {            // 64 B: everything a wave needs about its unit in one scalar load
   int64_t j0;                 // first sample of the unit in its channel
   int32_t ch;
-  int32_t n_samples;          // samples covered (mixed units: <= WFK_SH_LCAP)
+  int32_t n_samples;          // samples covered (<= WFK_SH_LCAP)
   int32_t slot0;              // first slot
   int32_t n_slots;            // 0: pure fill (`offset` everywhere)
-  int32_t gaps;               // the slots do not cover the range: LDS is pre-filled with `offset`
+  int32_t gaps;               // bit 0: the slots do not cover the range: LDS is pre-filled with `offset`
   int32_t do_clip;            // channel constants, copied here: no dependent second load
   double offset, clip_lo, clip_hi;
-  double pad;
+  int64_t rec0;               // first record of the unit, in 16-B units of `params`
 };
 
 struct DevPiece {
@@ -180,7 +186,7 @@ struct DevChannel {
 struct SArgs {                // short-tier launch (wfk_short.hip)
   const DevChannel* channels;
   const ShortUnit* units;
-  const uint64_t* slots;
+  const uint32_t* slots;
   const double* recs;         // == the plan's `params`
   void* out;
   int64_t ch_stride;          // elements
@@ -253,7 +259,7 @@ struct HostPlan {
   // short tier (WFK_SH_*): `params` then holds the compact records
   bool shortp = false;
   std::vector<ShortUnit> s_units;
-  std::vector<uint64_t> s_slots;
+  std::vector<uint32_t> s_slots;
   int32_t s_lds_samples = 0, s_units_per_chunk = 1;
 };
 

@@ -140,30 +140,32 @@ __device__ __forceinline__ double clip_np(double v, double lo, double hi) {
 
 // one op record in registers (the first op of the NEXT unit is fetched while this unit stores)
 struct OpRec {
-  double2 a, b, c, d, e, f, g;    // doubles 0..13 of the record
+  double2 a, b, c, d, e, f;    // doubles 0..11 of the record (WFK_SH_OP1)
 };
 __device__ __forceinline__ OpRec load_op(const double* p) {
   const double2* q = reinterpret_cast<const double2*>(p);
   OpRec r;
 #if defined(WFK_SH_EXP) && WFK_SH_EXP == 2
-  r.a = r.b = r.c = r.d = r.e = r.f = r.g = make_double2(1.0, 0.5);   // timing experiment: no record traffic
+  r.a = r.b = r.c = r.d = r.e = r.f = make_double2(1.0, 0.5);   // timing experiment: no record traffic
   return r;
 #endif
-  r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4]; r.f = q[5]; r.g = q[6];
+  r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4]; r.f = q[5];
   return r;
 }
 __device__ __forceinline__ int op_word(const OpRec& r) { return (int)__double2loint(r.a.x); }
+__device__ __forceinline__ int op_ref(const OpRec& r) { return (int)__double2hiint(r.a.x); }
 
-// one fused op over the lane's run: acc[k] += E_k (A(u_k) c_k + B(u_k) s_k), all state per lane
+// one fused op over the lane's run: acc[k] += E_k (A(u_k) c_k + B(u_k) s_k), all state per lane.
+// `kf`: samples between the record's reference sample and the lane's first one.
 template <int R, bool CUBIC, bool CPLX>
 __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w, double kf, double step,
                                          double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
   const int env = (w >> 4) & 3;
-  const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.y, q = o.e.x;
-  const double A0 = o.e.y, A1 = o.f.x, B0 = o.f.y, B1 = o.g.x;
+  const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.x, q = o.d.y;
+  const double A0 = o.e.x, A1 = o.e.y, B0 = o.f.x, B1 = o.f.y;
   double A2 = 0.0, A3 = 0.0, B2 = 0.0, B3 = 0.0;
   if constexpr (CUBIC) {
-    if ((w & 3) > 1) { A2 = op[14]; A3 = op[15]; B2 = op[16]; B3 = op[17]; }
+    if ((w & 3) > 1) { A2 = op[12]; A3 = op[13]; B2 = op[14]; B3 = op[15]; }
   }
   // exact seeds at the lane's first sample, `kf` samples after the record's reference sample
   double c, s;
@@ -173,11 +175,11 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
     sincospi_small(x - n, &s, &c);
     if (((int)n) & 1) { c = -c; s = -s; }
   }
-  const double vv = fma(kf, Hh, o.d.x);
+  const double vv = fma(kf, Hh, o.c.y);
   const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
   const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
   double g = exp_small(ea), r = exp_small(eb);
-  double u = fma(kf, step, o.c.y);
+  double u = kf * step;
   double mr = 1.0, mi = 0.0;
   if constexpr (CPLX) {
     if (w & 8) { mr = 0.0; mi = 1.0; }
@@ -214,7 +216,7 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
 #define WFK_SH_WAVES 3
 #endif
 struct UnitDesc {
-  int64_t j0;
+  int64_t j0, rec0;
   int ch, ns, slot0, nslots, gaps, do_clip;
   double offset, clip_lo, clip_hi;
 };
@@ -230,6 +232,7 @@ __device__ __forceinline__ UnitDesc load_unit(const ShortUnit* up) {
   u.offset = cload<double>(up, offsetof(ShortUnit, offset));
   u.clip_lo = cload<double>(up, offsetof(ShortUnit, clip_lo));
   u.clip_hi = cload<double>(up, offsetof(ShortUnit, clip_hi));
+  u.rec0 = cload<int64_t>(up, offsetof(ShortUnit, rec0));
   return u;
 }
 
@@ -289,17 +292,17 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
   const int64_t u1 = u0 + a.units_per_chunk < a.n_units ? u0 + a.units_per_chunk : a.n_units;
   const int64_t ulast = a.n_units - 1;
 
-  auto slot_of = [&](const UnitDesc& d) -> uint64_t {     // lanes >= nslots read 0: no segment
-    return buf_load<uint64_t>(make_rsrc(a.slots + d.slot0, (unsigned)d.nslots * 8u), lane * 8);
+  auto slot_of = [&](const UnitDesc& d) -> uint32_t {     // lanes >= nslots read 0: no segment
+    return buf_load<uint32_t>(make_rsrc(a.slots + d.slot0, (unsigned)d.nslots * 4u), lane * 4);
   };
-  // (len, o, kf, record) of this lane's segment
-  struct Seg { int len, o; double kf; const double* rec; };
-  auto decode = [&](uint64_t slot) -> Seg {
+  // (len, o, first sample's index, record) of this lane's segment
+  struct Seg { int len, o, j; const double* rec; };
+  auto decode = [&](uint32_t slot, const UnitDesc& d) -> Seg {
     Seg g;
-    g.len = (int)((slot >> 44) & 63);
-    g.o = (int)((slot >> 32) & 0xfff);
-    g.kf = (double)(int)((slot >> 50) & 0xfff);
-    g.rec = a.recs + 2 * (int64_t)(uint32_t)slot;
+    g.len = (slot >> 31) ? (int)((slot >> 26) & 15) + 1 : 0;
+    g.o = (int)((slot >> 16) & 0x3ff);
+    g.j = (int)(uint32_t)d.j0 + g.o;
+    g.rec = a.recs + 2 * (d.rec0 + (int64_t)(slot & 0xffff));
     return g;
   };
 
@@ -309,14 +312,14 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
   // every store of the previous unit), instead of leaving the 16 stores and the slot load in flight.
   UnitDesc cur{};
   UnitDesc nxt = load_unit(a.units + u0);
-  Seg seg{0, 0, 0.0, a.recs};
+  Seg seg{0, 0, 0, a.recs};
   OpRec first{};
 
   for (int64_t ui = u0 - 1; ui < u1; ++ui) {
     // two units ahead: descriptor; one ahead: slot words (none past the end of the chunk)
     const UnitDesc nn = load_unit(a.units + (ui + 2 <= ulast ? ui + 2 : ulast));
     if (ui + 1 >= u1) { nxt.nslots = 0; nxt.ns = 0; }
-    const uint64_t nslot = slot_of(nxt);
+    const uint32_t nslot = slot_of(nxt);
 
     E* const orow = uniptr(reinterpret_cast<E*>(a.out) + (int64_t)cur.ch * a.ch_stride + cur.j0);
     const int head = (int)(cur.j0 & 15);     // rows start on 16-sample boundaries (whole 128-B lines for fp64)
@@ -331,13 +334,13 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
     SH_EACH(CPLX ? R : 1, k) acci[k] = 0.0; SH_END
 
     if (cur.nslots != 0) {
-      const double kf = seg.kf;
+      const double kf = (double)(seg.j - op_ref(first));   // samples from the record's reference sample
       const double* op = seg.rec;
       OpRec rec = first;
       bool live = seg.len > 0;
 #if defined(WFK_SH_EXP) && (WFK_SH_EXP == 1 || WFK_SH_EXP == 2)
       live = false;                       // timing experiment: no evaluation
-      acc[0] = rec.a.y + rec.g.x;
+      acc[0] = rec.a.y + rec.f.x;
 #endif
       // The first op is evaluated in straight-line code, further ops (multi-tone pieces) in a loop:
       // a loop whose body reads registers loaded before it gets a vmcnt(0) in its preheader from the
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         // (the unused halves of the record stay "live" up to here: registers that die at the load are
         //  handed out again as temporaries while the load is still in flight, and writing them means
         //  waiting for it -- a vmcnt(3) right behind the prefetch)
-        asm volatile("" : : "v"(rc.a.x), "v"(rc.g.y));
+        asm volatile("" : : "v"(rc.a.x));
         const int w = op_word(rc);
         const bool mine = lv && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
         const bool cubic = __any(mine && (w & 3) > 1);
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
     }
 
     // the next unit's segment and first op record: in flight while this unit is staged and stored
-    const Seg nseg = decode(nslot);
+    const Seg nseg = decode(nslot, nxt);
     first = load_op(nseg.rec);
 
     if (cur.nslots != 0) {
