@@ -21,8 +21,9 @@ case "$WL" in
   iir) ARGS="tools/iir_bench.py" ;;
   readout) ARGS="tools/readout_bench.py" ;;
   multitone) ARGS="tools/multitone_bench.py 10" ;;
-  awg) ARGS="tools/awg_bench.py 2048 1e5 2" ;;
-  awg30) ARGS="tools/awg_bench.py 2048 1e5 2 1" ;;
+  awg) ARGS="tools/awg_bench.py 2048 1e5 2 0 float64" ;;
+  awg30) ARGS="tools/awg_bench.py 2048 1e5 2 1 float64" ;;
+  awg_f32) ARGS="tools/awg_bench.py 2048 1e5 2 0 float32" ;;
 esac
 echo "== stats pass ($WL)"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/stats.log" 2>&1

@@ -1215,6 +1215,17 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         if (U.n_samples > 0) {
           if (U.n_slots > 0) H.s_lds_samples = std::max(H.s_lds_samples, U.n_samples);
           if (U.rec0 < 0) U.rec0 = 0;
+          if (U.n_slots > 0) {
+            // LDS staging layout of this unit (wfk_short.hip): plain or padded by one element per 16,
+            // whichever spreads the lanes' first elements over more of the 16 bank pairs
+            int plain[16] = {0}, padded[16] = {0}, wp = 0, wq = 0;
+            for (int32_t k = 0; k < U.n_slots; ++k) {
+              const int o = (int)((H.s_slots[(size_t)U.slot0 + k] >> 16) & 0x3ff);
+              wp = std::max(wp, ++plain[o & 15]);
+              wq = std::max(wq, ++padded[(o + (o >> 4)) & 15]);
+            }
+            if (wq < wp) U.gaps |= 2;
+          }
           H.s_units.push_back(U);
         }
         fresh(next_j0);
@@ -1263,14 +1274,14 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (H.s_slots.empty()) H.s_slots.push_back(0);
     // workgroup = one wave walking `units_per_chunk` consecutive units
     const int64_t nu = (int64_t)H.s_units.size();
-    H.s_units_per_chunk = (int32_t)std::min<int64_t>(8, std::max<int64_t>(1, nu / 8192));
+    H.s_units_per_chunk = (int32_t)std::min<int64_t>(6, std::max<int64_t>(1, nu / 8192));
     if (const char* e = std::getenv("WFK_SH_UPC")) {   // tuning override
       const int v = std::atoi(e);
       if (v >= 1 && v <= 64) H.s_units_per_chunk = v;
     }
     H.chunks_per_ch = 0;
     if (H.pool.empty()) H.pool.push_back(0.0);
-    H.params.resize(H.params.size() + 8, 0.0);   // (the kernel may read one op record past the last real one)
+    H.params.resize(H.params.size() + 272, 0.0);   // (the kernel reads one op record past the last real one, and touches 2 KB ahead)
     return WFK_OK;
   }
 

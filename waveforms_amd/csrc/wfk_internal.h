@@ -162,7 +162,8 @@ struct ShortUnit {            // 64 B: everything a wave needs about its unit in
   int32_t n_samples;          // samples covered (<= WFK_SH_LCAP)
   int32_t slot0;              // first slot
   int32_t n_slots;            // 0: pure fill (`offset` everywhere)
-  int32_t gaps;               // bit 0: the slots do not cover the range: LDS is pre-filled with `offset`
+  int32_t gaps;               // bit 0: the slots do not cover the range: LDS is pre-filled with `offset`; bit 1: the
+                              // staging array is padded by one element per 16 (segments that start 16 apart)
   int32_t do_clip;            // channel constants, copied here: no dependent second load
   double offset, clip_lo, clip_hi;
   int64_t rec0;               // first record of the unit, in 16-B units of `params`

@@ -320,14 +320,19 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
     const UnitDesc nn = load_unit(a.units + (ui + 2 <= ulast ? ui + 2 : ulast));
     if (ui + 1 >= u1) { nxt.nslots = 0; nxt.ns = 0; }
     const uint32_t nslot = slot_of(nxt);
-
     E* const orow = uniptr(reinterpret_cast<E*>(a.out) + (int64_t)cur.ch * a.ch_stride + cur.j0);
     const int head = (int)(cur.j0 & 15);     // rows start on 16-sample boundaries (whole 128-B lines for fp64)
     const int ns = cur.ns;
     E fillv;
     if constexpr (CPLX) { fillv.x = (T)cur.offset; fillv.y = (T)0; } else { fillv = (T)cur.offset; }
     const int l0 = lane - head;                 // this lane's sample in row 0 (negative: before the unit)
-    const int s0 = l0 + (l0 >> 4);              // swz(64 r + l0) = 68 r + s0 for every row r (arithmetic shift)
+    // Staging layout, chosen per unit by the host for the unit's own segment offsets: plain (sample i at
+    // element i: conflict-free when the runs start an odd number of samples apart, e.g. 15), or padded by
+    // one element per 16 (i + (i >> 4): runs of 16 then start 17 apart).  Either way row r, lane x sits at
+    // rs * r + f(x), one per-lane base and a uniform row stride.
+    const bool sw = (cur.gaps & 2) != 0;
+    const int rs = sw ? 68 : 64;
+    const int s0 = sw ? l0 + (l0 >> 4) : l0;    // (arithmetic shift: exact for the negative l0 of row 0 too)
 
     double acc[R], acci[CPLX ? R : 1];
     SH_EACH(R, k) acc[k] = 0.0; SH_END
@@ -374,12 +379,10 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
 
     if (cur.nslots != 0) {
       __syncthreads();            // the previous unit's store phase is done with the staging array
-      // Staging layout: sample i of the unit sits at element swz(i) = i + (i >> 4) (a lane's run of 16
-      // starts 17 elements after its neighbour's: no bank conflicts); row r, lane x: 68 r + swz(x).
-      if (cur.gaps) {
-        const int f0 = swz(lane);
+      if (cur.gaps & 1) {
+        const int f0 = sw ? swz(lane) : lane;
         SH_EACH(16, r)
-          if (64 * r < ns) s_out[f0 + 68 * r] = fillv;
+          if (64 * r < ns) s_out[f0 + rs * r] = fillv;
         SH_END
         __syncthreads();
       }
@@ -388,10 +391,10 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         SH_EACH(R, k) acc[k] = clip_np(acc[k], cur.clip_lo, cur.clip_hi); SH_END
       }
       {
-        // element o + k lands at swz(o) + k + [k >= 16 - (o & 15)]: two bases, immediate offsets
+        // padded layout: element o + k lands at swz(o) + k + [k >= 16 - (o & 15)]: two bases, immediate offsets
         const int o = seg.o, len = seg.len;
-        const int t = 16 - (o & 15);
-        E* const b0 = s_out + swz(o);
+        const int t = sw ? 16 - (o & 15) : 99;
+        E* const b0 = s_out + (sw ? swz(o) : o);
         SH_EACH(R, k)
           if (k < len) {                      // (a masked LDS write needs no wait: the branch is cheap)
             E* const at = (k >= t ? b0 + 1 : b0) + k;
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
       SH_EACH(8, rr)
         constexpr int r = hb * 8 + rr;
         v[rr] = fillv;
-        if (cur.nslots != 0) v[rr] = s_out[r == 0 ? max(s0, 0) : s0 + 68 * r];
+        if (cur.nslots != 0) v[rr] = s_out[r == 0 ? max(s0, 0) : s0 + rs * r];
       SH_END
       if constexpr (ACC) {
         SH_EACH(8, rr)
