@@ -14,8 +14,14 @@ Workloads (SURVEY.md §8(d) / BASELINE.json configs):
   c4                    sampler256 followed by the 1024-tap FIR stage
   c5                    C5 per-rank shape: 512 channels x 1e7 points per GPU (seeds 1000+c
                         over the GLOBAL channel index; 4096 channels at --gpus 8), fp64
-  far                   256 channels x 2e6 points at 2 GS/s = a 1 ms sequence, 300 MHz
-                        carriers (phases of ~2e6 rad: the grid-rounding regime)
+  far                   256 channels x 2e6 points at 2 GS/s = a 1 ms sequence of back-to-back 10 us
+                        pulses under 250-350 MHz carriers (phases of ~2e6 rad: the grid-rounding
+                        regime; every sample carries the correction).  far_sparse: the
+                        round-2 shape, 200 ns pulses 10 us apart (97 % zero fill)
+  awg / awg_duty30      2048 rows x 1e5 points at 2 GS/s (np.arange grid, what Waveform.sample()
+                        uses): mixing(gaussian(20 ns), DRAGScaling) pulses back to back (60 samples
+                        per pulse) / 100 ns apart (30 % duty); 16 distinct channels per 2048 rows,
+                        every row with its own device tables (short-piece tier)
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); channels are
 independent, so each rank samples its own block of channels with no data-path
@@ -109,7 +115,8 @@ def launch_ranks(args, argv):
 # ---------------------------------------------------------------------------------------
 def far_channel(ns, c, nseg=100, spacing=10e-6, width=200e-9):
     """One channel of a 1 ms sequence: `nseg` gaussian+DRAG pulses 10 us apart, carriers of
-    +-(250..350) MHz: phases up to 2 pi * 350e6 * 1e-3 = 2.2e6 rad (routine T1/echo shapes)."""
+    +-(250..350) MHz: phases up to 2 pi * 350e6 * 1e-3 = 2.2e6 rad (routine T1/echo shapes).
+    width = spacing / 1.5 makes the pulses contiguous (gaussian(w) lives on +-0.75 w)."""
     import numpy as np
     rng = np.random.default_rng(5000 + c)
     ws = []
@@ -149,16 +156,28 @@ def workload(name, channels, points):
     if name == 'c3':
         return (lambda c: wl.vstack_channel(wf, 20, 100 + c)), wl.c3_grid(points), np.float32, (
             f'C3: {channels} WaveVStack ch/GPU x 20 pulses x {points:.0e} pts')
-    if name == 'far':
-        return (lambda c: far_channel(wf, c)), ('linspace', 0.0, points / 2e9, points, False), \
-            np.float64, (f'{channels} ch/GPU x {points:.0e} pts at 2 GS/s, 100 pulses/ch with '
+    if name in ('far', 'far_sparse'):
+        width = 200e-9 if name == 'far_sparse' else 10e-6 / 1.5
+        return (lambda c: far_channel(wf, c, width=width)), ('linspace', 0.0, points / 2e9, points, False), \
+            np.float64, (f'{channels} ch/GPU x {points:.0e} pts at 2 GS/s, 100 pulses/ch '
+                         f'({"200 ns wide, 10 us apart" if name == "far_sparse" else "10 us each, back to back"}) with '
                          f'250-350 MHz carriers out to t = {points / 2e9 * 1e3:.1f} ms')
+    if name in ('awg', 'awg_duty30'):
+        d30 = name == 'awg_duty30'
+        return (lambda c: wl.awg_channel(wf, c, points, 2e9, d30)), wl.awg_grid(points, 2e9), np.float64, (
+            f'{channels} rows/GPU x {points:.0e} pts at 2 GS/s (np.arange grid of Waveform.sample), '
+            f'mixing(gaussian(20 ns), DRAGScaling) pulses ' + ('100 ns apart (30 % duty)' if d30 else 'back to back') +
+            f', 60 samples per pulse; {channels // TILE[name]} distinct channels x {TILE[name]} copies, every row with '
+            f'its own device tables')
     raise SystemExit(f'unknown workload {name}')
 
 
+TILE = {'awg': 128, 'awg_duty30': 128}     # rows = TILE copies of rows / TILE distinct channels
+
+
 def default_shape(name):
-    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512}.get(name, 256)
-    points = {'c3': 10**6, 'far': 2 * 10**6}.get(name, 10**7)
+    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512, 'awg': 2048, 'awg_duty30': 2048}.get(name, 256)
+    points = {'c3': 10**6, 'far': 2 * 10**6, 'far_sparse': 2 * 10**6, 'awg': 10**5, 'awg_duty30': 10**5}.get(name, 10**7)
     return channels, points
 
 
@@ -257,8 +276,9 @@ def run_plan_only(args, rank, world):
     channels, points = args.channels or dch, int(args.points or dpts)
     make_channel, grid, dtype, desc = workload(name, channels, points)
     a, b = channel_block(channels * world, rank, world)
+    tile = TILE.get(name, 1)
     t0 = time.perf_counter()
-    prog = _flatten.flatten([make_channel(c) for c in range(a, b)])
+    prog = _flatten.tile_program(_flatten.flatten([make_channel(c) for c in range(a // tile, a // tile + (b - a) // tile)]), tile)
     plan = _engine.Plan(prog, grid=_flatten.grid_from_desc(grid))
     dt = time.perf_counter() - t0
     info = [float(a), float(b), float(plan.info.n_pieces), float(plan.info.n_fused), dt]
@@ -322,9 +342,12 @@ def run_rank(args):
     if args.dtype:
         dtype = np.float64 if args.dtype == 'f64' else np.float32
     # weak scaling: every rank owns a block of `channels` channels of the global job
-    sh = ShardedSampler(channels * world, make_channel, grid, rank, world)
+    tile = TILE.get(name, 1)
+    if channels % tile:
+        raise SystemExit(f'--channels must be a multiple of {tile} for workload {name}')
+    sh = ShardedSampler(channels * world, make_channel, grid, rank, world, tile=tile)
     bs = sh.local
-    chans = [make_channel(c) for c in range(min(channels, 32))] if rank == 0 else []
+    chans = [make_channel(c) for c in range(min(channels // tile, 32))] if rank == 0 else []
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     out = torch.empty((bs.n_channels, bs.n), dtype=tdt, device='cuda')
     fir = chain = None
@@ -401,9 +424,12 @@ def run_rank(args):
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     traffic, traffic_src = profile_traffic(name)
 
+    table_bytes = bs.plan.table_bytes()
     roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,
+            'table_bytes_per_launch': table_bytes,
+            'frac_incl_tables': (algo_bytes + table_bytes) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'kernel': bs.plan.kernel_name(dtype),
             'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': algo_bytes,
             'timing': 'HIP events around every launch on the launch stream, mean over the timed steps'}
@@ -529,10 +555,11 @@ def run_rank(args):
             del o32
         # BASELINE configs[1] and [2], and the far-from-origin sequence, in the same line (kernel time
         # by HIP events, frac of 8 TB/s)
-        for wname in ('c2', 'c3', 'far'):
+        for wname in ('c2', 'c3', 'far', 'awg', 'awg_duty30'):
             wch, wpts = default_shape(wname)
             mk, g, dt_, d_ = workload(wname, wch, wpts)
-            b2 = BatchSampler([mk(c) for c in range(wch)], g)
+            wt = TILE.get(wname, 1)
+            b2 = BatchSampler([mk(c) for c in range(wch // wt)], g, tile=wt)
             o2 = torch.empty((b2.n_channels, b2.n), device='cuda',
                              dtype=torch.float64 if dt_ == np.float64 else torch.float32)
             ms = timed(lambda: b2.launch_torch(o2), 200 if wname == 'c2' else 50, 10)
@@ -542,11 +569,22 @@ def run_rank(args):
                            'algorithmic_bytes_per_launch': nbytes,
                            'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            'dtype': 'f64' if dt_ == np.float64 else 'f32'}
+            if wname.startswith('awg'):
+                # at 60 samples per piece the tables are real traffic: report them, and the float launch
+                tb = b2.plan.table_bytes()
+                also[wname]['table_bytes_per_launch'] = tb
+                also[wname]['frac_incl_tables'] = (nbytes + tb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                o3 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float32)
+                ms3 = timed(lambda: b2.launch_torch(o3), 50, 10)
+                also[wname]['f32'] = {'kernel': b2.plan.kernel_name(np.float32), 'kernel_ms': ms3,
+                                      'msamples_per_s': b2.n_channels * b2.n / (ms3 * 1e-3) / 1e6,
+                                      'frac': nbytes / 2 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del o3
             del o2
             b2.close()
         line['also'] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline and name in (
-            'sampler256', 'c4', 'c5', 'c2', 'far'):
+            'sampler256', 'c4', 'c5', 'c2', 'far', 'far_sparse', 'awg', 'awg_duty30'):
         base, outs = cpu_baseline(chans, grid)
         line['cpu_baseline'] = base
         line['speedup_vs_cpu_baseline'] = line['value'] / base['value']

@@ -169,6 +169,10 @@ int wfk_plan_channel_is_complex(const wfk_plan* plan, int32_t channel);
 /* Name of the device kernel a launch of this plan with `out_kind` selects (the symbol
  * rocprofv3 --kernel-trace shows, template arguments included), for reports.           */
 const char* wfk_plan_kernel_name(const wfk_plan* plan, int out_kind);
+/* Bytes of device tables a launch of this plan reads (channels, pieces / units, parameter records,
+ * slots, pool): at AWG sample rates (tens of samples per piece) they are a real share of the HBM
+ * traffic next to the output stream, and bench.py reports them beside the algorithmic bytes.      */
+int64_t wfk_plan_table_bytes(const wfk_plan* plan);
 /* Evaluate every channel into out_dev[ch*ch_stride + i] (elements of out_kind).
  * Asynchronous on `hip_stream` (a hipStream_t, or NULL for the null stream).   */
 int wfk_plan_launch(wfk_plan* plan, void* out_dev, int64_t ch_stride,

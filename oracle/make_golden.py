@@ -24,6 +24,7 @@ Outputs
   tests/golden/c4_full.npz        C4 rows 0 and 7 at the full 1e7 points: sampled + FIR-filtered subsets
   tests/golden/logic.json         marker / mask / | / & flat lists per case
   tests/golden/user.npz           scripts with Python-callable primitives (function(), function_lib=)
+  tests/golden/awg.npz            pulse trains on 1-5 GS/s arange grids (AWG_CASES): full vectors + piece edges
 """
 import json
 import os
@@ -127,6 +128,31 @@ def make_late(ref, gold):
     np.savez_compressed(os.path.join(gold, 'late.npz'), **late)
 
 
+def make_awg(ref, gold):
+    """tests/cases.py AWG_CASES: pulse trains on 1-5 GS/s np.arange grids (the regime of Waveform.sample,
+    reference waveform.py:173-207), FULL reference vectors + the np.searchsorted piece edges."""
+    import cases
+    from waveforms_amd import workloads as wl
+    from waveforms.waveform import WaveVStack
+    awg = {}
+    for name, (build, rate, n) in cases.AWG_CASES.items():
+        w = build(ref, rate)
+        t = wl.make_grid(cases._awg_grid(n, rate))
+        y = np.asarray(w(t))
+        if isinstance(w, WaveVStack):
+            edges = np.concatenate([np.searchsorted(t - w.shift if w.shift != 0 else t, b) for b, _ in w.wlist])
+        else:
+            edges = np.searchsorted(t, w.bounds)
+        awg[name + '.y'] = y
+        awg[name + '.edges'] = edges.astype(np.int64)
+        # Waveform.sample() itself on the same grid (waveform.py:190: np.arange(start, stop, 1 / rate))
+        if not isinstance(w, WaveVStack):
+            w.start, w.stop, w.sample_rate = 0.0, n / rate, rate
+            ys = np.asarray(w.sample())
+            assert ys.shape == y.shape and np.array_equal(ys, y), name
+    np.savez_compressed(os.path.join(gold, 'awg.npz'), **awg)
+
+
 def main():
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -142,6 +168,9 @@ def main():
         return
     if sys.argv[1:] == ['late']:           # regenerate this fixture only
         make_late(ref, gold)
+        return
+    if sys.argv[1:] == ['awg']:            # regenerate this fixture only
+        make_awg(ref, gold)
         return
 
     # ---- filter-design helpers of distortion.py (host-side, no sampling) ----------
@@ -342,6 +371,7 @@ def main():
     spec['zker'] = dist.zDistortKernel(1e-9, [(50e-9, 0.02), (400e-9, -0.01)])
     np.savez_compressed(os.path.join(gold, 'spectral.npz'), **spec)
     make_late(ref, gold)
+    make_awg(ref, gold)
     for f in sorted(os.listdir(gold)):
         print(f, os.path.getsize(os.path.join(gold, f)))
 

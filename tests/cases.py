@@ -620,3 +620,95 @@ LATE_CASES = {
     'exp': (_late_exp, LATE_GRID),
     'far_flat': (_late_far, ('linspace', 1.0e-3, 1.0e-3 + 180e-9, 600_000, False)),
 }
+
+
+# ---- AWG-rate grids (round 3): what Waveform.sample() is called with (1-5 GS/s, pulses of tens of
+# samples) -- the short-piece tier (wfk_short.hip).  Reference vectors: tests/golden/awg.npz.
+def _awg_readme(ns, rate):
+    """The README sequence stretched over 10 us: cosPulse + mixing(DRAGScaling): five-term pieces."""
+    pulse = ns.cosPulse(20e-9)
+    x = ns.zero()
+    for k in range(200):
+        I, Q = ns.mixing((0.3 + 0.003 * k) * pulse >> (25e-9 + 50e-9 * k), freq=-20e6 + 1e5 * k,
+                         phase=0.01 * k, DRAGScaling=0.2)
+        x = x + (I if k % 2 else Q)
+    return x
+
+
+def _awg_mixed(ns, rate):
+    """Gaussian pulses of several widths, plateaus (constant pieces), an exponential decay, a cubic
+    polynomial under a Gaussian, gaps between them."""
+    w = ns.zero()
+    t = 0.0
+    rng = np.random.default_rng(77)
+    for k in range(150):
+        width = float(rng.choice([12e-9, 20e-9, 32e-9, 41e-9]))
+        kind = k % 5
+        t += 0.75 * width + float(rng.choice([0.0, 0.0, 7e-9, 31e-9]))
+        if kind == 0:
+            p = ns.gaussian(width) * ns.cos(2 * pi * float(rng.uniform(20e6, 300e6)))
+        elif kind == 1:
+            I, Q = ns.mixing(ns.gaussian(width), freq=float(rng.uniform(-250e6, 250e6)),
+                             phase=float(rng.uniform(0, 6)), DRAGScaling=float(rng.uniform(1e-10, 4e-10)))
+            p = I - 0.5 * Q
+        elif kind == 2:
+            p = 0.4 * ns.square(1.5 * width) * ns.cos(2 * pi * float(rng.uniform(20e6, 120e6)))
+        elif kind == 3:
+            p = ns.square(1.5 * width) * (ns.exp(-1 / (0.7 * width)) >> (-0.75 * width))
+        else:
+            p = ns.gaussian(width) * ns.poly([0.2, 3e7, -2e15, 5e22])
+        w = w + float(rng.uniform(0.2, 1.0)) * (p >> t)
+        t += 0.75 * width
+    return w
+
+
+def _awg_cplx(ns, rate):
+    w = ns.zero()
+    for k in range(120):
+        I, Q = ns.mixing(0.6 * ns.gaussian(24e-9) >> (20e-9 + 40e-9 * k), freq=35e6 + 3e6 * k, phase=0.1 * k,
+                         DRAGScaling=2e-10)
+        w = w + (I + 1j * Q)
+    return w
+
+
+def _awg_vstack(ns, rate):
+    ws = []
+    for k in range(90):
+        I, _ = ns.mixing((0.2 + 0.005 * k) * ns.gaussian(30e-9) >> (30e-9 + 45e-9 * k), freq=-80e6 + 2e6 * k,
+                         phase=0.3 * k, DRAGScaling=1.5e-10)
+        ws.append(I)
+    return (ns.WaveVStack(ws) >> 3.3e-9) + 0.125
+
+
+def _awg_clip(ns, rate):
+    w = ns.zero()
+    for k in range(150):
+        w = w + ((0.1 + 0.01 * k) * ns.gaussian(20e-9) * ns.cos(2 * pi * 150e6) >> (16e-9 + 31e-9 * k))
+    w.min, w.max = -0.45, 0.7
+    return w
+
+
+def _awg_chan(c, duty30=False):
+    def build(ns, rate):
+        from waveforms_amd import workloads as wl
+        return wl.awg_channel(ns, c, 100000 if rate == 2e9 else 20000, rate, duty30)
+    return build
+
+
+def _awg_grid(n, rate):
+    return ('arange', 0.0, n / rate, 1.0 / rate)
+
+
+AWG_CASES = {   # name -> (build(ns, rate), rate, n)
+    'b2b_2g': (_awg_chan(0), 2e9, 100000),
+    'duty30_2g': (_awg_chan(1, True), 2e9, 100000),
+    'b2b_1g': (_awg_chan(2), 1e9, 20000),
+    'b2b_2p4g': (_awg_chan(3), 2.4e9, 20000),
+    'b2b_5g': (_awg_chan(4), 5e9, 20000),
+    'readme_1g': (_awg_readme, 1e9, 10000),
+    'readme_2p4g': (_awg_readme, 2.4e9, 24000),
+    'mixed_2g': (_awg_mixed, 2e9, 20000),
+    'cplx_2g': (_awg_cplx, 2e9, 10000),
+    'vstack_2g': (_awg_vstack, 2e9, 8400),
+    'clip_2g': (_awg_clip, 2e9, 10000),
+}

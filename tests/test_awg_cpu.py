@@ -1,0 +1,93 @@
+"""AWG-rate grids (1-5 GS/s: the regime of Waveform.sample, reference waveform.py:173-207) on the CPU:
+both oracles against vectors of the REAL reference (tests/golden/awg.npz, oracle/make_golden.py awg),
+and the host side of the short-piece tier: which plans take it, np.searchsorted indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+import waveforms_amd as wf
+from oracle import c_oracle, np_oracle
+from waveforms_amd import _engine, _flatten, workloads as wl
+
+AWG = golden_io.npz('awg.npz')
+
+
+def _case(name):
+    build, rate, n = cases.AWG_CASES[name]
+    return build(wf, rate), cases._awg_grid(n, rate)
+
+
+def _edges(plan_or_none, prog, g):
+    m0, m1 = prog.member_range(0)
+    return np.concatenate([c_oracle.member_index(prog, m, grid=g) for m in range(m0, m1)])
+
+
+@pytest.mark.parametrize('name', sorted(cases.AWG_CASES))
+def test_oracles_match_reference_on_awg_grids(name):
+    w, grid = _case(name)
+    want = AWG[name + '.y']
+    t = wl.make_grid(grid)
+    assert len(t) == len(want)
+    pk = max(1.0, float(np.abs(want).max()))
+    got = np_oracle.call(w, t)
+    assert got.dtype == want.dtype
+    assert np.max(np.abs(got - want)) <= 1e-14 * pk
+    prog = _flatten.flatten([w])
+    g = _flatten.grid_from_desc(grid)
+    assert np.array_equal(c_oracle.grid_values(g), t)       # bit-exact np.arange grid
+    cplx = want.dtype == np.complex128
+    assert np.max(np.abs(c_oracle.eval_grid(prog, g, cplx)[0] - want)) <= 1e-12 * pk
+    assert np.array_equal(_edges(None, prog, g), AWG[name + '.edges'])
+
+
+@pytest.mark.parametrize('name', sorted(cases.AWG_CASES))
+def test_short_tier_is_selected_and_indices_are_exact(name):
+    w, grid = _case(name)
+    prog = _flatten.flatten([w])
+    g = _flatten.grid_from_desc(grid)
+    plan = _engine.Plan(prog, grid=g)            # host-only plan when no GPU is visible
+    m0, m1 = prog.member_range(0)
+    idx = np.concatenate([plan.member_index(m) for m in range(m0, m1)])
+    assert np.array_equal(idx, AWG[name + '.edges'])
+    # GAUSSIAN / COS / LINEAR / EXP factors fuse at every AWG rate: nothing is left to device libm
+    assert plan.info.n_direct == 0 and plan.info.n_generic == 0, (plan.info.n_direct, plan.info.n_generic)
+    assert plan.kernel_name().startswith('wfk_sample_short<'), plan.kernel_name()
+
+
+@pytest.mark.parametrize('rate', [1e9, 2.4e9, 5e9])
+def test_gaussian_drag_pulses_fuse_at_awg_rates(rate):
+    # round-2 verdict: at 1-5 GS/s n_fused was 0 and the Gaussian went through device libm
+    chans = [wl.awg_channel(wf, c, 20000, rate, duty30=(c == 1)) for c in range(2)]
+    g = _flatten.grid_from_desc(wl.awg_grid(20000, rate))
+    plan = _engine.Plan(_flatten.flatten(chans), grid=g)
+    assert plan.info.n_direct == 0 and plan.info.n_generic == 0 and plan.info.n_fused > 0
+    assert plan.kernel_name(np.float32).startswith('wfk_sample_short<float,')
+
+
+def test_long_pieces_keep_the_lean_tier_and_env_overrides():
+    prog = _flatten.flatten([wl.c2_channel(wf)])
+    g = _flatten.grid_from_desc(wl.c2_grid(10**6))
+    assert _engine.Plan(prog, grid=g).kernel_name().startswith('wfk_sample_lean<')
+    prog2 = _flatten.flatten([wl.awg_channel(wf, 0, 20000, 2e9)])
+    g2 = _flatten.grid_from_desc(wl.awg_grid(20000, 2e9))
+    os.environ['WFK_SHORT'] = '0'
+    try:
+        assert not _engine.Plan(prog2, grid=g2).kernel_name().startswith('wfk_sample_short<')
+    finally:
+        del os.environ['WFK_SHORT']
+    # a piece the short tier cannot take (erf edge at 2 GS/s: generic) sends the plan to the standard tiers
+    w = wl.awg_channel(wf, 0, 20000, 2e9) + (wf.square(30e-9, edge=4e-9) >> 5e-6)
+    p3 = _engine.Plan(_flatten.flatten([w]), grid=g2)
+    assert not p3.kernel_name().startswith('wfk_sample_short<')
+
+
+def test_tile_program_equals_flattening_the_repeated_list():
+    chans = [wl.awg_channel(wf, c, 5000, 2e9) for c in range(3)]
+    g = _flatten.grid_from_desc(wl.awg_grid(5000, 2e9))
+    a = _flatten.tile_program(_flatten.flatten(chans, g), 4)
+    b = _flatten.flatten(chans * 4, g)
+    for k in a.arrays:
+        assert a.arrays[k].dtype == b.arrays[k].dtype and np.array_equal(a.arrays[k], b.arrays[k]), k

@@ -23,7 +23,7 @@ def _run(*argv, env_extra=None):
 
 def test_self_launch_two_ranks_c5_shape():
     line = _run('--gpus', '2', '--backend', 'gloo', '--plan-only', '--workload', 'c5',
-                '--channels', '3', '--points', '40000')
+                '--channels', '3', '--points', '400000')      # 4000 samples per pulse: the lean tier
     assert line['n_gpus'] == 2 and line['plan_only'] is True
     assert [r['channels'] for r in line['ranks']] == [[0, 3], [3, 6]]     # global channel index
     assert all(r['fused_terms'] > 0 for r in line['ranks'])

@@ -1,0 +1,143 @@
+"""Short-piece tier (wfk_short.hip) on AWG-rate grids against vectors of the REAL reference
+(tests/golden/awg.npz: pulse trains on 1-5 GS/s np.arange grids, full vectors), the C oracle, and the
+standard tiers evaluating the same plans."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+import waveforms_amd as wf
+from oracle import c_oracle
+from waveforms_amd import _engine, _flatten, workloads as wl
+from waveforms_amd._sampling import BatchSampler
+
+pytestmark = pytest.mark.gpu
+AWG = golden_io.npz('awg.npz')
+
+
+def _case(name):
+    build, rate, n = cases.AWG_CASES[name]
+    return build(wf, rate), cases._awg_grid(n, rate), rate, n
+
+
+@pytest.mark.parametrize('name', sorted(cases.AWG_CASES))
+def test_short_tier_matches_reference_vectors(name):
+    w, grid, rate, n = _case(name)
+    want = AWG[name + '.y']
+    cplx = np.iscomplexobj(want)
+    pk = max(1.0, float(np.abs(want).max()))
+    prog = _flatten.flatten([w])
+    plan = _engine.Plan(prog, grid=_flatten.grid_from_desc(grid))
+    assert plan.kernel_name().startswith('wfk_sample_short<') and plan.info.n_direct == 0
+    got = plan.run_host(np.complex128 if cplx else np.float64)[0]
+    assert np.max(np.abs(got - want)) <= 1e-9 * pk           # north_star: fp64 max abs err < 1e-9
+    assert np.max(np.abs(got - want)) <= 5e-11 * pk          # (measured: grid jitter x carrier, <= 2e-11)
+    g32 = plan.run_host(np.complex64 if cplx else np.float32)[0]
+    assert np.max(np.abs(g32 - want)) <= 2e-6 * pk           # float output of fp64 arithmetic: rounding only
+    # the drop-in call on the caller's own np.arange array (recognised as a grid)
+    t = wl.make_grid(grid)
+    y = np.asarray(w(t))
+    assert y.dtype == want.dtype and np.max(np.abs(y - want)) <= 5e-11 * pk
+
+
+@pytest.mark.parametrize('name', ['b2b_2g', 'duty30_2g', 'readme_2p4g', 'mixed_2g', 'clip_2g'])
+def test_sample_api_and_out_accumulate(name):
+    w, grid, rate, n = _case(name)
+    want = AWG[name + '.y']
+    pk = max(1.0, float(np.abs(want).max()))
+    w.start, w.stop, w.sample_rate = 0.0, n / rate, rate
+    y = w.sample()                                            # reference waveform.py:173-207
+    assert y.shape == want.shape and np.max(np.abs(y - want)) <= 5e-11 * pk
+    t = wl.make_grid(grid)
+    out = np.full(len(t), 0.25)
+    r = w(t, out=out, accumulate=True)                        # out += samples (waveform.py:548-563)
+    assert r is out and np.max(np.abs(out - 0.25 - want)) <= 5e-11 * pk
+    # chunked: np.linspace(start, stop, size, endpoint=False) per chunk (waveform.py:209-257) -- other
+    # grid values than np.arange's, so a sample that sits ON a bound may change sides: compare with the
+    # oracle on the very same chunk grids
+    chunks = list(w.sample(chunk_size=3000))
+    prog = _flatten.flatten([w])
+    a, length = float(w.start), 3000 / rate                   # the chunk starts accumulate (waveform.py:224-257)
+    for ch in chunks:
+        b = float(w.stop) if a + length > w.stop else a + length
+        g = _flatten.grid_linspace(a, b, len(ch), endpoint=False)
+        assert np.max(np.abs(ch - c_oracle.eval_grid(prog, g)[0])) <= 5e-11 * pk
+        a = b
+    assert sum(len(c) for c in chunks) == n
+
+
+def test_accumulate_launch_and_channel_batches():
+    chans = [wl.awg_channel(wf, c, 30000, 2e9, duty30=(c % 2 == 1)) for c in range(5)]
+    grid = wl.awg_grid(30000, 2e9)
+    bs = BatchSampler(chans, grid)
+    assert bs.plan.kernel_name().startswith('wfk_sample_short<')
+    ref = c_oracle.eval_grid(bs.prog, bs.grid)
+    got = bs.to_host(np.float64)
+    assert np.max(np.abs(got - ref)) <= 5e-11
+    # device-side accumulate into a padded buffer: rows keep their stride, the padding its poison
+    stride = 30000 + 24
+    buf = _engine.DeviceBuffer(5 * stride * 8)
+    init = np.full((5, stride), 3.0)
+    buf.upload(init)
+    bs.launch(buf.ptr, stride, np.float64, accumulate=True)
+    _engine.sync()
+    back = buf.download((5, stride), np.float64)
+    assert np.max(np.abs(back[:, :30000] - 3.0 - ref)) <= 5e-11
+    assert np.array_equal(back[:, 30000:], init[:, 30000:])
+    buf.close()
+    bs.close()
+
+
+@pytest.mark.parametrize('name', ['b2b_2g', 'mixed_2g', 'cplx_2g', 'vstack_2g', 'clip_2g', 'readme_1g'])
+def test_short_and_standard_tiers_agree(name):
+    w, grid, rate, n = _case(name)
+    want = AWG[name + '.y']
+    cplx = np.iscomplexobj(want)
+    prog = _flatten.flatten([w])
+    g = _flatten.grid_from_desc(grid)
+    a = _engine.Plan(prog, grid=g)
+    os.environ['WFK_SHORT'] = '0'
+    try:
+        b = _engine.Plan(prog, grid=g)
+    finally:
+        del os.environ['WFK_SHORT']
+    assert a.kernel_name().startswith('wfk_sample_short<') and not b.kernel_name().startswith('wfk_sample_short<')
+    dt = np.complex128 if cplx else np.float64
+    ya, yb = a.run_host(dt)[0], b.run_host(dt)[0]
+    pk = max(1.0, float(np.abs(want).max()))
+    assert np.max(np.abs(ya - yb)) <= 5e-11 * pk
+    assert np.max(np.abs(yb - want)) <= 1e-9 * pk
+
+
+def test_ragged_ends_offsets_and_tiny_grids():
+    # grids that end inside a pulse / inside a gap, units with one slot, n below one row, vstack offset
+    w = wl.awg_channel(wf, 7, 6000, 2e9, duty30=True)
+    for n in (1, 2, 15, 16, 17, 63, 64, 65, 1007, 1008, 1009, 1024, 2999, 3001):
+        g = _flatten.grid_arange(0.0, n / 2e9, 1 / 2e9)
+        prog = _flatten.flatten([w])
+        plan = _engine.Plan(prog, grid=g)
+        got = plan.run_host(np.float64)[0]
+        ref = c_oracle.eval_grid(prog, g)[0]
+        assert got.shape == ref.shape and np.max(np.abs(got - ref), initial=0.0) <= 5e-11, n
+    st = (wf.WaveVStack([wl.awg_channel(wf, c, 6000, 2e9) for c in range(3)]) >> 1.7e-9) - 0.4
+    g = _flatten.grid_arange(-40e-9, 2.9e-6, 1 / 2.4e9)
+    prog = _flatten.flatten([st])
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.kernel_name().startswith('wfk_sample_short<')
+    assert np.max(np.abs(plan.run_host(np.float64)[0] - c_oracle.eval_grid(prog, g)[0])) <= 5e-11
+
+
+def test_long_zero_stretches_are_pure_fill_units():
+    # 100 us of silence between two bursts: zero stretches far longer than a unit
+    a = wl.awg_channel(wf, 3, 4000, 2e9)
+    w = a + (a >> 60e-6) + 0.0
+    g = _flatten.grid_arange(0.0, 70e-6, 1 / 2e9)
+    prog = _flatten.flatten([w])
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.kernel_name().startswith('wfk_sample_short<')
+    got = plan.run_host(np.float64)[0]
+    ref = c_oracle.eval_grid(prog, g)[0]
+    assert np.max(np.abs(got - ref)) <= 5e-11
+    assert np.count_nonzero(got[10000:110000]) == 0

@@ -127,6 +127,19 @@ def drive(n_scripts):
             prog = _flatten.flatten([c >> gd[1] for c in fine[k:k + 3]])
             assert compile_(prog, grid=g) == 0, err.value
             done += 1
+    # AWG-rate grids: the short-piece tier's unit / slot / record tables (tests/cases.py AWG_CASES and
+    # random pulse trains at 1-5 GS/s, ragged lengths)
+    for name, (build, rate, n) in cases.AWG_CASES.items():
+        for nn in (n, n // 3 + 1, 17):
+            assert compile_(_flatten.flatten([build(wf, rate)]), grid=_flatten.grid_from_desc(cases._awg_grid(nn, rate))) == 0, (name, err.value)
+            done += 1
+    from waveforms_amd import workloads as wl
+    for seed in range(12):
+        rate = float(rng.choice([1e9, 2e9, 2.4e9, 3.2e9, 5e9]))
+        chans = [wl.awg_channel(wf, 100 + seed * 3 + c, 9000, rate, duty30=bool(c % 2)) for c in range(3)]
+        g = _flatten.grid_arange(float(rng.uniform(-50e-9, 50e-9)), 9000 / rate, 1 / rate)
+        assert compile_(_flatten.flatten(chans), grid=g) == 0, err.value
+        done += 1
     # multi-channel programs (chunk tables across channels) and the edge grids
     chans = [cases.random_channel(wf, rng)[0] for _ in range(9)]
     prog = _flatten.flatten(chans)

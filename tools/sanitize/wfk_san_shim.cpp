@@ -21,8 +21,53 @@ extern "C" int wfk_san_compile(const wfk_program* prog, const wfk_grid* grid, co
   double d = 0.0;
   if (rc == 0) {
     for (const DevChannel& c : H.channels) d += c.offset + c.piece_begin + c.piece_end;
+    if (H.shortp) {
+      // short tier (WFK_SH_*): every unit, slot and record reference must stay inside its table, the
+      // units of a channel must tile [0, n) in order, the slots of a unit its sample range
+      int64_t next_j = 0;
+      int32_t ch = -1;
+      for (const ShortUnit& u : H.s_units) {
+        if (u.ch != ch) {
+          if (ch >= 0 && next_j != H.n) return -1100;
+          if (u.ch != ch + 1) return -1101;
+          ch = u.ch; next_j = 0;
+        }
+        if (u.j0 != next_j || u.n_samples <= 0 || u.n_samples > WFK_SH_LCAP) return -1102;
+        next_j += u.n_samples;
+        if (u.n_slots < 0 || u.n_slots > 64 || u.slot0 < 0 || (size_t)u.slot0 + (size_t)u.n_slots > H.s_slots.size()) return -1103;
+        int32_t covered = 0, prev_end = 0;
+        for (int32_t k = 0; k < u.n_slots; ++k) {
+          const uint32_t w = H.s_slots[(size_t)u.slot0 + k];
+          if (!(w >> 31)) return -1104;
+          const int32_t o = (int32_t)((w >> 16) & 0x3ff), len = (int32_t)((w >> 26) & 15) + 1;
+          if (o < prev_end || o + len > u.n_samples || len > WFK_SH_R) return -1105;
+          prev_end = o + len; covered += len;
+          int64_t at = 2 * (u.rec0 + (int64_t)(w & 0xffff));
+          for (;;) {                                   // the record's ops, up to the one flagged last
+            if (at < 0 || at + WFK_SH_OP1 > (int64_t)H.params.size()) return -1106;
+            uint64_t word;
+            __builtin_memcpy(&word, &H.params[(size_t)at], sizeof word);
+            const int deg = (int)(word & 3);
+            const int64_t ref = (int64_t)(word >> 32);
+            if (ref > u.j0 + o || u.j0 + o - ref >= WFK_SH_SUB) return -1107;
+            const int sz = deg > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
+            if (at + sz > (int64_t)H.params.size()) return -1108;
+            for (int i = 1; i < sz; ++i) d += H.params[(size_t)at + i] == H.params[(size_t)at + i] ? 1e-9 : 0.0;
+            at += sz;
+            if (word & WFK_SH_LAST) break;
+          }
+        }
+        if (((u.gaps & 1) == 0) != (covered == u.n_samples) && u.n_slots > 0) return -1109;
+        d += (double)u.j0 + u.n_samples + u.rec0;
+      }
+      if (H.n_channels > 0 && H.n > 0 && (ch != H.n_channels - 1 || next_j != H.n)) return -1110;
+    }
     for (const DevPiece& p : H.pieces) {
       d += (double)p.start + (double)p.stop + p.n_blk;
+      if (p.flags & WFK_PF_SHORT) {
+        if (p.par_off < 0 || p.par_off + (int64_t)p.n_blk * p.first_len > (int64_t)H.params.size()) return -1111;
+        continue;
+      }
       // every block of the piece must lie inside params[] and its header must be consistent
       int64_t off = p.par_off;
       int32_t len = p.first_len;

@@ -25,12 +25,21 @@ class ShardedSampler:
     `make_channel(c)` builds channel c (a Waveform / WaveVStack); only the local block
     is ever built, flattened and uploaded."""
 
-    def __init__(self, n_channels, make_channel, grid, rank, world, plan_only=False):
+    def __init__(self, n_channels, make_channel, grid, rank, world, plan_only=False, tile=1):
+        """`tile`: the job's rows are `tile` copies of n_channels / tile distinct channels (synthetic
+        batches); a rank then builds only the distinct channels of its block."""
         from ._sampling import BatchSampler
         self.rank, self.world, self.n_channels = rank, world, n_channels
         self.start, self.stop = channel_block(n_channels, rank, world)
-        self.local = BatchSampler([make_channel(c) for c in range(self.start, self.stop)],
-                                  grid)
+        if tile > 1:
+            if (self.stop - self.start) % tile:
+                raise ValueError('rows per rank must be a multiple of tile')
+            distinct = (self.stop - self.start) // tile
+            first = self.start // tile
+            self.local = BatchSampler([make_channel(c) for c in range(first, first + distinct)], grid, tile=tile)
+        else:
+            self.local = BatchSampler([make_channel(c) for c in range(self.start, self.stop)],
+                                      grid)
         self.n = self.local.n
 
     def launch_torch(self, out, accumulate=False):

@@ -69,6 +69,8 @@ def lib():
         l.wfk_plan_channel_is_complex.argtypes = [VP, I32]
         l.wfk_plan_kernel_name.argtypes = [VP, C.c_int]
         l.wfk_plan_kernel_name.restype = C.c_char_p
+        l.wfk_plan_table_bytes.argtypes = [VP]
+        l.wfk_plan_table_bytes.restype = C.c_int64
         l.wfk_plan_launch.argtypes = [VP, VP, I64, C.c_int, C.c_uint32, VP]
         l.wfk_plan_run_host.argtypes = [VP, VP, I64, C.c_int]
         l.wfk_fir_plan_create.argtypes = [VP, I32, I64, I32, C.c_int, P(VP)]
@@ -166,6 +168,10 @@ class Plan:
     def kernel_name(self, dtype=np.float64) -> str:
         """Symbol of the kernel a launch with this output dtype runs (as rocprofv3 shows it)."""
         return lib().wfk_plan_kernel_name(self._h, _KIND_OF[np.dtype(dtype)]).decode()
+
+    def table_bytes(self) -> int:
+        """Bytes of device tables a launch reads next to the output stream."""
+        return int(lib().wfk_plan_table_bytes(self._h))
 
     def launch(self, out_ptr: int, ch_stride: int, kind: int, accumulate=False,
                stream: int = 0):

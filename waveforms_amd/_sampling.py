@@ -215,11 +215,14 @@ class BatchSampler:
         arr = bs.to_host(np.float32)                # or: run + copy back
     """
 
-    def __init__(self, channels, grid, function_lib=None):
+    def __init__(self, channels, grid, function_lib=None, tile=1):
+        """`tile` > 1 repeats the channel list that many times (rows c, c + len(channels), ... are copies:
+        every copy owns its rows of every device table) -- synthetic batches of thousands of rows without
+        building thousands of expression trees."""
         if not isinstance(grid, _flatten.wfk_grid):
             grid = _flatten.grid_from_desc(grid)
         self.grid = grid
-        self.prog = _flatten.flatten(list(channels), grid, function_lib)
+        self.prog = _flatten.tile_program(_flatten.flatten(list(channels), grid, function_lib), tile)
         self.plan = _engine.Plan(self.prog, grid=grid)
         self.n = self.plan.n
         self.n_channels = self.plan.n_channels

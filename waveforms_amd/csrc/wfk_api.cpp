@@ -295,6 +295,15 @@ int wfk_plan_channel_is_complex(const wfk_plan* p, int32_t channel) {
   return p->h.channel_complex[channel];
 }
 
+int64_t wfk_plan_table_bytes(const wfk_plan* p) {
+  if (!p) return fail(WFK_EINVAL, "null plan");
+  const HostPlan& h = p->h;
+  size_t b = h.channels.size() * sizeof(DevChannel) + h.params.size() * sizeof(double) + h.pool.size() * sizeof(double);
+  if (h.shortp) b += h.s_units.size() * sizeof(ShortUnit) + h.s_slots.size() * sizeof(uint32_t);
+  else b += h.pieces.size() * sizeof(DevPiece) + (h.chunk_first.size() + h.lean_chunk_first.size()) * sizeof(int32_t);
+  return (int64_t)b;
+}
+
 const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   if (!p || out_kind < 0 || out_kind > 3) return "";
   static thread_local std::string name;
