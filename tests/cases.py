@@ -392,6 +392,34 @@ def random_channel(wf, rng):
     return ch, grid
 
 
+def random_awg_channel(wf, rng):
+    """A pulse train on an AWG-rate grid (1-5 GS/s np.arange, the regime of Waveform.sample): 3-60 random
+    pulses of 8-60 ns (random_pulse: every fusable shape, erf edges, DRAG primitives, mollifiers, ...)
+    placed one after the other with random gaps, as a sum, a WaveVStack, clipped or complex."""
+    rate = float(rng.choice([1e9, 1.2e9, 2e9, 2.4e9, 3.2e9, 5e9]))
+    scale = float(rng.uniform(4e-9, 12e-9))
+    n = int(rng.integers(3, 60))
+    pulses, t = [], 0.0
+    for _ in range(n):
+        p = random_pulse(wf, rng, scale)
+        t += scale * float(rng.uniform(2.0, 14.0))
+        pulses.append(p >> t)
+    mode = rng.random()
+    if mode < 0.3:
+        ch = wf.WaveVStack(pulses)
+        if rng.random() < 0.5:
+            ch = (ch + rng.uniform(-0.5, 0.5)) >> (scale * rng.uniform(-1, 1))
+    else:
+        ch = pulses[0]
+        for k, p in enumerate(pulses[1:]):
+            ch = ch + (p * (1j if (mode > 0.9 and k % 3 == 0) else 1))
+        if 0.3 <= mode < 0.45:
+            ch = wf.cut(ch, min=-0.4, max=0.6)
+    a = -scale * float(rng.uniform(0, 10))
+    b = t + scale * float(rng.uniform(0, 12))
+    return ch, ('arange', a, b, 1.0 / rate)
+
+
 FUZZ_GOLD = 120      # seeds evaluated by the real reference (oracle/make_golden.py -> fuzz.npz)
 
 

@@ -78,10 +78,15 @@ def test_long_pieces_keep_the_lean_tier_and_env_overrides():
         assert not _engine.Plan(prog2, grid=g2).kernel_name().startswith('wfk_sample_short<')
     finally:
         del os.environ['WFK_SHORT']
-    # a piece the short tier cannot take (erf edge at 2 GS/s: generic) sends the plan to the standard tiers
+    # pieces the short tier cannot take (erf edges at 2 GS/s: generic terms) go to the general kernel in a
+    # second launch; the rest of the plan keeps the short tier
     w = wl.awg_channel(wf, 0, 20000, 2e9) + (wf.square(30e-9, edge=4e-9) >> 5e-6)
     p3 = _engine.Plan(_flatten.flatten([w]), grid=g2)
-    assert not p3.kernel_name().startswith('wfk_sample_short<')
+    assert p3.kernel_name().startswith('wfk_sample_short<') and ' + wfk_sample<' in p3.kernel_name()
+    assert p3.info.n_generic > 0 and p3.info.n_fused > 0
+    # ... and a plan with nothing for it falls back whole
+    p4 = _engine.Plan(_flatten.flatten([(wf.square(30e-9, edge=14e-9) >> 1e-6) * wf.sinc(3e7)]), grid=g2)
+    assert not p4.kernel_name().startswith('wfk_sample_short<')
 
 
 def test_tile_program_equals_flattening_the_repeated_list():

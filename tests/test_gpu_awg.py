@@ -141,3 +141,33 @@ def test_long_zero_stretches_are_pure_fill_units():
     ref = c_oracle.eval_grid(prog, g)[0]
     assert np.max(np.abs(got - ref)) <= 5e-11
     assert np.count_nonzero(got[10000:110000]) == 0
+
+
+@pytest.mark.parametrize('seed', range(80))
+def test_random_awg_script(seed):
+    """Random pulse trains on 1-5 GS/s grids (tests/cases.py random_awg_channel: every shape of the
+    general fuzz, sums / vstacks / clips / complex amplitudes): short tier alone or mixed with the
+    general kernel for the pieces it cannot take (erf edges, mollifiers, unfusable DRAG primitives)."""
+    rng = np.random.default_rng(10_000 + seed)
+    ch, grid = cases.random_awg_channel(wf, rng)
+    prog = _flatten.flatten([ch])
+    g = _flatten.grid_from_desc(grid)
+    cplx = bool(prog.complex_amp)
+    ora = c_oracle.eval_grid(prog, g, cplx)[0]
+    pk = max(1.0, float(np.max(np.abs(ora), initial=0.0)))
+    plan = _engine.Plan(prog, grid=g)
+    got = plan.run_host(np.complex128 if cplx else np.float64)[0]
+    assert np.all(np.isfinite(got)) or not np.all(np.isfinite(ora))
+    assert np.max(np.abs(got - ora), initial=0.0) <= 1e-9 * pk, (seed, plan.kernel_name())
+    got32 = plan.run_host(np.complex64 if cplx else np.float32)[0]
+    assert np.max(np.abs(got32 - ora), initial=0.0) <= 5e-5 * pk, seed
+    # accumulate through both launches of a mixed plan: every sample is still written exactly once
+    if seed % 5 == 0 and not cplx:
+        n = plan.n
+        buf = _engine.DeviceBuffer(max(n, 1) * 8)
+        buf.upload(np.full(max(n, 1), 2.0))
+        plan.launch(buf.ptr, n, _engine.OUT_F64, accumulate=True)
+        _engine.sync()
+        back = buf.download((max(n, 1), ), np.float64)[:n]
+        assert np.max(np.abs(back - 2.0 - ora), initial=0.0) <= 1e-9 * pk, seed
+        buf.close()

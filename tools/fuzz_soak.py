@@ -1,5 +1,6 @@
 """Long differential fuzz (not part of the suite): random scripts x grids, HIP vs the C oracle.
-usage: python tools/fuzz_soak.py [first_seed] [count]   -> prints failing seeds"""
+usage: python tools/fuzz_soak.py [first_seed] [count] [awg]   -> prints failing seeds
+(awg: pulse trains on 1-5 GS/s grids, tests/cases.py random_awg_channel; also counts the tiers taken)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -11,16 +12,29 @@ from waveforms_amd import _engine, _flatten
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+awg = len(sys.argv) > 3 and sys.argv[3] == 'awg'
+tiers = {}
 bad, t0 = [], time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(10_000 + seed)
     try:
-        ch, grid = cases.random_channel(wf, rng)
+        ch, grid = cases.random_awg_channel(wf, rng) if awg else cases.random_channel(wf, rng)
         prog = _flatten.flatten([ch])
         g = _flatten.grid_from_desc(grid)
         ora = c_oracle.eval_grid(prog, g)[0]
         pk = max(1.0, float(np.max(np.abs(ora)))) if ora.size else 1.0
         plan = _engine.Plan(prog, grid=g)
+        kn = plan.kernel_name().split('<')[0]
+        tiers[kn] = tiers.get(kn, 0) + 1
+        cplx = bool(plan.prog.complex_amp) and awg
+        if cplx:
+            ora = c_oracle.eval_grid(prog, g, True)[0]
+            got = plan.run_host(np.complex128)[0]
+            e = float(np.max(np.abs(got - ora), initial=0.0))
+            if not e <= 1e-9 * max(1.0, float(np.max(np.abs(ora), initial=0.0))):
+                bad.append((seed, 'complex', e))
+                print('FAIL', bad[-1], flush=True)
+            continue
         got = plan.run_host(np.float64)[0]
         e64 = float(np.max(np.abs(got - ora), initial=0.0))
         got32 = plan.run_host(np.float32)[0].astype(np.float64)
@@ -38,4 +52,4 @@ for seed in range(first, first + count):
         print('ERROR', bad[-1], flush=True)
     if (seed - first) % 250 == 249:
         print(f'{seed - first + 1} scripts, {len(bad)} failures, {time.time() - t0:.0f} s', flush=True)
-print('done', count, 'scripts;', len(bad), 'failures', bad[:10])
+print('done', count, 'scripts;', len(bad), 'failures', bad[:10], 'tiers', tiers)

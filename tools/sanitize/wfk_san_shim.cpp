@@ -22,17 +22,31 @@ extern "C" int wfk_san_compile(const wfk_program* prog, const wfk_grid* grid, co
   if (rc == 0) {
     for (const DevChannel& c : H.channels) d += c.offset + c.piece_begin + c.piece_end;
     if (H.shortp) {
-      // short tier (WFK_SH_*): every unit, slot and record reference must stay inside its table, the
-      // units of a channel must tile [0, n) in order, the slots of a unit its sample range
+      // short tier (WFK_SH_*): every unit, slot and record reference must stay inside its table; the
+      // units of a channel, together with the pieces left to the general kernel (mixed plans), must
+      // tile [0, n) in order; the slots of a unit its sample range
       int64_t next_j = 0;
-      int32_t ch = -1;
+      int32_t ch = -1, fp = 0;      // fp: next piece of the channel to look at for a foreign stretch
+      auto skip_foreign = [&](int32_t c, int64_t upto) -> bool {   // foreign pieces starting at next_j, up to `upto`
+        for (; fp < H.channels[c].piece_end; ++fp) {
+          const DevPiece& p = H.pieces[fp];
+          if (p.stop <= next_j) continue;
+          if (p.n_blk != 0 && !(p.flags & WFK_PF_SHORT) && p.start == next_j && p.stop <= upto) { next_j = p.stop; continue; }
+          break;
+        }
+        return next_j == upto;
+      };
       for (const ShortUnit& u : H.s_units) {
         if (u.ch != ch) {
-          if (ch >= 0 && next_j != H.n) return -1100;
-          if (u.ch != ch + 1) return -1101;
-          ch = u.ch; next_j = 0;
+          if (ch >= 0 && !skip_foreign(ch, H.n)) return -1100;
+          for (int32_t c = ch + 1; c < u.ch; ++c) {     // channels made of foreign pieces only
+            next_j = 0; fp = H.channels[c].piece_begin;
+            if (!skip_foreign(c, H.n)) return -1101;
+          }
+          ch = u.ch; next_j = 0; fp = H.channels[ch].piece_begin;
         }
-        if (u.j0 != next_j || u.n_samples <= 0 || u.n_samples > WFK_SH_LCAP) return -1102;
+        if (!skip_foreign(ch, u.j0)) return -1102;
+        if (u.n_samples <= 0 || u.n_samples > WFK_SH_LCAP) return -1102;
         next_j += u.n_samples;
         if (u.n_slots < 0 || u.n_slots > 64 || u.slot0 < 0 || (size_t)u.slot0 + (size_t)u.n_slots > H.s_slots.size()) return -1103;
         int32_t covered = 0, prev_end = 0;
@@ -60,7 +74,13 @@ extern "C" int wfk_san_compile(const wfk_program* prog, const wfk_grid* grid, co
         if (((u.gaps & 1) == 0) != (covered == u.n_samples) && u.n_slots > 0) return -1109;
         d += (double)u.j0 + u.n_samples + u.rec0;
       }
-      if (H.n_channels > 0 && H.n > 0 && (ch != H.n_channels - 1 || next_j != H.n)) return -1110;
+      if (H.n > 0) {
+        if (ch >= 0 && !skip_foreign(ch, H.n)) return -1110;
+        for (int32_t c = ch + 1; c < H.n_channels; ++c) {
+          next_j = 0; fp = H.channels[c].piece_begin;
+          if (!skip_foreign(c, H.n)) return -1110;
+        }
+      }
     }
     for (const DevPiece& p : H.pieces) {
       d += (double)p.start + (double)p.stop + p.n_blk;

@@ -152,7 +152,7 @@ static int plan_upload(wfk_plan* p, const double* tlist) {
   }
   const HostPlan& h = p->h;
   const size_t b_ch = h.channels.size() * sizeof(DevChannel);
-  const size_t b_pc = h.shortp ? 0 : h.pieces.size() * sizeof(DevPiece);   // (the short kernel walks units, not pieces)
+  const size_t b_pc = h.shortp && !h.mixed ? 0 : h.pieces.size() * sizeof(DevPiece);   // (the short kernel walks units, not pieces)
   const size_t b_pa = h.params.size() * sizeof(double);
   const size_t b_po = h.pool.size() * sizeof(double);
   const size_t b_cf = h.chunk_first.size() * sizeof(int32_t);
@@ -300,7 +300,7 @@ int64_t wfk_plan_table_bytes(const wfk_plan* p) {
   const HostPlan& h = p->h;
   size_t b = h.channels.size() * sizeof(DevChannel) + h.params.size() * sizeof(double) + h.pool.size() * sizeof(double);
   if (h.shortp) b += h.s_units.size() * sizeof(ShortUnit) + h.s_slots.size() * sizeof(uint32_t);
-  else b += h.pieces.size() * sizeof(DevPiece) + (h.chunk_first.size() + h.lean_chunk_first.size()) * sizeof(int32_t);
+  if (!h.shortp || h.mixed) b += h.pieces.size() * sizeof(DevPiece) + (h.chunk_first.size() + h.lean_chunk_first.size()) * sizeof(int32_t);
   return (int64_t)b;
 }
 
@@ -312,6 +312,9 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   const HostPlan& h = p->h;
   if (h.shortp) {
     name = std::string("wfk_sample_short<") + T + "," + cplx + ",false," + std::to_string(WFK_SH_R) + ">";
+    if (h.mixed)      // pieces the short tier cannot take: a second launch of the general kernel
+      name += std::string(" + wfk_sample<") + T + "," + cplx + ",false," + (h.n_direct > 0 || h.n_generic > 0 ? "true" : "false") +
+              "," + (h.n_direct > 0 ? "true" : "false") + "," + std::to_string(h.ns) + ">";
     return name.c_str();
   }
   const std::string lean_name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +
@@ -352,7 +355,8 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
     if (hip_stream) p->async_launch = true;
     std::string serr;
     const int src = wfk_launch_short(sa, out_kind, hip_stream, serr);
-    return src ? fail(src, serr) : WFK_OK;
+    if (src) return fail(src, serr);
+    if (!p->h.mixed) return WFK_OK;
   }
   KArgs a{};
   a.channels = p->d_channels;
@@ -389,7 +393,9 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
   if (hip_stream) p->async_launch = true;
   std::string err;
   int rc = WFK_OK;
-  if (p->h.mixed) {
+  if (p->h.shortp) {
+    a.mixed = 1;      // the short launch above wrote its pieces and the zero stretches; now the rest
+  } else if (p->h.mixed) {
     // lean and zero pieces first (own chunking: one wave per workgroup) ...
     KArgs l = a;
     l.mixed = 1;

@@ -143,6 +143,14 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   // (generic terms, erf edges, corrected carriers) sends the whole plan back to the standard tiers.
   int rc = compile_impl(P, grid, tlist, n_tlist, H, err, true, 64, 0, -1);
   if (rc == WFK_RETRY_STD) rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
+  else if (rc == WFK_OK && H.shortp && H.short_needs_corr) {
+    // far from t = 0 fast carriers need the per-sample rounding correction, which only the lean kernel
+    // has: where the standard tiers can run the plan lean (pieces long enough for its recurrences) they
+    // win; otherwise the short tier keeps what it can take and libm serves those carriers either way
+    HostPlan S;
+    std::string e2;
+    if (compile_impl(P, grid, tlist, n_tlist, S, e2, true) == WFK_OK && (S.lean || S.mixed)) H = std::move(S);
+  }
   if (rc == WFK_OK && !H.shortp && H.n_corr > 0 && !H.lean && !H.mixed) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
   return rc;
 }
@@ -167,7 +175,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.tile = WFK_WG * H.ns;
   int NS = H.ns;
   double dstride = grid ? (double)lane_stride * grid->step : 0.0;  // time between a lane's samples
-  bool shortm = false;          // contiguous-lane geometry of the short tier (decided after the piece search)
+  bool shortm = false;          // the plan is compiled for the short tier (decided after the piece search)
+  bool cur_short = false;       // ... and the piece being built uses its contiguous-lane geometry
   const int lean_par_cap = ns_override > 0 ? WFK_CHAIN_PAR : WFK_LEAN_PAR;
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
@@ -266,10 +275,15 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (const char* m = std::getenv("WFK_SHORT_MAXLEN")) maxlen = std::atoll(m);
     if (mode != 0 && live > 0 && (mode == 1 || live_samples < maxlen * live)) {
       shortm = true;
-      NS = WFK_SH_R;
-      dstride = grid->step;
     }
   }
+  // geometry of the piece being built: lanes one sample apart (short tier) or `lane_stride` apart
+  auto set_geom = [&](bool sh) {
+    cur_short = sh;
+    NS = sh ? WFK_SH_R : H.ns;
+    dstride = grid ? (sh ? 1.0 : (double)lane_stride) * grid->step : 0.0;
+  };
+  set_geom(shortm);
 
   // phasor table (C[k], S[k]) = (cos, sin)(k * dphase), k < NS, shared per block
   auto table_for = [&](BlockBuilder& B, double dphase) -> int {
@@ -499,7 +513,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const char* noexp_env = std::getenv("WFK_DISABLE_EXPFUSE");
   const bool expfuse = !(noexp_env && noexp_env[0] == '1');
   const char* noerf_env = std::getenv("WFK_DISABLE_ERFMUL");
-  const bool erfmod = can_fuse && ns_override == 0 && !shortm && !(noerf_env && noerf_env[0] == '1');
+  const bool erfmod_base = can_fuse && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
 
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
                        int64_t s1, int32_t skip = -1) -> bool {   // skip: a factor handled by the caller
@@ -657,6 +671,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     bool any_corr = false;
     for (const Car& q : cars)
       if (!rate_safe((double)q.W, s0, s1)) {
+        if (shortm) H.short_needs_corr = true;
         if (!corr_safe((double)q.W, s0, s1)) return false;
         any_corr = true;
       }
@@ -943,7 +958,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
 
   // ---- merge members into disjoint device pieces -----------------------------
   bool lean_ok = can_fuse;
-  int64_t n_lean_pieces = 0;
+  int64_t n_lean_pieces = 0, n_short_pieces = 0, n_foreign_pieces = 0, n_short_samples = 0, n_foreign_samples = 0;
   H.channels.resize(P->n_channels);
   H.channel_complex.assign(P->n_channels, 0);
   for (int32_t c = 0; c < P->n_channels; ++c) {
@@ -1031,7 +1046,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         bool mod_on = false;
         double mod_sigma = 0, mod_shift = 0;
         auto erf_factor_of = [&](int32_t k, double& sg_out, double& sh_out) -> int32_t {
-          if (!erfmod) return -1;
+          if (!erfmod_base || cur_short) return -1;
           int32_t at = -1;
           for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
             if (P->fc_type[f] == WFK_ERF) {
@@ -1113,7 +1128,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // pulse), the envelope is factored out: the ops run without envelope and one closing
         // pseudo-op multiplies the accumulators by it -- 2 instead of 5 FMAs per sample and tone.
         // (From four carriers on: the extra op costs a pair of pieces what it saves them.)
-        if (groups.size() >= 4 && !mod_on && !shortm) {
+        if (groups.size() >= 4 && !mod_on && !cur_short) {
           bool shared = true, e32 = true;
           for (const FceGroup& g : groups) {
             shared = shared && g.has_env && !g.has_exp && g.sigma == groups[0].sigma && g.sg == groups[0].sg;
@@ -1126,14 +1141,27 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             groups.push_back(E);
           }
         }
-        if (shortm) {
-          // compact records of the short tier (WFK_SH_*): one per <= WFK_SH_SUB samples of the piece
-          if (!generic.empty() || groups.empty() || groups.size() > 255) return WFK_RETRY_STD;
-          for (const FceGroup& G : groups)
-            if (G.corr || G.erfmul || G.envmul) return WFK_RETRY_STD;
+        if (cur_short) {
+          // compact records of the short tier (WFK_SH_*): one per <= WFK_SH_SUB samples of the piece.  A
+          // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
+          // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
+          bool ok = generic.empty() && !groups.empty() && groups.size() <= 255;
+          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.erfmul || G.envmul);
+          if (!ok) {
+            H.params.resize(snap.params); H.pool.resize(snap.pool);
+            H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
+            sampled_at = snap.sampled;
+            D = D0;
+            set_geom(false);
+            ++n_foreign_pieces;
+            n_foreign_samples += s1 - s0;
+            continue;
+          }
           const int32_t first = emit_short_piece(groups, C.tshift, s0, s1, D.n_blk);
           D.first_len = first;
           D.flags |= WFK_PF_SHORT;
+          ++n_short_pieces;
+          n_short_samples += s1 - s0;
           break;
         }
         piece_lean = generic.empty() && !groups.empty() && groups.size() <= WFK_LEAN_OPS;
@@ -1176,7 +1204,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           piece_corr_ok = false;
           continue;
         }
-        if (piece_lean) {
+        if (piece_lean && !shortm) {   // (a short plan has no lean launch: its other pieces all go to the general kernel)
           D.flags |= WFK_PF_LEAN;
           ++n_lean_pieces;
           H.lean_ops = std::max<int32_t>(H.lean_ops, piece_units);
@@ -1187,6 +1215,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         break;
       }
       piece_corr_ok = true;
+      if (shortm) set_geom(true);
       // fuse adjacent zero pieces
       if (D.n_blk == 0 && (int32_t)H.pieces.size() > C.piece_begin &&
           H.pieces.back().n_blk == 0 && H.pieces.back().stop == s0) {
@@ -1198,9 +1227,57 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     C.piece_end = (int32_t)H.pieces.size();
   }
 
+  // ---- workgroup chunking ------------------------------------------------------
+  // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
+  // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
+  H.lean = lean_ok && !nolean && H.n_fused > 0;
+  // mixed plans: some pieces are lean, some are not (the erf edges of a flat-top pulse next to its
+  // multi-tone plateau).  Two launches over the same output: the lean kernel takes the lean and the
+  // zero pieces, the general kernel the rest -- every sample is still written exactly once.
+  const char* nomix_env = std::getenv("WFK_DISABLE_MIXED");
+  H.mixed = !H.lean && can_fuse && !nolean && n_lean_pieces > 0 && ns_override == 0 &&
+            !(nomix_env && nomix_env[0] == '1');
+  H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
+  H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
+  auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
+                      std::vector<int32_t>& chunk_first, int lean_cap = WFK_LEAN_TPC, int64_t lean_div = 2048) {
+    // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
+    // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
+    tile = (lean_geom ? 64 : WFK_WG) * H.ns;
+    const int64_t tiles_per_ch = (ax.n + tile - 1) / tile;
+    const int64_t total_tiles = tiles_per_ch * P->n_channels;
+    // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves.  Longer
+    // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
+    // any moment compact, which is what the HBM write rate depends on (DESIGN.md 3.3a):
+    // measured best at 8 tiles (= one seed per chunk) on the headline config while a degree-1 op cost
+    // 12 instructions per sample, at 5 since the phasor fold (8: same box 3.19 / 6: 3.11 / 5: 3.07 / 4: 3.16 ms);
+    // 4 on C2.
+    const int64_t tpc = total_tiles / (lean_geom ? lean_div : 8192);
+    tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? lean_cap : 16, std::max<int64_t>(1, tpc));
+    if (const char* e = std::getenv("WFK_TPC")) {   // tuning override
+      int v = std::atoi(e);
+      if (v >= 1 && v <= 64) tiles_per_chunk = v;
+    }
+    chunks_per_ch = (tiles_per_ch + tiles_per_chunk - 1) / tiles_per_chunk;
+    chunk_first.assign((size_t)(chunks_per_ch * P->n_channels), 0);
+    const int64_t chunk_samples = (int64_t)tiles_per_chunk * tile;
+    for (int32_t c = 0; c < P->n_channels; ++c) {
+      int32_t p = H.channels[c].piece_begin;
+      for (int64_t k = 0; k < chunks_per_ch; ++k) {
+        int64_t g0 = k * chunk_samples;
+        while (p < H.channels[c].piece_end - 1 && H.pieces[p].stop <= g0) ++p;
+        chunk_first[(size_t)(c * chunks_per_ch + k)] = p;
+      }
+    }
+  };
   // ---- short tier: wave units and lane slots ------------------------------------
   if (shortm) {
+    // Mostly pieces the short tier cannot take (e.g. carriers that need the lean kernel's grid-rounding
+    // correction far from t = 0): the standard tiers serve the whole plan better
+    if (n_foreign_samples > n_short_samples) return WFK_RETRY_STD;
     H.shortp = true;
+    H.lean = false;
+    H.mixed = n_foreign_pieces > 0;       // foreign pieces: a second launch of the general kernel
     H.tile = 64 * WFK_SH_R;
     for (int32_t c = 0; c < P->n_channels; ++c) {
       ShortUnit U{};
@@ -1232,6 +1309,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       };
       for (int32_t pi = H.channels[c].piece_begin; pi < H.channels[c].piece_end; ++pi) {
         const DevPiece& D = H.pieces[pi];
+        if (D.n_blk != 0 && !(D.flags & WFK_PF_SHORT)) {   // the general kernel's piece: no unit covers it
+          close(D.stop);
+          continue;
+        }
         if (D.n_blk == 0) {
           // zero stretch: rides in the current unit's range while it fits, long ones as pure-fill units
           int64_t z0 = D.start, left = D.stop - D.start;
@@ -1281,53 +1362,15 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     }
     H.chunks_per_ch = 0;
     if (H.pool.empty()) H.pool.push_back(0.0);
-    H.params.resize(H.params.size() + 272, 0.0);   // (the kernel reads one op record past the last real one, and touches 2 KB ahead)
+    H.params.resize(H.params.size() + 16, 0.0);   // (the kernel reads one op record past the last real one)
+    if (H.mixed) {
+      set_geom(false);
+      H.ns = WFK_NS_GRID;
+      chunking(false, H.tile, H.tiles_per_chunk, H.chunks_per_ch, H.chunk_first);
+    }
     return WFK_OK;
   }
 
-  // ---- workgroup chunking ------------------------------------------------------
-  // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
-  // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
-  H.lean = lean_ok && !nolean && H.n_fused > 0;
-  // mixed plans: some pieces are lean, some are not (the erf edges of a flat-top pulse next to its
-  // multi-tone plateau).  Two launches over the same output: the lean kernel takes the lean and the
-  // zero pieces, the general kernel the rest -- every sample is still written exactly once.
-  const char* nomix_env = std::getenv("WFK_DISABLE_MIXED");
-  H.mixed = !H.lean && can_fuse && !nolean && n_lean_pieces > 0 && ns_override == 0 &&
-            !(nomix_env && nomix_env[0] == '1');
-  H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
-  H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
-  auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
-                      std::vector<int32_t>& chunk_first, int lean_cap = WFK_LEAN_TPC, int64_t lean_div = 2048) {
-    // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
-    // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
-    tile = (lean_geom ? 64 : WFK_WG) * H.ns;
-    const int64_t tiles_per_ch = (ax.n + tile - 1) / tile;
-    const int64_t total_tiles = tiles_per_ch * P->n_channels;
-    // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves.  Longer
-    // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
-    // any moment compact, which is what the HBM write rate depends on (DESIGN.md 3.3a):
-    // measured best at 8 tiles (= one seed per chunk) on the headline config while a degree-1 op cost
-    // 12 instructions per sample, at 5 since the phasor fold (8: same box 3.19 / 6: 3.11 / 5: 3.07 / 4: 3.16 ms);
-    // 4 on C2.
-    const int64_t tpc = total_tiles / (lean_geom ? lean_div : 8192);
-    tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? lean_cap : 16, std::max<int64_t>(1, tpc));
-    if (const char* e = std::getenv("WFK_TPC")) {   // tuning override
-      int v = std::atoi(e);
-      if (v >= 1 && v <= 64) tiles_per_chunk = v;
-    }
-    chunks_per_ch = (tiles_per_ch + tiles_per_chunk - 1) / tiles_per_chunk;
-    chunk_first.assign((size_t)(chunks_per_ch * P->n_channels), 0);
-    const int64_t chunk_samples = (int64_t)tiles_per_chunk * tile;
-    for (int32_t c = 0; c < P->n_channels; ++c) {
-      int32_t p = H.channels[c].piece_begin;
-      for (int64_t k = 0; k < chunks_per_ch; ++k) {
-        int64_t g0 = k * chunk_samples;
-        while (p < H.channels[c].piece_end - 1 && H.pieces[p].stop <= g0) ++p;
-        chunk_first[(size_t)(c * chunks_per_ch + k)] = p;
-      }
-    }
-  };
   chunking(H.lean, H.tile, H.tiles_per_chunk, H.chunks_per_ch, H.chunk_first);
   if (H.mixed) chunking(true, H.lean_tile, H.lean_tiles_per_chunk, H.lean_chunks_per_ch, H.lean_chunk_first);
   if ((H.lean || H.mixed) && ns_override == 0) {

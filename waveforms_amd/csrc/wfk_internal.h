@@ -259,6 +259,7 @@ struct HostPlan {
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most state units (128 doubles) of a piece
   // short tier (WFK_SH_*): `params` then holds the compact records
   bool shortp = false;
+  bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
   std::vector<ShortUnit> s_units;
   std::vector<uint32_t> s_slots;
   int32_t s_lds_samples = 0, s_units_per_chunk = 1;

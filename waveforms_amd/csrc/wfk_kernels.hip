@@ -1097,8 +1097,8 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? 3 : ((DIRECT || (GENERIC && CP
     for (int q = p; q < C.piece_end; q = uni(q + 1)) {
       const DevPiece P = load_piece(a.pieces + q);
       if (P.start >= g1) break;
-      // (mixed plans: the lean and the zero pieces were written by the lean kernel's launch)
-      if (a.mixed && (P.n_blk == 0 || (P.flags & WFK_PF_LEAN))) continue;
+      // (mixed plans: the lean / short and the zero pieces were written by the other kernel's launch)
+      if (a.mixed && (P.n_blk == 0 || (P.flags & (WFK_PF_LEAN | WFK_PF_SHORT)))) continue;
       const bool active = w0 < a.n && P.start < w0 + WT && P.stop > w0;  // wave-uniform
 
       T acc[NS], acci[CPLX ? NS : 1];
