@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--share-gpu', action='store_true')
     ap.add_argument('--plan-only', action='store_true')
+    ap.add_argument('--deadline', type=float, default=1500.0,
+                    help='self-launched ranks (--gpus N without a rendezvous in the environment): seconds '
+                         'after which the parent stops every rank and returns non-zero')
     return ap.parse_args(argv)
 
 
@@ -80,34 +83,62 @@ def parse_args(argv=None):
 def launch_ranks(args, argv):
     """Start one rank process per GPU and relay rank 0's line.  Runs before any GPU call
     and never imports torch: a process that has initialised the GPU must neither fork
-    workers that use it nor be replaced by exec."""
+    workers that use it nor be replaced by exec.
+
+    The parent polls ALL children: the first one that exits non-zero (or the overall
+    deadline, --deadline seconds) ends the job -- the remaining children, exactly the ones
+    started here, are terminated, then killed, and the parent returns non-zero.  Without
+    that a rank dying during rendezvous leaves rank 0 blocked in init_process_group until the
+    NCCL timeout, and the driver sees a hang instead of an error."""
     import socket
+    import tempfile
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL needs it here)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()                                   # the exact child we started
-            rcs.append(p.wait())
+                                      stdout=out0 if r == 0 else sys.stderr))
+    deadline = time.time() + args.deadline
+    rcs = [None] * len(procs)
+    failed = None
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0) and failed is None:
+                    failed = f'rank {i} exited with code {rcs[i]}'
+        if failed is None and time.time() > deadline:
+            failed = f'deadline of {args.deadline:.0f} s passed'
+        if failed is not None:
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        sys.stderr.write(f'bench.py launcher: {failed}; stopping the other ranks\n')
+        for i, p in enumerate(procs):          # the exact children started above
+            if rcs[i] is None:
+                p.terminate()
+        t_kill = time.time() + 5.0
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                try:
+                    rcs[i] = p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    rcs[i] = p.wait()
     # rank 0's JSON line goes to stdout; anything else it printed there (backend chatter) to stderr
-    for ln in out0.decode('utf-8', 'replace').splitlines():
-        (sys.stdout if ln.startswith('{') else sys.stderr).write(ln + '\n')
+    out0.seek(0)
+    for ln in out0.read().decode('utf-8', 'replace').splitlines():
+        (sys.stdout if ln.startswith('{') and failed is None else sys.stderr).write(ln + '\n')
     sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    return bad[0] if bad else 0
+    if failed is not None:
+        return next((rc for rc in rcs if rc not in (None, 0)), 1) or 1
+    return 0
 
 
 # ---------------------------------------------------------------------------------------
@@ -311,6 +342,10 @@ def run_rank(args):
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if os.environ.get('WFK_BENCH_FAIL_RANK') == str(rank):      # (tests/test_bench_launcher.py: a rank that dies early)
+        raise SystemExit(7)
+    if os.environ.get('WFK_BENCH_HANG_RANK') == str(rank):      # ... and one that never comes back
+        time.sleep(3600)
     if args.plan_only:
         return run_plan_only(args, rank, world)
     import torch
@@ -386,7 +421,7 @@ def run_rank(args):
     def prewarm(fn, min_s=0.25):
         # Untimed device pre-warm, before the W warm-up steps: the first ~40 ms of launches
         # after idle run ~10% slower (memory/fabric clocks still ramping; measured per launch in
-        # tools/placement_probe2.py), and W = 3 steps of a 3 ms kernel end well inside that ramp.
+        # tools/attic/placement_probe2.py), and W = 3 steps of a 3 ms kernel end well inside that ramp.
         t_pre, n_pre = time.perf_counter(), 0
         while n_pre < 10 or time.perf_counter() - t_pre < min_s:
             fn()
@@ -583,10 +618,10 @@ def run_rank(args):
             del o2
             b2.close()
         line['also'] = also
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and name in (
+    if rank == 0 and not args.no_cpu_baseline and name in (
             'sampler256', 'c4', 'c5', 'c2', 'far', 'far_sparse', 'awg', 'awg_duty30'):
         base, outs = cpu_baseline(chans, grid)
-        line['cpu_baseline'] = base
+        line['cpu_baseline'] = base        # (timed after the last barrier of the timed region: rank 0's host only)
         line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
         got = out[:len(outs)].cpu().numpy().astype(np.float64)
         line['max_abs_err_vs_numpy_ref'] = float(

@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   // ---- load: sample j = i*64 + lane of the chunk belongs to block j / OP_LB, position j % OP_LB
   // (a whole chunk loads unconditionally: with the bounds test inside the loop every load sits in
   //  its own branch and is waited for before the next one is issued -- the whole kernel then runs
-  //  at a fraction of the copy rate, tools/iir_stream_probe.hip)
+  //  at a fraction of the copy rate, tools/attic/iir_stream_probe.hip)
   if (whole) {
     T v[OP_LB];
 #pragma unroll
@@ -895,7 +895,7 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     // 256 x 1e7 11.7 / 11.5 vs 8.6 / 9.9, 64 x 1e7 3.0 / 3.2 vs 2.8 / 3.1, 64 x 1e5 0.39 / 0.46 vs
     // 0.04 / 0.05 (one launch instead of three).  WFK_IIR_ONEPASS=0 keeps the three-launch form.
     const char* on = getenv("WFK_IIR_ONEPASS");
-    // Between 8 and 64 LONG rows the three-launch form is still ahead (tools/iir_depth.py, 2 biquads,
+    // Between 8 and 64 LONG rows the three-launch form is still ahead (tools/attic/iir_depth.py, 2 biquads,
     // fp64, three-launch vs single pass: 8 x 1e7 0.61 vs 0.75 ms, 16 x 1e7 0.80 vs 1.22, 32 x 1e7 1.55 vs
     // 1.84, 48 x 1e7 2.29 vs 2.48; but 16 x 1e6 0.49 vs 0.12, 4 x 1e7 0.54 vs 0.38, 1 x 1e7 0.51 vs 0.15):
     // 2304 / rows chunks of a row are in flight there and every look-back reads all of them.

@@ -895,7 +895,7 @@ __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, 
 // (workgroup b runs on XCD b % 8), so a plain chunk = b makes every XCD touch every region
 // of the output at once.  Give XCD x the x-th contiguous eighth of the chunk list instead,
 // walked in order: each XCD's L2 / TLB then sees one compact, linearly advancing write
-// window (tools/store_pattern6.hip: 5.86 -> 6.26 TB/s for this walk with stores only).
+// window (tools/attic/store_pattern6.hip: 5.86 -> 6.26 TB/s for this walk with stores only).
 // Returns -1 for the padding workgroups of the rounded-up grid.
 __device__ __forceinline__ int64_t xcd_chunk(const KArgs& a) {
   const int64_t b = blockIdx.x;
