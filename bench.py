@@ -291,6 +291,25 @@ def profile_traffic(key):
     return v, 'profiles/traffic.json (separate rocprofv3 --pmc pass, not this run)'
 
 
+def valu_roofline(key, kernel_ms, samples):
+    """Second roofline for kernels bound by fp64 VALU issue, not by HBM (the FIR transform of C4, DESIGN
+    3.7): VALU wave instructions per launch from the committed PMC pass x 4 cycles (a wave64 fp64
+    instruction occupies its SIMD for 4 cycles) / 1024 SIMDs / shader clock = the time the kernel
+    needs at 100 % VALU issue; valu_frac = that / the kernel time measured in THIS run."""
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(tfile):
+        return None
+    v = json.load(open(tfile)).get(key)
+    if not isinstance(v, dict) or 'valu_wave_instr' not in v:
+        return None
+    clock = v.get('shader_clock_ghz', 1.9)
+    issue_ms = v['valu_wave_instr'] * 4 / 1024 / (clock * 1e9) * 1e3
+    return {'bound': 'valu_fp64', 'valu_instr_per_sample': v['valu_wave_instr'] * 64 / samples,
+            'issue_limited_ms': issue_ms, 'valu_frac': issue_ms / kernel_ms,
+            'shader_clock_ghz': clock, 'simds': 1024, 'cycles_per_wave_instr': 4,
+            'source': 'profiles/' + v.get('source', 'traffic.json') + ' (separate rocprofv3 --pmc pass: SQ_INSTS_VALU, GRBM_GUI_ACTIVE)'}
+
+
 # ---------------------------------------------------------------------------------------
 # plan-only rehearsal (CPU): sharding, rendezvous, reductions -- no kernels
 # ---------------------------------------------------------------------------------------
@@ -472,7 +491,11 @@ def run_rank(args):
         # fused chain: the samples never touch HBM; algorithmic traffic = the filtered output only
         roof['kernel'] = 'fir_sampled<%s,12>' % ('double' if dtype == np.float64 else 'float')
         roof['note'] = ('sampler fused into the FIR transform: algorithmic bytes = B_out per sample '
-                        '(SURVEY 8(d) "fused sampler->FIR: B_out only")')
+                        '(SURVEY 8(d) "fused sampler->FIR: B_out only"); the kernel is bound by fp64 VALU issue, '
+                        'not by HBM: see roofline_valu')
+        rv = valu_roofline('c4', kern_ms, bs.n_channels * bs.n)
+        if rv is not None:
+            roof['roofline_valu'] = rv
     if fir is not None:
         # the FIR stage dominates this workload: report ITS roofline (16 B/sample: read+write)
         fir_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_fir]))
@@ -551,7 +574,11 @@ def run_rank(args):
                         'fir_frac_16B_per_sample': 2 * algo_bytes / (fir_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         'step_ms': kern_ms + fir_ms},
             'note': 'C4 (BASELINE configs[3]) = predistort(wav(t), ker 1024 taps): sampler fused into the '
-                    'LDS-FFT FIR kernel; frac = 8 B/sample (output only) / kernel time / 8 TB/s'}
+                    'LDS-FFT FIR kernel; frac = 8 B/sample (output only) / kernel time / 8 TB/s; the roof that '
+                    'binds is fp64 VALU issue (roofline_valu)'}
+        rv = valu_roofline('c4', chain_ms, bs.n_channels * bs.n) if chn.fused else None
+        if rv is not None:
+            also['c4']['roofline_valu'] = rv
         chn.close()
         fst.close()
         # IIR stages of sample(filters=) / predistort(filters=) on the same 256 x 1e7 block (SURVEY 8(f)

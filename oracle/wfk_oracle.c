@@ -285,8 +285,16 @@ static int eval(const wfk_program* P, const tsrc* ts, double* re, double* im,
               sre = sre + P->tm_amp_re[k] * prod;
               sim = sim + P->tm_amp_im[k] * prod;
             }
-            ore[i] += clipd(sre, lo, hi);
-            if (oim) oim[i] += sim;
+            if (oim) {
+              /* np.clip of a complex part: NumPy orders complex numbers lexicographically (real part,
+                 then imaginary) against the real bounds lo + 0j, hi + 0j; NaN propagates */
+              if (sre < lo || (sre == lo && sim < 0.0)) { sre = lo; sim = 0.0; }
+              if (sre > hi || (sre == hi && sim > 0.0)) { sre = hi; sim = 0.0; }
+              ore[i] += sre;
+              oim[i] += sim;
+            } else {
+              ore[i] += clipd(sre, lo, hi);
+            }
           }
         }
         start = stop;

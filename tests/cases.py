@@ -202,6 +202,9 @@ def iir_cases():
                         -1, 1.5, 4000, 4, 90.0, 0.3),
         'iir_long': (lambda ns: ns.square(30.0) * ns.cos(3.0) >> 40,
                      0, 80, 1500, 2, 7.0, 0),
+        # complex-valued waveform through the (real) sections: scipy.signal.sosfilt takes complex input
+        'iir_cplx': (lambda ns: (1 + 0.5j) * ns.square(0.8, edge=0.1) * ns.cos(40.0) + 0.2j * (ns.gaussian(0.5) >> 0.6),
+                     -1, 1.5, 4000, 4, 90.0, 0.3),
     }
 
 
@@ -551,7 +554,33 @@ def _u_registered_id(ns):
     return w, None, _user_x()
 
 
+def uf_cexp(t, w, tau):
+    return np.exp(1j * w * t - (t / tau)**2)          # complex-valued callable
+
+
+def _u_complex_fn(ns):
+    f = ns.function(uf_cexp, 2 * pi * 30e6, 40e-9, start=-60e-9, stop=90e-9)
+    w = 0.8 * f * ns.cos(2 * pi * 11e6) + (0.3 - 0.2j) * (f >> 20e-9)**2 + 0.1 * (ns.gaussian(30e-9) >> 100e-9)
+    return w, None, _user_x()
+
+
+def _u_complex_pow(ns):
+    # built-in factors raised to complex powers: value**n with NumPy's complex power (_waveform.pyx:143-146)
+    g = ns.gaussian(60e-9) >> 20e-9
+    w = 0.7 * g**(1.5 + 0.8j) + (ns.square(50e-9) >> 110e-9) * (ns.cos(2 * pi * 20e6)**(2 + 1j)) * 0.25
+    return w, None, _user_x()
+
+
+def _u_clip_complex(ns):
+    # np.clip on a complex part: lexicographic against the real bounds (_waveform.pyx:162)
+    w = (1 + 2j) * (ns.gaussian(50e-9) >> 10e-9) * ns.cos(2 * pi * 40e6) + (-1.5 + 0.5j) * (ns.gaussian(30e-9) >> 90e-9) \
+        + 0.4 * (ns.square(40e-9) >> -70e-9)
+    w.min, w.max = -0.5, 0.4
+    return w, None, _user_x()
+
+
 USER_CASES = {
+    'u_complex_fn': _u_complex_fn, 'u_complex_pow': _u_complex_pow, 'u_clip_complex': _u_clip_complex,
     'u_tanh': _u_tanh, 'u_power_const': _u_power_const, 'u_shared_factor': _u_shared_factor,
     'u_vstack': _u_vstack, 'u_lib_override': _u_lib_override,
     'u_lib_vstack_attr': _u_lib_vstack_attr, 'u_lib_remap_builtin': _u_lib_remap_builtin,

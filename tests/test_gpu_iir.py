@@ -62,12 +62,12 @@ def test_sample_with_filters(name):
     w = _configure(name)
     want = IIR[name + '.full']
     got = w.sample()
-    assert got.shape == want.shape and got.dtype == np.float64
+    assert got.shape == want.shape and got.dtype == want.dtype      # (complex128 for a complex waveform)
     assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, np.abs(want).max())
     assert np.max(np.abs(got - np_oracle.sample_filtered(w))) <= 1e-10
     # chunked: state carried chunk to chunk, also written into `out`
     wantc = IIR[name + '.chunked']
-    out = np.zeros(len(wantc) + 300)
+    out = np.zeros(len(wantc) + 300, dtype=want.dtype)
     gotc = np.concatenate(list(w.sample(chunk_size=300, out=out)))
     assert gotc.shape == wantc.shape
     assert np.max(np.abs(gotc - wantc)) <= 1e-10 * max(1.0, np.abs(wantc).max())
@@ -257,8 +257,32 @@ def test_predistort_combined_order_above_16():
     for b, a in filters:
         want = lfilter(b, a, want)
     assert np.max(np.abs(got - want)) <= 1e-9
-    with pytest.raises(NotImplementedError):
-        distortion.predistort(x, filters, initial=0.3)
+    # Non-zero initial state and return_zf at this order.  (The reference itself is of no use as a
+    # yardstick here: its order-20 direct-form lfilter overflows to 1e125 / NaN in double precision on
+    # such sections; the truth is the cascade.)  initial = c means "the line sat at c for ever": the
+    # exp-decay sections have unit DC gain, so the answer is cascade(x - c) from rest, + c.
+    c = 0.3
+    got_i = distortion.predistort(x + c, filters, initial=c)
+    assert np.max(np.abs(got_i - (want + c))) <= 1e-9
+    # zf handed back as zi continues the signal: two halves == one run (the state is the cascade's:
+    # a direct-form state of this order cannot carry the information in doubles)
+    xs = rng.normal(size=6000)
+    whole = xs
+    for b, a in filters:
+        whole = lfilter(b, a, whole)
+    y1, zf = distortion.predistort(xs[:2500], filters, return_zf=True)
+    assert zf.shape == (20, )
+    y2, zf2 = distortion.predistort(xs[2500:], filters, zi=zf, return_zf=True)
+    assert np.max(np.abs(np.concatenate([y1, y2]) - whole)) <= 1e-9
+    # ... also when the pieces are shorter than the order, and with the FIR stage behind it
+    ys, z = [], None
+    for k in range(0, 60, 7):
+        y_, z = distortion.predistort(xs[k:k + 7], filters, zi=z, return_zf=True)
+        ys.append(y_)
+    assert np.max(np.abs(np.concatenate(ys) - whole[:63])) <= 1e-9
+    ker = rng.normal(size=9)
+    yk = distortion.predistort(xs, filters, ker=ker, initial=0.0)
+    assert np.max(np.abs(yk - np.convolve(whole, ker, 'full')[4:4 + len(xs)])) <= 1e-9
 
 
 @pytest.mark.parametrize('nsec,n,rows', [(2, 100003, 3), (1, 65536, 2), (2, 8192 * 4, 5), (2, 1_000_001, 7),

@@ -47,9 +47,13 @@ class wfk_grid(C.Structure):
 class Program:
     """Owns the NumPy arrays behind a `wfk_program` and exposes `.struct`."""
 
-    def __init__(self, arrays: dict, counts: dict, complex_amp: bool):
+    def __init__(self, arrays: dict, counts: dict, complex_amp: bool, host_complex: bool = False):
         self.arrays = arrays
         self.complex_amp = complex_amp
+        # a Python callable returned complex values, or a factor carries a complex power, in a piece
+        # that holds samples: the reference's result is complex128 then (calc_parts looks at the
+        # evaluated part's dtype, _waveform.pyx:164-166) even if every amplitude is real
+        self.host_complex = host_complex
         s = wfk_program()
         for k, v in counts.items():
             setattr(s, k, v)
@@ -150,16 +154,14 @@ class _HostFactors:
 
     @staticmethod
     def evaluate(fn, factor, xs, start, stop):
+        """-> float64 or complex128 values of the factor over the piece's samples (a complex-valued
+        callable is legal: `_apply` is dtype-agnostic, _waveform.pyx:130-131)."""
         _tid, *args, shift = factor
         if stop <= start:
             return np.zeros(0)
         v = np.asarray(fn(xs[start:stop] - shift, *args))
-        if np.iscomplexobj(v):
-            if np.any(v.imag != 0):
-                raise NotImplementedError('complex-valued Python-callable primitive')
-            v = v.real
-        return np.ascontiguousarray(np.broadcast_to(v.astype(np.float64, copy=False),
-                                                    (stop - start, )))
+        dt = np.complex128 if np.iscomplexobj(v) else np.float64
+        return np.ascontiguousarray(np.broadcast_to(v.astype(dt, copy=False), (stop - start, )))
 
 
 def flatten(channels, axis=None, function_lib=None) -> Program:
@@ -175,6 +177,7 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
     fc_type, fc_power, fc_shift, fc_arg_off = [], [], [], [0]
     pool, pool_parts, pool_len = [], [], 0     # scalars collect in `pool`; big tables go in as arrays
     any_complex = False
+    host_complex = False
     host = None
 
     for w in channels:
@@ -201,50 +204,95 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
                 for (factors, powers), amp in zip(terms, amps):
                     if isinstance(amp, complex):
                         any_complex = True
-                        if math.isfinite(lo) or math.isfinite(hi):
-                            raise NotImplementedError(
-                                'clip (min/max) of a complex-valued waveform')
-                    amp_re.append(float(amp.real))
-                    amp_im.append(float(amp.imag))
+                    # Factors whose VALUES are complex -- a complex-valued Python callable, or any factor
+                    # raised to a complex power (`value**n`, _waveform.pyx:143-146) -- cannot be device
+                    # factors (those are real).  The host evaluates them where the reference does, applies
+                    # the power with NumPy as the reference does, and the term is expanded over (re, im) of
+                    # each such factor: amp (re + i im) rest = amp re rest + (i amp) im rest.
+                    # Hot path: every factor a native device primitive with a real power -> appended as it is.
+                    nf0, np0 = len(fc_type), len(pool)
                     for f, n in zip(factors, powers):
-                        if isinstance(n, complex):
-                            raise NotImplementedError('complex power')
                         tid = f[0]
+                        if tid not in native or type(n) is complex:
+                            break
                         fc_power.append(n)
                         fc_shift.append(f[-1])
-                        if tid in native:
-                            fc_type.append(tid)
-                            argc = _SIMPLE_ARGC.get(tid)
-                            if argc is not None and len(f) == argc + 2:
-                                if argc:
-                                    pool.extend(f[1:-1])    # converted to float64 in one go below
-                            else:
-                                pool.extend(_factor_args(f))
+                        fc_type.append(tid)
+                        argc = _SIMPLE_ARGC.get(tid)
+                        if argc is not None and len(f) == argc + 2:
+                            if argc:
+                                pool.extend(f[1:-1])    # converted to float64 in one go below
                         else:
-                            fn = lib[tid]     # KeyError for an unknown id, like the reference
-                            if isinstance(fn, BuiltinPrimitive):
-                                # the id is mapped onto ANOTHER device primitive
-                                fc_type.append(fn.type_id)
-                                pool.extend(_factor_args((fn.type_id, ) + tuple(f[1:])))
+                            pool.extend(_factor_args(f))
+                        fc_arg_off.append(pool_len + len(pool))
+                    else:
+                        amp_re.append(float(amp.real))
+                        amp_im.append(float(amp.imag))
+                        tm_factor_off.append(len(fc_type))
+                        continue
+                    del fc_type[nf0:], fc_power[nf0:], fc_shift[nf0:], fc_arg_off[nf0 + 1:], pool[np0:]
+                    cplx = []         # [(start, re values, im values)]
+                    staged = []       # the term's other factors: (type, power, shift, args | (start, values))
+                    for f, n in zip(factors, powers):
+                        tid = f[0]
+                        if tid in native and not isinstance(n, complex):
+                            argc = _SIMPLE_ARGC.get(tid)
+                            staged.append((tid, n, f[-1], f[1:-1] if (argc is not None and len(f) == argc + 2)
+                                           else _factor_args(f)))
+                            continue
+                        fn = lib[tid]     # KeyError for an unknown id, like the reference
+                        if isinstance(fn, BuiltinPrimitive) and not isinstance(n, complex):
+                            # the id is mapped onto ANOTHER device primitive
+                            staged.append((fn.type_id, n, f[-1], _factor_args((fn.type_id, ) + tuple(f[1:]))))
+                            continue
+                        if host is None:
+                            host = _HostFactors(axis)
+                        if xs is None:
+                            xs, edges = host.member_axis(tshift, bounds)
+                        start = int(edges[ip - 1]) if ip > 0 else 0
+                        stop = int(edges[ip])
+                        if f not in cache:
+                            cache[f] = host.evaluate(fn, f, xs, start, stop)
+                        vals = cache[f]
+                        if isinstance(n, complex) or np.iscomplexobj(vals):
+                            v = vals if n == 1 else vals**n
+                            v = v.astype(np.complex128, copy=False)
+                            cplx.append((start, np.ascontiguousarray(v.real), np.ascontiguousarray(v.imag)))
+                            if stop > start:
+                                host_complex = True
+                        else:
+                            staged.append((SAMPLED, n, f[-1], (start, vals)))
+                    if cplx and (math.isfinite(lo) or math.isfinite(hi)):
+                        pass      # (clip of a complex piece: np.clip's lexicographic rule, done by the kernels)
+                    for choice in range(1 << len(cplx)):
+                        a_c = complex(amp)
+                        tabs = []
+                        for k, (start, re, im) in enumerate(cplx):
+                            if (choice >> k) & 1:
+                                a_c = a_c * 1j
+                                tabs.append((start, im))
                             else:
-                                if host is None:
-                                    host = _HostFactors(axis)
-                                if xs is None:
-                                    xs, edges = host.member_axis(tshift, bounds)
-                                start = int(edges[ip - 1]) if ip > 0 else 0
-                                stop = int(edges[ip])
-                                if f not in cache:
-                                    cache[f] = host.evaluate(fn, f, xs, start, stop)
-                                vals = cache[f]
-                                fc_type.append(SAMPLED)
+                                tabs.append((start, re))
+                        if cplx:
+                            any_complex = True
+                        amp_re.append(float(a_c.real))
+                        amp_im.append(float(a_c.imag))
+                        for tid, n, shift, args in staged + [(SAMPLED, 1, 0.0, t) for t in tabs]:
+                            fc_power.append(n)
+                            fc_shift.append(shift)
+                            fc_type.append(tid)
+                            if tid == SAMPLED:
+                                start, vals = args
                                 pool.append(float(start))
                                 if len(vals):
                                     pool_parts.append(np.asarray(pool, dtype=np.float64))
                                     pool_parts.append(vals)
                                     pool_len += len(pool) + len(vals)
                                     pool = []
-                        fc_arg_off.append(pool_len + len(pool))
-                    tm_factor_off.append(len(fc_type))
+                            elif args:
+                                pool.extend(args)    # converted to float64 in one go below
+                            fc_arg_off.append(pool_len + len(pool))
+                        tm_factor_off.append(len(fc_type))
                 pc_term_off.append(len(amp_re))
             mb_piece_off.append(len(pc_bound))
         ch_member_off.append(len(mb_piece_off) - 1)
@@ -272,7 +320,7 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
     counts = dict(n_channels=len(ch_offset), n_members=len(mb_piece_off) - 1,
                   n_pieces=len(pc_bound), n_terms=len(amp_re),
                   n_factors=len(fc_type), n_pool=len(pool))
-    return Program(arrays, counts, any_complex)
+    return Program(arrays, counts, any_complex, host_complex)
 
 
 def tile_program(prog: Program, reps: int) -> Program:
@@ -304,7 +352,7 @@ def tile_program(prog: Program, reps: int) -> Program:
                   n_factors=s.n_factors * reps, n_pool=s.n_pool * reps)
     if max(counts['n_pieces'], counts['n_terms'], counts['n_factors']) >= 2**31:
         raise ValueError('tiled program exceeds the 32-bit table indices')
-    return Program(arrays, counts, prog.complex_amp)
+    return Program(arrays, counts, prog.complex_amp, prog.host_complex)
 
 
 def grid_linspace(a, b, n, endpoint=True) -> wfk_grid:

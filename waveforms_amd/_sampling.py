@@ -43,9 +43,15 @@ def _result_dtype(live):
     return np.complex128 if any(_has_complex_amp(e) for _, _, e in live) else np.float64
 
 
+def _is_complex(w, plan):
+    """The reference's dtype rule for a Waveform (_waveform.pyx:164-166): complex128 when an evaluated
+    piece is complex -- a complex amplitude, a complex-valued callable or a complex power."""
+    return (_result_dtype(_live_pieces(plan, 0, w.seq)) is np.complex128) or plan.prog.host_complex
+
+
 def _finish(w, plan, frag, out, accumulate):
     live = _live_pieces(plan, 0, w.seq)
-    dtype = _result_dtype(live)
+    dtype = np.complex128 if (_result_dtype(live) is np.complex128 or plan.prog.host_complex) else np.float64
     res = plan.run_host(dtype)[0]
     if not frag:
         if out is None:
@@ -110,32 +116,61 @@ def _sos_sections(sos):
     return [(row[:3], row[3:]) for row in sos]
 
 
+def _rotated(prog):
+    """The program with every amplitude multiplied by -1j: its real part is the imaginary part of `prog`."""
+    arrays = dict(prog.arrays)
+    arrays['tm_amp_re'] = np.ascontiguousarray(prog.arrays['tm_amp_im'])
+    arrays['tm_amp_im'] = np.ascontiguousarray(-prog.arrays['tm_amp_re'])
+    s = prog.struct
+    counts = {k: getattr(s, k) for k in ('n_channels', 'n_members', 'n_pieces', 'n_terms', 'n_factors', 'n_pool')}
+    return _flatten.Program(arrays, counts, True, prog.host_complex)
+
+
 def _sample_filtered(w, plan, sos, initial, zi):
     """sampler -> SOS IIR cascade, both on the device; one download.
-    == sosfilt(sos, sig - initial, zi) + initial (reference waveform.py:193-203,244-251)."""
+    == sosfilt(sos, sig - initial, zi) + initial (reference waveform.py:193-203,244-251).
+    A complex-valued waveform goes through as two real rows -- its real and its imaginary part, the
+    second sampled from the program with the amplitudes turned by -1j: the sections are real, so the
+    filter acts on the two parts independently and the result is exact."""
     from .waveform import WaveVStack
-    if not isinstance(w, WaveVStack):
-        if _result_dtype(_live_pieces(plan, 0, w.seq)) is np.complex128:
-            raise NotImplementedError('IIR filters on a complex-valued waveform')
+    cplx = (not isinstance(w, WaveVStack)) and _is_complex(w, plan)
+    if zi is not None and np.iscomplexobj(zi) and np.any(np.imag(zi) != 0):
+        cplx = True          # a chunk of real samples behind complex ones: the carried state is complex
     n = plan.n
+    rows = 2 if cplx else 1
     iir = _engine.IirPlan(_sos_sections(sos), n, 1, np.float64)
     D = iir.state_dim
-    buf = _engine.DeviceBuffer(max(n, 1) * 8)
-    dzi = _engine.DeviceBuffer(max(D, 1) * 8)
-    dzf = _engine.DeviceBuffer(max(D, 1) * 8)
+    buf = _engine.DeviceBuffer(max(n, 1) * 8 * rows)
+    dzi = _engine.DeviceBuffer(max(D, 1) * 8 * rows)
+    dzf = _engine.DeviceBuffer(max(D, 1) * 8 * rows)
+    plan_im = None
     try:
         plan.launch(buf.ptr, n, _engine.OUT_F64)
-        dzi.upload(np.ascontiguousarray(np.zeros(D) if zi is None
-                                        else np.asarray(zi, dtype=np.float64).reshape(-1)))
-        iir.apply(buf.ptr, n, buf.ptr, n, dzi.ptr, dzf.ptr, initial or 0.0)   # in place
+        z0 = np.zeros(D, dtype=np.complex128) if zi is None else np.asarray(zi, dtype=np.complex128).reshape(-1)
+        init = complex(initial or 0.0)
+        if cplx:
+            plan_im = _engine.Plan(_rotated(plan.prog), grid=plan.grid)
+            plan_im.launch(buf.ptr + max(n, 1) * 8, n, _engine.OUT_F64)
+        dzi.upload(np.ascontiguousarray(np.concatenate([z0.real, z0.imag])[:D * rows]))
+        for r in range(rows):
+            off, zoff = r * max(n, 1) * 8, r * max(D, 1) * 8
+            iir.apply(buf.ptr + off, n, buf.ptr + off, n, dzi.ptr + zoff, dzf.ptr + zoff,
+                      init.imag if r else init.real)                       # in place
         _engine.sync()
-        sig = buf.download((n, ), np.float64) if n else np.zeros(0)
-        zf = dzf.download((D, ), np.float64).reshape(-1, 2)
+        if n:
+            sig = buf.download((rows, max(n, 1)), np.float64)
+            sig = sig[0] + 1j * sig[1] if cplx else sig[0]
+        else:
+            sig = np.zeros(0, dtype=np.complex128 if cplx else np.float64)
+        zf = dzf.download((rows, max(D, 1)), np.float64)[:, :D]
+        zf = (zf[0] + 1j * zf[1] if cplx else zf[0]).reshape(-1, 2)
     finally:
         buf.close()
         dzi.close()
         dzf.close()
         iir.close()
+        if plan_im is not None:
+            plan_im.close()
     return sig, zf
 
 

@@ -836,6 +836,16 @@ __device__ __forceinline__ T clip_np(T v, T lo, T hi) {
   return v;
 }
 
+// np.clip of a COMPLEX value against real bounds (reference _waveform.pyx:162 on a complex part):
+// minimum(maximum(v, lo + 0j), hi + 0j) in NumPy's lexicographic order -- real part first, then the
+// imaginary part -- so a value whose real part leaves [lo, hi] becomes the bare bound (imaginary part 0),
+// and on the bound itself the sign of the imaginary part decides.  NaN propagates (comparisons false).
+template <typename T>
+__device__ __forceinline__ void clip_np_cplx(T& re, T& im, T lo, T hi) {
+  if (re < lo || (re == lo && im < (T)0)) { re = lo; im = (T)0; }
+  if (re > hi || (re == hi && im > (T)0)) { re = hi; im = (T)0; }
+}
+
 // write one wave tile of one piece: clip (evaluated pieces only), + offset, optional
 // accumulate into `out`; lanes outside [P.start, P.stop) keep their hands off.
 // `tr`/`tc` point at the tile's first sample (wave-uniform => scalar base + lane offset).
@@ -858,12 +868,16 @@ __device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel
     const int o = lane + 64 * k;
     if (PLAIN || (o >= lo_l && o < hi_l)) {
       T v = acc[k];
-      if (clip) v = clip_np(v, lo, hi);
+      T vi = CPLX ? acci[k] : (T)0;
+      if (clip) {
+        if constexpr (CPLX) clip_np_cplx(v, vi, lo, hi);
+        else v = clip_np(v, lo, hi);
+      }
       v += base;
       if constexpr (CPLX) {
         OutC w;
         w.x = v;
-        w.y = acci[k];
+        w.y = vi;
         if (accum) {
           const OutC old = tc[o];
           w.x += old.x;

@@ -388,7 +388,15 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
       }
       // clip (evaluated pieces only: every slot is one), + offset
       if (cur.do_clip) {
-        SH_EACH(R, k) acc[k] = clip_np(acc[k], cur.clip_lo, cur.clip_hi); SH_END
+        if constexpr (CPLX) {
+          // np.clip of complex values: lexicographic against the real bounds (see clip_np_cplx in wfk_kernels.hip)
+          SH_EACH(R, k)
+            if (acc[k] < cur.clip_lo || (acc[k] == cur.clip_lo && acci[k] < 0.0)) { acc[k] = cur.clip_lo; acci[k] = 0.0; }
+            if (acc[k] > cur.clip_hi || (acc[k] == cur.clip_hi && acci[k] > 0.0)) { acc[k] = cur.clip_hi; acci[k] = 0.0; }
+          SH_END
+        } else {
+          SH_EACH(R, k) acc[k] = clip_np(acc[k], cur.clip_lo, cur.clip_hi); SH_END
+        }
       }
       {
         // padded layout: element o + k lands at swz(o) + k + [k >= 16 - (o & 15)]: two bases, immediate offsets

@@ -206,6 +206,11 @@ def predistort(sig, filters=None, ker=None, initial=0.0, initial_x=None,
         _, p, _ = tf2zpk(b, a)
         if not np.all(np.abs(p) < 1):
             warnings.warn('Warning: filter is unstable')
+        if max(len(b), len(a)) - 1 > 16:
+            if initial_x is not None or initial_y is not None:
+                raise ValueError('predistort: a combined filter of order > 16 has no usable direct form in double '
+                                 'precision; initial_x / initial_y histories cannot be honoured -- use initial=')
+            return _predistort_high_order(sig, filters, zi, ker, return_zf, float(initial) if zi is None else None)
         if zi is None:
             ix = (np.full((len(b) - 1, ), initial) if initial_x is None else
                   np.asarray(initial_x)[:len(b) - 1])
@@ -213,21 +218,45 @@ def predistort(sig, filters=None, ker=None, initial=0.0, initial_x=None,
                   np.asarray(initial_y)[:len(a) - 1])
             zi = lfiltic(b, a, iy, ix)
         sections = [(b, a)]
-        if max(len(b), len(a)) - 1 > 16:
-            # One direct-form section of order > 16 has no device form.  With a zero initial
-            # state the cascade of the caller's own sections is the same LTI system (the
-            # reference multiplies them into one polynomial first, distortion.py:298-300); a
-            # non-zero lfilter state of the combined form does not map onto cascade states.
-            if np.any(np.asarray(zi) != 0) or return_zf:
-                raise NotImplementedError(
-                    'predistort: combined filter order > 16 with a non-zero initial state '
-                    '(or return_zf) -- pass fewer sections per call')
-            sections, zi = [(np.atleast_1d(b_), np.atleast_1d(a_)) for b_, a_ in filters], None
         sig, zf = iir_host(sig, sections, zi=zi, ker=ker)
         return (sig, zf) if return_zf else sig
     if ker is None:
         return (sig, zf) if return_zf else sig
     out = fir_host(sig, np.asarray(ker, dtype=np.float64))
+    return (out, zf) if return_zf else out
+
+
+def _predistort_high_order(sig, filters, zi, ker, return_zf, steady):
+    """predistort(filters=...) for a combined order > 16 (reference distortion.py:298-321: one lfilter call on
+    the product polynomials), which has no single device section -- and no usable direct form at all: with
+    twenty poles next to z = 1 the free response of a direct-form state is the difference of terms 1e50
+    times its size, the reference's own double-precision lfilter returns 1e125 or NaN on such sections
+    (measured; tests/test_gpu_iir.py), and a state vector of doubles cannot even carry the information.
+    The same LTI system is the cascade of the caller's own sections, run on the device:
+      * `initial=c` ("the line sat at c for ever", steady != None): every section starts in ITS steady state
+        for the constant level that reaches it, c times the DC gains before it -- exact, well conditioned;
+      * zi / return_zf: the state is the CASCADE's (the sections' direct-form-II-transposed states back to
+        back, sum of the section orders = the combined order values): what `return_zf` hands out, `zi`
+        takes back, and a signal processed in pieces equals the signal processed whole."""
+    secs = [(np.atleast_1d(np.asarray(b_, dtype=np.float64)), np.atleast_1d(np.asarray(a_, dtype=np.float64)))
+            for b_, a_ in filters]
+    orders = [max(len(b_), len(a_)) - 1 for b_, a_ in secs]
+    zsec = None
+    if steady is not None:
+        if steady != 0:
+            from scipy.signal import lfiltic
+            level, parts = float(steady), []
+            for (b_, a_), m in zip(secs, orders):
+                gain = b_.sum() / a_.sum()
+                z = lfiltic(b_, a_, np.full(len(a_) - 1, level * gain), np.full(len(b_) - 1, level))
+                parts.append(np.concatenate([z, np.zeros(m - len(z))]))
+                level *= gain
+            zsec = np.concatenate(parts)
+    elif zi is not None:
+        zsec = np.asarray(zi, dtype=np.float64).reshape(-1)
+        if len(zsec) != sum(orders):
+            raise ValueError(f'predistort: zi must hold the {sum(orders)} cascade state values')
+    out, zf = iir_host(sig, secs, zi=zsec, ker=ker)
     return (out, zf) if return_zf else out
 
 
