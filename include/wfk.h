@@ -35,6 +35,7 @@ extern "C" {
 #define WFK_EUNSUP (-2)   /* primitive id without a device implementation      */
 #define WFK_EHIP   (-3)   /* HIP runtime / rocFFT failure                      */
 #define WFK_ENOMEM (-4)
+#define WFK_ETIMEOUT (-5)  /* a chained device-side wait ran out of polls (IIR single pass)   */
 
 /* Primitive ids == the reference registry (waveforms/_waveform.pyx:374-388).
  * args (in `pool`, at fc_arg_off) per id, evaluated at u = t - shift:
@@ -231,6 +232,10 @@ int wfk_iir_state_dim(const wfk_iir_plan* plan);
 int wfk_iir_apply(wfk_iir_plan* plan, const void* in_dev, int64_t in_stride, void* out_dev,
                   int64_t out_stride, const double* zi_dev, double* zf_dev, double initial,
                   void* hip_stream);
+/* Synchronises `hip_stream`; WFK_ETIMEOUT if a single-pass launch of this plan since the last check ran
+ * out of look-back polls (its outputs then hold NaN -- never silently: the same condition also fails the
+ * NEXT wfk_iir_apply of the plan).  The plan switches to the three-launch form, so launching again works. */
+int wfk_iir_status(wfk_iir_plan* plan, void* hip_stream);
 int wfk_iir_plan_destroy(wfk_iir_plan* plan);
 
 /* -- whole-signal transfer function ------------------- */

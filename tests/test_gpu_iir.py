@@ -433,3 +433,49 @@ def test_single_pass_persistent_waves(rows, n, first):
         assert np.max(np.abs(run() - got)) <= 1e-12 * pk
     finally:
         os.environ.pop('WFK_IIR_ONEPASS', None)
+
+
+def test_lookback_timeout_is_an_error_not_silent_nans():
+    """A look-back that runs out of polls (stalled / preempted predecessor chunk) must reach the caller:
+    forced here with WFK_IIR_SPIN=0 (no poll at all).  The launch's outputs hold NaN, wfk_iir_status says
+    so, the plan switches to the three-launch form, and the second launch is correct; the Python stages
+    (predistort, sample(filters=)) recover by themselves."""
+    import os
+    if os.environ.get('WFK_IIR_ONEPASS') == '0':
+        pytest.skip('three-launch form: nothing to time out')
+    rng = np.random.default_rng(3)
+    n, rows = 300_000, 3
+    sos = butter(4, 0.05, output='sos')
+    secs = [(r[:3], r[3:]) for r in sos]
+    x = rng.normal(size=(rows, n))
+    want = np.stack([sosfilt(sos, r) for r in x])
+    plan = _engine.IirPlan(secs, n, rows, np.float64)
+    dx, dy = _engine.DeviceBuffer(x.nbytes), _engine.DeviceBuffer(x.nbytes)
+    dx.upload(x)
+    os.environ['WFK_IIR_SPIN'] = '0'
+    try:
+        plan.apply(dx.ptr, n, dy.ptr, n)
+        assert plan.status() is False                       # reported ...
+        assert np.isnan(dy.download((rows, n), np.float64)).any()   # ... and nothing plausible was written
+        assert plan.status() is True                        # (the word is cleared by the check)
+        plan.apply(dx.ptr, n, dy.ptr, n)                    # three-launch form now
+        assert plan.status() is True
+        assert np.max(np.abs(dy.download((rows, n), np.float64) - want)) <= 1e-10
+        # a caller that never asks: the NEXT apply of a faulted plan fails loudly
+        plan2 = _engine.IirPlan(secs, n, rows, np.float64)
+        plan2.apply(dx.ptr, n, dy.ptr, n)
+        _engine.sync()
+        with pytest.raises(_engine.EngineError, match='look-back timed out'):
+            plan2.apply(dx.ptr, n, dy.ptr, n)
+        plan2.apply(dx.ptr, n, dy.ptr, n)
+        assert plan2.status() is True
+        assert np.max(np.abs(dy.download((rows, n), np.float64) - want)) <= 1e-10
+        plan2.close()
+        # the host-level stages retry by themselves
+        y, _ = distortion.iir_host(x[0], secs)
+        assert np.max(np.abs(y - want[0])) <= 1e-10
+    finally:
+        del os.environ['WFK_IIR_SPIN']
+        plan.close()
+        dx.close()
+        dy.close()

@@ -25,6 +25,7 @@ _KIND_OF = {np.dtype(np.float64): OUT_F64, np.dtype(np.float32): OUT_F32,
 _DTYPE_OF = {v: k for k, v in _KIND_OF.items()}
 
 E_UNSUP = -2
+E_TIMEOUT = -5
 
 
 class wfk_plan_info(C.Structure):
@@ -86,6 +87,7 @@ def lib():
         l.wfk_iir_state_dim.argtypes = [VP]
         l.wfk_iir_apply.argtypes = [VP, VP, I64, VP, I64, VP, VP, C.c_double, VP]
         l.wfk_iir_plan_destroy.argtypes = [VP]
+        l.wfk_iir_status.argtypes = [VP, VP]
         l.wfk_spectral_plan_create.argtypes = [I64, I32, C.c_int, P(VP)]
         l.wfk_spectral_apply.argtypes = [VP, VP, VP, VP, VP]
         l.wfk_spectral_plan_destroy.argtypes = [VP]
@@ -267,6 +269,15 @@ class IirPlan:
               initial=0.0, stream=0):
         check(lib().wfk_iir_apply(self._h, in_ptr, in_stride, out_ptr, out_stride, zi_ptr,
                                   zf_ptr, float(initial), stream))
+
+    def status(self, stream=0) -> bool:
+        """Synchronise `stream`; False if a single-pass launch since the last check ran into a look-back
+        timeout (its outputs hold NaN; the plan has switched to the three-launch form: apply again)."""
+        rc = lib().wfk_iir_status(self._h, stream)
+        if rc == E_TIMEOUT:
+            return False
+        check(rc)
+        return True
 
     def close(self):
         if self._h and _lib is not None:

@@ -145,17 +145,25 @@ def _sample_filtered(w, plan, sos, initial, zi):
     dzf = _engine.DeviceBuffer(max(D, 1) * 8 * rows)
     plan_im = None
     try:
-        plan.launch(buf.ptr, n, _engine.OUT_F64)
         z0 = np.zeros(D, dtype=np.complex128) if zi is None else np.asarray(zi, dtype=np.complex128).reshape(-1)
         init = complex(initial or 0.0)
         if cplx:
             plan_im = _engine.Plan(_rotated(plan.prog), grid=plan.grid)
-            plan_im.launch(buf.ptr + max(n, 1) * 8, n, _engine.OUT_F64)
         dzi.upload(np.ascontiguousarray(np.concatenate([z0.real, z0.imag])[:D * rows]))
-        for r in range(rows):
-            off, zoff = r * max(n, 1) * 8, r * max(D, 1) * 8
-            iir.apply(buf.ptr + off, n, buf.ptr + off, n, dzi.ptr + zoff, dzf.ptr + zoff,
-                      init.imag if r else init.real)                       # in place
+        for attempt in range(2):
+            plan.launch(buf.ptr, n, _engine.OUT_F64)
+            if cplx:
+                plan_im.launch(buf.ptr + max(n, 1) * 8, n, _engine.OUT_F64)
+            for r in range(rows):
+                off, zoff = r * max(n, 1) * 8, r * max(D, 1) * 8
+                iir.apply(buf.ptr + off, n, buf.ptr + off, n, dzi.ptr + zoff, dzf.ptr + zoff,
+                          init.imag if r else init.real)                       # in place
+            if iir.status():
+                break
+            # a single-pass look-back timed out: the filter ran in place, so sample again; the plan has
+            # switched to the three-launch form
+            if attempt == 1:
+                raise _engine.EngineError('IIR stage failed twice')
         _engine.sync()
         if n:
             sig = buf.download((rows, max(n, 1)), np.float64)

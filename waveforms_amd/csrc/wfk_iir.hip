@@ -390,7 +390,8 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
                                                   const double* __restrict__ pw1, const double* __restrict__ lanep1,
                                                   const double* __restrict__ lanepU, const double* __restrict__ zi,
                                                   double* __restrict__ zf, int64_t n, int64_t nchunks, int rows,
-                                                  unsigned epoch, double pre_sub, double post_add, int persist) {
+                                                  unsigned epoch, double pre_sub, double post_add, int persist,
+                                                  unsigned* __restrict__ fault, int spin_limit) {
   constexpr int DD = NSEC * ORD;       // state dimension (<= 4)
   __shared__ T tile[64][OP_LB + 1];
   const int lane = threadIdx.x;
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
       unsigned st = 0;
       int kstop = -1;
       bool whole_window = false;
-      for (; spins < OP_SPIN; ++spins) {
+      for (; spins < spin_limit; ++spins) {
         if (pc >= 0 && !(st == F_PRE)) st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool pre = pc >= 0 && st == F_PRE;
         const bool agg = pc >= 0 && (st == F_AGG || st == F_PRE);
@@ -554,6 +555,10 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
     for (int i = 0; i < DD; ++i) sin_[i] = hop[i];
   }
   poisoned = __any(poisoned);
+  // a look-back that ran out of polls (a predecessor preempted or stalled on a shared GPU): the chunk's
+  // outputs become NaN AND the plan's fault word -- host memory, mapped -- is raised, so the failure
+  // reaches the caller as an error code (wfk_iir_status / the next wfk_iir_apply), never as silent NaNs
+  if (poisoned && lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
   // ---- publish the inclusive prefix: agg + U * S_in
   if (lane == 0) {
@@ -689,6 +694,8 @@ struct wfk_iir_plan {
   double* op_pw1 = nullptr;
   double* op_lanep1 = nullptr;
   double* op_lanepU = nullptr;
+  unsigned* op_fault = nullptr;      // host memory, mapped: raised by a chunk whose look-back timed out
+  unsigned* op_fault_dev = nullptr;  // ... its device address
 };
 
 extern "C" {
@@ -705,6 +712,7 @@ int wfk_iir_plan_destroy(wfk_iir_plan* p) {
   (void)hipFree(p->op_pw1);
   (void)hipFree(p->op_lanep1);
   (void)hipFree(p->op_lanepU);
+  if (p->op_fault) (void)hipHostFree(p->op_fault);
   (void)hipFree(p->state);
   (void)hipFree(p->grp);
   (void)hipFree(p->pw);
@@ -926,10 +934,13 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
                  hipMalloc(&p->op_agg, slots * D * 8) == hipSuccess &&
                  hipMalloc(&p->op_pref, slots * D * 8) == hipSuccess && upload(&p->op_pw1, pw1) &&
                  upload(&p->op_lanep1, lanep1) && upload(&p->op_lanepU, lanepU);
+      ok1 = ok1 && hipHostMalloc((void**)&p->op_fault, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&p->op_fault_dev, p->op_fault, 0) == hipSuccess;
       if (!ok1) {
         wfk_iir_plan_destroy(p);
         return iir_fail(WFK_ENOMEM, "IIR single-pass buffer allocation failed");
       }
+      *p->op_fault = 0;
       p->onepass = true;
     }
   }
@@ -1016,7 +1027,17 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
     }
     return WFK_OK;
   }
+  if (p->onepass && *(volatile unsigned*)p->op_fault != 0) {
+    // an earlier launch of this plan timed out in a look-back (its outputs hold NaN): say so now, and
+    // serve this plan in the three-launch form from here on (no chained waits, cannot time out)
+    *(volatile unsigned*)p->op_fault = 0;
+    p->onepass = false;
+    return iir_fail(WFK_ETIMEOUT, "IIR single pass: a look-back timed out in an EARLIER launch of this plan (a stalled or "
+                                  "preempted predecessor chunk); its outputs hold NaN. The plan now runs in the three-launch form: launch again");
+  }
   if (p->onepass) {
+    int spin_limit = OP_SPIN;
+    if (const char* e = getenv("WFK_IIR_SPIN")) spin_limit = atoi(e);   // (tests: force the timeout)
     // tickets restart at 0; the flags of earlier launches are told apart by the epoch
     if (hipMemsetAsync(p->op_ticket, 0, (size_t)p->batch * 64, s) != hipSuccess)
       return iir_fail(WFK_EHIP, "IIR ticket reset failed");
@@ -1047,12 +1068,12 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
     hipLaunchKernelGGL((iir_onepass<TT, NS, OR, true>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
                        (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
                        p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
-                       initial, post, persist);                                                                         \
+                       initial, post, persist, p->op_fault_dev, spin_limit);                                            \
     else                                                                                                       \
     hipLaunchKernelGGL((iir_onepass<TT, NS, OR, false>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
                        (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
                        p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
-                       initial, post, persist)
+                       initial, post, persist, p->op_fault_dev, spin_limit)
 #define OP_SHAPES(TT)                                                                              \
     do {                                                                                           \
       const int ns_ = p->c.nsec, or_ = p->c.ord[0];                                                \
@@ -1073,6 +1094,28 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
   if (p->kind == WFK_OUT_F32) iir_launch<float>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, post, s);
   else iir_launch<double>(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, post, s);
   if (hipGetLastError() != hipSuccess) return iir_fail(WFK_EHIP, "IIR kernel launch failed");
+  return WFK_OK;
+}
+
+// Synchronise `hip_stream` and report whether a single-pass launch of this plan (or of one of its
+// passes) ran into a look-back timeout since the last check.  On a fault the plan switches to the
+// three-launch form, so the caller can simply launch again (not in place: the input is gone then).
+extern "C" int wfk_iir_status(wfk_iir_plan* p, void* hip_stream) {
+  if (!p) return iir_fail(WFK_EINVAL, "null plan");
+  if (hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) return iir_fail(WFK_EHIP, "stream synchronisation failed");
+  bool fault = false;
+  auto look = [&](wfk_iir_plan* q) {
+    if (q->op_fault && *(volatile unsigned*)q->op_fault != 0) {
+      *(volatile unsigned*)q->op_fault = 0;
+      q->onepass = false;
+      fault = true;
+    }
+  };
+  look(p);
+  for (wfk_iir_plan* q : p->parts) look(q);
+  if (fault)
+    return iir_fail(WFK_ETIMEOUT, "IIR single pass: a look-back timed out (a stalled or preempted predecessor chunk); the outputs "
+                                  "of that launch hold NaN. The plan now runs in the three-launch form: launch again");
   return WFK_OK;
 }
 

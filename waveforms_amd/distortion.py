@@ -178,6 +178,10 @@ def iir_host(sig, sections, zi=None, initial=0.0, ker=None):
             dzi.upload(z)
         dzf = dev(batch * D * 8)
         plan.apply(x.ptr, n, y.ptr, n, dzi.ptr if dzi else None, dzf.ptr, initial)
+        if not plan.status():      # a single-pass look-back timed out (stalled predecessor chunk): the plan has
+            plan.apply(x.ptr, n, y.ptr, n, dzi.ptr if dzi else None, dzf.ptr, initial)   # switched form; x is intact
+            if not plan.status():
+                raise _engine.EngineError('IIR stage failed twice')
         res = y
         if ker is not None and n > 0:
             fir = FirStage(ker, n, batch, np.float64)
