@@ -248,6 +248,15 @@ int wfk_spectral_apply(wfk_spectral_plan* plan, const void* in_dev, void* out_de
                        const void* H_dev, void* hip_stream);
 int wfk_spectral_plan_destroy(wfk_spectral_plan* plan);
 
+/* -- pinned host blocks for results ------------------------------------------------------- */
+/* Page-locked host memory from a per-process cache (power-of-two blocks, parked on free).  A result
+ * buffer taken from here costs no page faults, takes the D2H DMA directly and lets wfk_plan_run_host
+ * overlap the copy of one part of a big single-channel result with the kernel of the next -- what the
+ * drop-in calls Waveform.__call__ / Waveform.sample (waveforms/waveform.py:529-563, 173-207) need at
+ * 1e7 points.  wfk_plan_run_host accepts any host pointer; only blocks from here get the pipeline.  */
+int wfk_host_alloc(void** host_ptr, size_t bytes);
+int wfk_host_free(void* host_ptr);
+
 /* -- device memory helpers for FFI callers without a HIP binding ---------- */
 int wfk_malloc(void** dev_ptr, size_t bytes);
 int wfk_free(void* dev_ptr);

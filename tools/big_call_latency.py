@@ -28,3 +28,24 @@ for rep in range(3):
     print('grid : plan %.2f  run_host(fresh out) %.2f  run_host(touched out) %.2f ms' % ((t2 - t1) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3))
 t0 = c(); y = w(t); print('w(t) total %.2f ms' % ((c() - t0) * 1e3))
 t0 = c(); y = w(t); print('w(t) total %.2f ms' % ((c() - t0) * 1e3))
+# round 3: the drop-in call with out= (reused buffer), without, and sample()
+out = np.zeros(n)
+for rep in range(4):
+    t0 = c(); r = w(t, out=out); t1 = c()
+    print('w(t, out=out) %.2f ms' % ((t1 - t0) * 1e3))
+for rep in range(4):
+    t0 = c(); y = w(t); t1 = c()
+    print('w(t) %.2f ms' % ((t1 - t0) * 1e3))
+    del y
+t0 = c(); gd = _engine.detect_grid(t); print('detect_grid %.2f ms' % ((c() - t0) * 1e3))
+w.start, w.stop, w.sample_rate = 0.0, 100 * wl.SPAN, n / (100 * wl.SPAN)
+for rep in range(3):
+    t0 = c(); y = w.sample(); print('w.sample() %.2f ms, n = %d' % ((c() - t0) * 1e3, len(y)))
+    del y
+for m in (10001, 100000):
+    tt = np.linspace(0, 100 * wl.SPAN, m, endpoint=False)
+    w(tt)
+    t0 = c()
+    for _ in range(50):
+        w(tt)
+    print('w(t) on %d points: %.1f us' % (m, (c() - t0) / 50 * 1e6))

@@ -91,6 +91,8 @@ def lib():
         l.wfk_spectral_plan_create.argtypes = [I64, I32, C.c_int, P(VP)]
         l.wfk_spectral_apply.argtypes = [VP, VP, VP, VP, VP]
         l.wfk_spectral_plan_destroy.argtypes = [VP]
+        l.wfk_host_alloc.argtypes = [P(VP), C.c_size_t]
+        l.wfk_host_free.argtypes = [VP]
         l.wfk_malloc.argtypes = [P(VP), C.c_size_t]
         l.wfk_free.argtypes = [VP]
         l.wfk_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
@@ -182,13 +184,44 @@ class Plan:
                                     ACCUMULATE if accumulate else 0, stream))
 
     def run_host(self, dtype=np.float64) -> np.ndarray:
-        """Launch, copy back, synchronise -> (n_channels, n) NumPy array."""
+        """Launch, copy back, synchronise -> (n_channels, n) NumPy array.  Big results live in a
+        page-locked block from the library's cache (`pinned_empty`): no page faults, DMA straight into
+        it, and for a single channel the copy overlaps the kernel part by part."""
         dtype = np.dtype(dtype)
-        out = np.empty((self.n_channels, self.n), dtype=dtype)
+        out = pinned_empty((self.n_channels, self.n), dtype)
         if out.size:
             check(lib().wfk_plan_run_host(self._h, out.ctypes.data, self.n,
                                           _KIND_OF[dtype]))
         return out
+
+    def run_host_into(self, out: np.ndarray):
+        """Launch and copy straight into the caller's C-contiguous array of n_channels * n elements
+        (`Waveform.__call__(x, out=...)`): no temporary, no second pass over the data."""
+        if out.size != self.n_channels * self.n or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError('out must be a writeable C-contiguous array of n_channels * n elements')
+        if out.size:
+            check(lib().wfk_plan_run_host(self._h, out.ctypes.data, self.n, _KIND_OF[out.dtype]))
+        return out
+
+
+PINNED_MIN_BYTES = 4 << 20
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """np.empty, but results of >= 4 MB are backed by a page-locked block from the library's cache
+    (wfk_host_alloc); the block goes back to the cache when the array and all its views are gone.
+    Falls back to an ordinary array when pinned memory is not to be had."""
+    import weakref
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    if nbytes < PINNED_MIN_BYTES:
+        return np.empty(shape, dtype=dtype)
+    p = C.c_void_p()
+    if lib().wfk_host_alloc(C.byref(p), nbytes) != 0 or not p.value:
+        return np.empty(shape, dtype=dtype)
+    buf = (C.c_byte * nbytes).from_address(p.value)
+    weakref.finalize(buf, lib().wfk_host_free, p.value)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 class FirPlan:

@@ -4,6 +4,7 @@
 // wfk_plan_launch() only fills a KArgs struct and launches: no allocation, no sync.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -331,13 +332,21 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   return name.c_str();
 }
 
-int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind, uint32_t flags,
-                    void* hip_stream) {
+// Launch the plan, or part `part` of `nparts` of it (single-channel plans only: the part's chunks are
+// a contiguous sample range, returned in *s_lo / *s_hi).  nparts == 1: everything.
+static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind, uint32_t flags,
+                            void* hip_stream, int part, int nparts, int64_t* s_lo, int64_t* s_hi) {
   if (!p || (!out_dev && p->h.n > 0)) return fail(WFK_EINVAL, "null plan or output");
   if (!p->on_device)
     return fail(WFK_EHIP, "plan has no device tables (no HIP device was visible at plan creation)");
   if (ch_stride < p->h.n) return fail(WFK_EINVAL, "ch_stride smaller than samples per channel");
+  if (s_lo) { *s_lo = 0; *s_hi = p->h.n; }
   if (p->h.n == 0 || p->h.n_channels == 0) return WFK_OK;
+  if (nparts > 1 && (p->h.n_channels != 1 || p->h.mixed)) return fail(WFK_EINVAL, "partial launch of a multi-channel or mixed plan");
+  auto sub = [&](int64_t total, int64_t& base, int64_t& count) {
+    base = total * part / nparts;
+    count = total * (part + 1) / nparts - base;
+  };
   if (p->h.shortp) {
     SArgs sa{};
     sa.channels = p->d_channels;
@@ -348,13 +357,19 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
     sa.ch_stride = ch_stride;
     sa.n_units = (int64_t)p->h.s_units.size();
     sa.units_per_chunk = p->h.s_units_per_chunk;
-    sa.n_chunks = (sa.n_units + sa.units_per_chunk - 1) / sa.units_per_chunk;
+    const int64_t all = (sa.n_units + sa.units_per_chunk - 1) / sa.units_per_chunk;
+    sub(all, sa.chunk_base, sa.n_chunks);
     sa.accumulate = (flags & WFK_ACCUMULATE) ? 1 : 0;
     sa.lds_samples = p->h.s_lds_samples;
     sa.step = p->h.step;
+    if (s_lo && nparts > 1) {
+      const int64_t u0 = sa.chunk_base * sa.units_per_chunk, u1 = (sa.chunk_base + sa.n_chunks) * sa.units_per_chunk;
+      *s_lo = u0 < sa.n_units ? p->h.s_units[(size_t)u0].j0 : p->h.n;
+      *s_hi = u1 < sa.n_units ? p->h.s_units[(size_t)u1].j0 : p->h.n;
+    }
     if (hip_stream) p->async_launch = true;
     std::string serr;
-    const int src = wfk_launch_short(sa, out_kind, hip_stream, serr);
+    const int src = sa.n_chunks > 0 ? wfk_launch_short(sa, out_kind, hip_stream, serr) : WFK_OK;
     if (src) return fail(src, serr);
     if (!p->h.mixed) return WFK_OK;
   }
@@ -408,11 +423,26 @@ int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind,
     if (rc) return fail(rc, err);
     a.mixed = 1;   // ... then the pieces with generic terms
   }
+  if (nparts > 1) {
+    const int64_t all = a.n_chunks;
+    sub(all, a.chunk_base, a.n_chunks);
+    const int64_t tile = (int64_t)(p->h.lean ? 64 : WFK_WG) * p->h.ns, span = tile * a.tiles_per_chunk;
+    if (s_lo) {
+      *s_lo = std::min<int64_t>(p->h.n, a.chunk_base * span);
+      *s_hi = std::min<int64_t>(p->h.n, (a.chunk_base + a.n_chunks) * span);
+    }
+    if (a.n_chunks == 0) return WFK_OK;
+  }
   rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.ns, p->h.lean,
                           p->h.n_generic > 0,
                           p->h.n_direct > 0,
                           hip_stream, err);
   return rc ? fail(rc, err) : WFK_OK;
+}
+
+int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind, uint32_t flags,
+                    void* hip_stream) {
+  return plan_launch_part(p, out_dev, ch_stride, out_kind, flags, hip_stream, 0, 1, nullptr, nullptr);
 }
 
 static size_t elem_size(int kind) {
@@ -424,6 +454,100 @@ static size_t elem_size(int kind) {
     default: return 0;
   }
 }
+
+// ---- pinned host blocks ---------------------------------------------------------------------
+// Results of the drop-in calls (Waveform.__call__ / sample, reference waveform.py:529-563) are NumPy
+// arrays of up to 80 MB.  A fresh pageable array costs a page fault per 4 KB while the copy lands in
+// it (3 ms per 80 MB) and as much again when it is freed; a pinned block from this cache costs
+// neither, takes the DMA directly, and lets the copy of one part overlap the kernel of the next.
+extern "C++" {
+namespace {
+struct HostBlockCache {
+  static constexpr size_t kMinBlock = size_t(1) << 16;
+  static constexpr size_t kMaxCachedTotal = size_t(1) << 30;     // parked blocks
+  static constexpr size_t kMaxLive = size_t(6) << 30;            // handed out + parked
+  std::mutex mu;
+  std::map<size_t, std::vector<void*>> free_;
+  std::map<void*, size_t> handed_;
+  size_t cached = 0, live = 0;
+};
+HostBlockCache& host_cache() {
+  static HostBlockCache* c = new HostBlockCache();
+  return *c;
+}
+}  // namespace
+}  // extern "C++"
+
+int wfk_host_alloc(void** host_ptr, size_t bytes) {
+  if (!host_ptr) return fail(WFK_EINVAL, "null host_ptr");
+  HostBlockCache& hc = host_cache();
+  size_t b = HostBlockCache::kMinBlock;
+  while (b < bytes) b <<= 1;
+  if (bytes > (size_t(1) << 28)) b = (bytes + (size_t(1) << 24) - 1) & ~((size_t(1) << 24) - 1);   // big ones: 16 MB steps
+  {
+    std::lock_guard<std::mutex> g(hc.mu);
+    auto it = hc.free_.find(b);
+    if (it != hc.free_.end() && !it->second.empty()) {
+      *host_ptr = it->second.back();
+      it->second.pop_back();
+      hc.cached -= b;
+      hc.handed_[*host_ptr] = b;
+      return WFK_OK;
+    }
+    if (hc.live + b > HostBlockCache::kMaxLive) return fail(WFK_ENOMEM, "pinned host memory budget exhausted");
+  }
+  void* ptr = nullptr;
+  if (hipHostMalloc(&ptr, b, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(WFK_ENOMEM, "hipHostMalloc failed");
+  }
+  std::lock_guard<std::mutex> g(hc.mu);
+  hc.live += b;
+  hc.handed_[ptr] = b;
+  *host_ptr = ptr;
+  return WFK_OK;
+}
+
+int wfk_host_free(void* host_ptr) {
+  if (!host_ptr) return WFK_OK;
+  HostBlockCache& hc = host_cache();
+  size_t b = 0;
+  {
+    std::lock_guard<std::mutex> g(hc.mu);
+    auto it = hc.handed_.find(host_ptr);
+    if (it == hc.handed_.end()) return fail(WFK_EINVAL, "wfk_host_free: not a wfk_host_alloc block");
+    b = it->second;
+    hc.handed_.erase(it);
+    if (hc.cached + b <= HostBlockCache::kMaxCachedTotal) {
+      hc.free_[b].push_back(host_ptr);
+      hc.cached += b;
+      return WFK_OK;
+    }
+    hc.live -= b;
+  }
+  (void)hipHostFree(host_ptr);
+  return WFK_OK;
+}
+
+extern "C++" {
+namespace {
+// two streams and a few events per device for wfk_plan_run_host's kernel / copy pipeline (created once)
+struct HostPipe {
+  std::mutex mu;
+  hipStream_t compute = nullptr, copy = nullptr;
+  hipEvent_t ev[8] = {};
+  bool ok = false, tried = false;
+};
+HostPipe& host_pipe(int dev) {
+  static std::mutex m;
+  static std::map<int, HostPipe*> pipes;
+  std::lock_guard<std::mutex> g(m);
+  HostPipe*& p = pipes[dev];
+  if (!p) p = new HostPipe();
+  return *p;
+}
+}  // namespace
+}  // extern "C++"
 
 int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_kind) {
   if (!p) return fail(WFK_EINVAL, "null plan");
@@ -441,6 +565,48 @@ int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_ki
     int sdev = 0;
     HIP_TRY(dev_cache().get(bytes, &p->d_scratch, &p->scratch_cap, &sdev));
     p->scratch_bytes = bytes;
+  }
+  // Pipeline (single-channel plans into PINNED memory, wfk_host_alloc blocks: the big drop-in calls): the
+  // output is evaluated in kParts launches on one stream and copied part by part on another, so all but
+  // the first part's kernel time hides behind the copies.
+  constexpr int kParts = 4;
+  bool pinned = false;
+  {
+    std::lock_guard<std::mutex> g(host_cache().mu);
+    auto it = host_cache().handed_.upper_bound(out_host);
+    if (it != host_cache().handed_.begin()) {
+      --it;
+      pinned = (const char*)out_host >= (const char*)it->first &&
+               (const char*)out_host + bytes <= (const char*)it->first + it->second;
+    }
+  }
+  if (pinned && p->h.n_channels == 1 && !p->h.mixed && bytes >= (size_t(8) << 20)) {
+    HostPipe& hp = host_pipe(p->dev);
+    std::lock_guard<std::mutex> g(hp.mu);
+    if (!hp.tried) {
+      hp.tried = true;
+      hp.ok = hipStreamCreateWithFlags(&hp.compute, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&hp.copy, hipStreamNonBlocking) == hipSuccess;
+      for (int k = 0; k < kParts && hp.ok; ++k)
+        hp.ok = hipEventCreateWithFlags(&hp.ev[k], hipEventDisableTiming) == hipSuccess;
+      if (!hp.ok) (void)hipGetLastError();
+    }
+    if (hp.ok) {
+      for (int k = 0; k < kParts; ++k) {
+        int64_t lo = 0, hi = 0;
+        int rc = plan_launch_part(p, p->d_scratch, p->h.n, out_kind, 0, hp.compute, k, kParts, &lo, &hi);
+        if (rc) { (void)hipStreamSynchronize(hp.compute); (void)hipStreamSynchronize(hp.copy); return rc; }
+        HIP_TRY(hipEventRecord(hp.ev[k], hp.compute));
+        HIP_TRY(hipStreamWaitEvent(hp.copy, hp.ev[k], 0));
+        if (hi > lo)
+          HIP_TRY(hipMemcpyAsync((char*)out_host + (size_t)lo * es, (const char*)p->d_scratch + (size_t)lo * es,
+                                 (size_t)(hi - lo) * es, hipMemcpyDeviceToHost, hp.copy));
+      }
+      HIP_TRY(hipStreamSynchronize(hp.copy));
+      HIP_TRY(hipStreamSynchronize(hp.compute));
+      p->async_launch = false;
+      return WFK_OK;
+    }
   }
   int rc = wfk_plan_launch(p, p->d_scratch, p->h.n, out_kind, 0, nullptr);
   if (rc) return rc;

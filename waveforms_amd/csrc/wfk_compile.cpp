@@ -1274,7 +1274,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   if (shortm) {
     // Mostly pieces the short tier cannot take (e.g. carriers that need the lean kernel's grid-rounding
     // correction far from t = 0): the standard tiers serve the whole plan better
-    if (n_foreign_samples > n_short_samples) return WFK_RETRY_STD;
+    if (n_foreign_samples > n_short_samples || (n_short_pieces == 0 && n_foreign_pieces > 0)) return WFK_RETRY_STD;
     H.shortp = true;
     H.lean = false;
     H.mixed = n_foreign_pieces > 0;       // foreign pieces: a second launch of the general kernel

@@ -193,6 +193,7 @@ struct SArgs {                // short-tier launch (wfk_short.hip)
   int64_t ch_stride;          // elements
   int64_t n_units;
   int64_t n_chunks;           // workgroups with work; the grid is rounded up to a multiple of 8
+  int64_t chunk_base;         // first chunk of this launch (a launch may cover a sub-range: wfk_plan_run_host's pipeline)
   int32_t units_per_chunk;
   int32_t accumulate;
   int32_t lds_samples;        // largest n_samples of a unit with slots
@@ -211,7 +212,8 @@ struct KArgs {
   int64_t ch_stride;           // elements
   int64_t n;                   // samples per channel
   int64_t chunks_per_ch;
-  int64_t n_chunks;            // n_channels * chunks_per_ch; the grid is rounded up to 8 * ceil(n_chunks / 8)
+  int64_t n_chunks;            // chunks of this launch (all: n_channels * chunks_per_ch); the grid is rounded up to 8 * ceil(n_chunks / 8)
+  int64_t chunk_base;          // first chunk of this launch (sub-range launches: wfk_plan_run_host's pipeline)
   int32_t tiles_per_chunk;     // workgroup tiles per workgroup
   int32_t accumulate;
   double t0, step, last;

@@ -868,7 +868,8 @@ __device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel
     const int o = lane + 64 * k;
     if (PLAIN || (o >= lo_l && o < hi_l)) {
       T v = acc[k];
-      T vi = CPLX ? acci[k] : (T)0;
+      T vi = (T)0;
+      if constexpr (CPLX) vi = acci[k];
       if (clip) {
         if constexpr (CPLX) clip_np_cplx(v, vi, lo, hi);
         else v = clip_np(v, lo, hi);
@@ -915,7 +916,7 @@ __device__ __forceinline__ int64_t xcd_chunk(const KArgs& a) {
   const int64_t b = blockIdx.x;
   const int64_t per = (a.n_chunks + 7) >> 3;
   const int64_t c = (b & 7) * per + (b >> 3);
-  return c < a.n_chunks ? c : -1;
+  return c < a.n_chunks ? a.chunk_base + c : -1;
 }
 
 // ---- lean kernel: fully fused plans ----------------------------------------------------
@@ -1211,7 +1212,7 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
 
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns, bool lean,
                        bool generic, bool direct, void* stream, std::string& err) {
-  if (a.n_chunks != (int64_t)n_channels * a.chunks_per_ch) { err = "n_chunks mismatch"; return WFK_EINVAL; }
+  if (a.chunk_base < 0 || a.chunk_base + a.n_chunks > (int64_t)n_channels * a.chunks_per_ch) { err = "chunk range outside the plan"; return WFK_EINVAL; }
   const int64_t blocks = ((a.n_chunks + 7) >> 3) << 3;   // see xcd_chunk()
   if (blocks == 0) return WFK_OK;
   if (blocks > 0x7fffffffLL) { err = "grid too large"; return WFK_EINVAL; }

@@ -286,8 +286,9 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
   // XCD-aware chunk map (workgroup b runs on XCD b % 8): XCD x walks the x-th contiguous eighth
   const int64_t b = blockIdx.x;
   const int64_t per = (a.n_chunks + 7) >> 3;
-  const int64_t chunk = (b & 7) * per + (b >> 3);
-  if (chunk >= a.n_chunks) return;
+  const int64_t lchunk = (b & 7) * per + (b >> 3);
+  if (lchunk >= a.n_chunks) return;
+  const int64_t chunk = a.chunk_base + lchunk;
   const int64_t u0 = chunk * a.units_per_chunk;
   const int64_t u1 = u0 + a.units_per_chunk < a.n_units ? u0 + a.units_per_chunk : a.n_units;
   const int64_t ulast = a.n_units - 1;
