@@ -1,0 +1,123 @@
+"""Fused LINEAR CHIRP op of the lean kernel (family 2): sin(phi0 + 2 pi (a u^2 + f0 u)), reference
+_waveform.pyx:323-324, against the C oracle (libm sin per sample) -- alone, under envelopes, multiplied
+with carriers (product-to-sum keeps the phase quadratic), with polynomial factors, complex amplitudes,
+clip / accumulate, in float; and the plans that must NOT take it (tlist mode, pieces with generic terms,
+short pieces, plans with corrected carriers)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+import waveforms_amd as wf
+from oracle import c_oracle
+from waveforms_amd import _engine, _flatten, workloads as wl
+
+pytestmark = pytest.mark.gpu
+pi = np.pi
+
+
+def _check(w, grid, tol=1e-9, want_kernel='wfk_sample_lean<double,false,16,false,2>', cplx=False):
+    prog = _flatten.flatten([w] if not isinstance(w, list) else w)
+    g = _flatten.grid_from_desc(grid)
+    plan = _engine.Plan(prog, grid=g)
+    if want_kernel is not None:
+        assert plan.kernel_name(np.complex128 if cplx else np.float64) == want_kernel.replace('double,false', 'double,true' if cplx else 'double,false'), plan.kernel_name()
+    ora = c_oracle.eval_grid(prog, g, cplx)
+    got = plan.run_host(np.complex128 if cplx else np.float64)
+    pk = max(1.0, float(np.abs(ora).max()))
+    err = float(np.max(np.abs(got - ora)))
+    assert err <= tol * pk, err
+    g32 = plan.run_host(np.complex64 if cplx else np.float32)
+    assert np.max(np.abs(g32 - ora)) <= 3e-5 * pk
+    return plan, err
+
+
+GRID = ('linspace', 0.0, 4e-6, 2_000_003, False)
+
+
+def test_bare_chirps_and_sums():
+    w = wf.chirp(1e8, 3e8, 1e-6) >> 0.2e-6
+    plan, err = _check(w, GRID)
+    assert plan.info.n_direct == 0 and plan.info.n_generic == 0
+    assert err <= 2e-11                                  # (measured; the budget is 1e-9)
+    # down-chirp, phase offset, several back to back, amplitudes
+    ws = wf.zero()
+    for k in range(6):
+        ws = ws + (0.3 + 0.1 * k) * (wf.chirp(2.5e8 - 2e7 * k, 0.4e8 + 1e7 * k, 0.55e-6, 0.3 * k) >> (0.1e-6 + 0.6e-6 * k))
+    _check(ws, GRID)
+
+
+def test_chirp_times_envelopes_carriers_polynomials():
+    c = wf.chirp(0.5e8, 2.5e8, 1.5e-6) >> 0.5e-6
+    _check(c * (wf.gaussian(1.2e-6) >> 1.25e-6), GRID)                                      # Gaussian envelope
+    _check(c * wf.cos(2 * pi * 40e6, 0.7), GRID)                                            # x carrier: two chirps
+    _check(c * (wf.gaussian(1.0e-6) >> 1.2e-6) * wf.cos(2 * pi * 25e6) * wf.sin(2 * pi * 10e6), GRID)
+    _check((c * (wf.exp(-2e6) >> 0.5e-6)), GRID)                                            # exponential envelope
+    _check(c * wf.poly([0.5, 2e5, -3e11]) , GRID)                                           # polynomial factor
+    _check(c * (wf.chirp(1e7, 6e7, 1.5e-6) >> 0.5e-6), GRID)                                # chirp x chirp
+    I, Q = wf.mixing(c * (wf.gaussian(1.2e-6) >> 1.25e-6), freq=30e6, phase=0.4)            # both quadratures
+    _check(I - 0.5 * Q, GRID)
+
+
+def test_complex_clip_accumulate_batches():
+    c = wf.chirp(0.5e8, 2.5e8, 1.5e-6) >> 0.5e-6
+    _check((1 + 2j) * c + 0.5j * (c >> 2e-6), GRID, cplx=True)
+    w = 1.5 * c
+    w.min, w.max = -0.8, 1.1
+    _check(w, GRID)
+    chans = [(0.2 + 0.1 * k) * (wf.chirp(1e8 + 1e7 * k, 3e8, 1e-6) >> (0.1e-6 * k)) + 0.3 * (wf.gaussian(0.4e-6) >> 3e-6) * wf.cos(2 * pi * 1e8)
+             for k in range(5)]
+    prog = _flatten.flatten(chans)
+    g = _flatten.grid_from_desc(GRID)
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.kernel_name().endswith(',false,2>')
+    ora = c_oracle.eval_grid(prog, g)
+    n = plan.n
+    buf = _engine.DeviceBuffer(5 * n * 8)
+    buf.upload(np.full((5, n), 1.0))
+    plan.launch(buf.ptr, n, _engine.OUT_F64, accumulate=True)
+    _engine.sync()
+    assert np.max(np.abs(buf.download((5, n), np.float64) - 1.0 - ora)) <= 1e-9
+    buf.close()
+
+
+def test_plans_that_do_not_take_the_fused_chirp():
+    c = wf.chirp(1e8, 3e8, 1e-6) >> 0.2e-6
+    # a generic factor in the same piece: the piece is rebuilt without the fused chirp (general kernel)
+    w = c * (wf.sinc(2e6) >> 0.7e-6)
+    plan, _ = _check(w, GRID, want_kernel=None)
+    assert 'lean' not in plan.kernel_name() and plan.info.n_generic > 0
+    # tlist mode: libm everywhere
+    t = np.sort(np.random.default_rng(3).uniform(0, 4e-6, 50001))
+    prog = _flatten.flatten([c])
+    got = _engine.Plan(prog, t=t).run_host(np.float64)[0]
+    assert np.max(np.abs(got - c_oracle.eval_tlist(prog, t)[0])) <= 1e-11
+    # switched off: same numbers through the direct tier
+    os.environ['WFK_DISABLE_CHIRP'] = '1'
+    try:
+        plan2, _ = _check(c, GRID, want_kernel=None)
+        assert plan2.info.n_direct > 0
+    finally:
+        del os.environ['WFK_DISABLE_CHIRP']
+    # the other families keep their own instantiations
+    assert _engine.Plan(_flatten.flatten([wl.c2_channel(wf)]), grid=_flatten.grid_from_desc(wl.c2_grid(10**6))).kernel_name() \
+        == 'wfk_sample_lean<double,false,16,false,0>'
+    flat = wf.square(300e-9, edge=40e-9) * wf.cos(2 * pi * 1e8) >> 1e-6
+    assert _engine.Plan(_flatten.flatten([flat]), grid=_flatten.grid_from_desc(GRID)).kernel_name().endswith(',false,1>')
+
+
+def test_reference_chirp_cases_and_goldens():
+    SAMPLES = golden_io.npz('samples.npz')
+    for name in ('chirp_lin', 'chirp_exp', 'chirp_hyp'):
+        build, grid = cases.CASES[name]
+        w = build(wf)
+        got = w(wl.make_grid(grid))
+        want = SAMPLES[name + '.y']
+        assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, np.abs(want).max())
+    # fine grid of the same linear chirp: the fused op, against the reference's closed form
+    t = np.linspace(0, 10, 4_000_001)
+    got = wf.chirp(1, 2, 10, 4, 'linear')(t)
+    want = np.where((t >= 0) & (t < 10), np.sin(4 + 2 * np.pi * ((2 - 1) / (2 * 10) * t**2 + 1 * t)), 0.0)
+    assert np.max(np.abs(got - want)) <= 1e-9

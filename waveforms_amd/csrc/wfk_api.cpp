@@ -319,7 +319,9 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
     return name.c_str();
   }
   const std::string lean_name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +
-      (h.n_corr > 0 && out_kind != WFK_OUT_F32 && out_kind != WFK_OUT_C64 ? ",true>" : ",false>");
+      (h.n_corr > 0 && out_kind != WFK_OUT_F32 && out_kind != WFK_OUT_C64
+           ? std::string(",true,") + std::to_string(h.lean_fam >= 1 ? 1 : 0) + ">"
+           : std::string(",false,") + std::to_string(h.lean_fam) + ">");
   if (!h.tlist && h.lean) {
     name = lean_name;
   } else {
@@ -394,6 +396,7 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
   a.lean_par = p->h.lean_par;
   a.lean_ops = p->h.lean_ops;
   a.corr = p->h.n_corr > 0 ? 1 : 0;
+  a.lean_fam = p->h.lean_fam;
   a.reseed = WFK_LEAN_RESEED;
   // float outputs of the lean launch: longer chunks, rarer exact reseeds (HostPlan::f32_*)
   const bool f32_lean = (out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64) && p->h.f32_tiles_per_chunk > 0;

@@ -100,6 +100,9 @@ struct FceGroup {
   bool envmul = false;          // pseudo-op: multiply the accumulators by the shared Gaussian envelope
   bool erfmul = false;          // pseudo-op: multiply them by m0 + m1 erf((t - sg) / sigma) (flat-top edge)
   double m0 = 0, m1 = 1;
+  long double K = 0;            // chirp: the phase is K t'^2 + W t' - psi_ref (W, psi_ref as for a plain carrier)
+  bool chirp = false;
+  double tref = 0;              // chirp: reference time inside the piece (the device works in t' - tref)
   bool corr = false;            // carrier needs the per-sample rounding correction (WFK_FCE_PACK bit 7)
   double wm = 0, sm = 0;        // corr: the reference COS factor (w, shift) whose rounded phase fl(w*fl(x-shift)) is mimicked
 };
@@ -116,6 +119,8 @@ struct BlockBuilder {
 };
 
 }  // namespace
+
+static thread_local bool g_no_chirp = false;   // second compile of a plan that mixes corrected carriers and chirps
 
 // want_short: -1 = decide from the mean live piece length (grid plans), 0 = never.  Returns
 // WFK_RETRY_STD when the short geometry was chosen but some piece cannot run in it.
@@ -152,6 +157,14 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     if (compile_impl(P, grid, tlist, n_tlist, S, e2, true) == WFK_OK && (S.lean || S.mixed)) H = std::move(S);
   }
   if (rc == WFK_OK && !H.shortp && H.n_corr > 0 && !H.lean && !H.mixed) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
+  if (rc == WFK_OK && !H.shortp && H.n_corr > 0 && H.lean_fam >= 2) {
+    // corrected carriers (far from t = 0) and fused chirps in one plan: the lean kernel is not instantiated
+    // for that combination; the chirps take the general path
+    g_no_chirp = true;
+    rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
+    if (rc == WFK_OK && H.n_corr > 0 && !H.lean && !H.mixed) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
+    g_no_chirp = false;
+  }
   return rc;
 }
 
@@ -347,6 +360,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const char* nocorr_env = std::getenv("WFK_DISABLE_CORR");
   const bool corr_enabled = allow_corr && !shortm && !(nocorr_env && nocorr_env[0] == '1');
   bool piece_corr_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
+  const char* nochirp_env = std::getenv("WFK_DISABLE_CHIRP");
+  const bool chirp_base = !H.tlist && ns_override == 0 && !g_no_chirp && !(nochirp_env && nochirp_env[0] == '1');
+  bool piece_chirp_ok = true;  // likewise: the fused chirp op exists in the lean kernel only
+  bool chirp_ok = false;
   auto corr_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {
     const double x = std::fabs(rate) * grid_jitter(s0, s1);
     return corr_enabled && piece_corr_ok && std::isfinite(x) && 2.0 * x * x <= 1e-11;   // (d <= ~2 W e)
@@ -488,7 +505,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (tab_off & 1) ++tab_off;  // 16-byte aligned tables
     for (auto& r : B.table_refs) B.body[r.first] = (double)(tab_off + (size_t)r.second * 2 * (NS + 1));
     for (size_t at : B.fce_ats) {   // the table offset also travels in the packed op word ...
-      B.body[at + WFK_FCE_DEG] += 256.0 * B.body[at + WFK_FCE_TAB];
+      if (!(((int64_t)B.body[at + WFK_FCE_DEG]) & WFK_FCE_CHIRP))      // (a chirp has no table: the slot holds its constant phasor)
+        B.body[at + WFK_FCE_DEG] += 256.0 * B.body[at + WFK_FCE_TAB];
       // ... which the device reads as a 32-bit integer (WFK_FCE_WORD): low half of the slot
       const uint64_t word = (uint32_t)(int64_t)B.body[at + WFK_FCE_DEG];
       std::memcpy(&B.body[at + WFK_FCE_DEG], &word, sizeof word);
@@ -537,7 +555,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     bool has_lin = false, has_env = false, env32 = false;
     double slin = 0, sigma = 0, sg = 0;
     double first_cos_shift = 0;
-    struct Car { long double c, W, Psi; };   // c * cos(W t' - Psi),  t' = t - tshift
+    struct Car { long double c, W, Psi, K = 0.0L; };   // c * cos(K t'^2 + W t' - Psi),  t' = t - tshift
     struct ExpV { long double c, a, b; };    // c * exp(a t' + b): EXP factors, COSH / SINH as two of them
     std::vector<ExpV> evs = {{1.0L, 0.0L, 0.0L}};
     bool has_expf = false;
@@ -554,8 +572,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       std::vector<Car> nx;
       for (const Car& q : cars)
         for (const Car& r : f) {
-          nx.push_back({q.c * r.c / 2, q.W + r.W, q.Psi + r.Psi});
-          nx.push_back({q.c * r.c / 2, q.W - r.W, q.Psi - r.Psi});
+          nx.push_back({q.c * r.c / 2, q.W + r.W, q.Psi + r.Psi, q.K + r.K});
+          nx.push_back({q.c * r.c / 2, q.W - r.W, q.Psi - r.Psi, q.K - r.K});
         }
       cars.swap(nx);
       return true;
@@ -637,6 +655,22 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           has_expf = true;
           break;
         }
+        case WFK_LINEARCHIRP: {
+          // sin(phi0 + 2 pi (a u^2 + f0 u)), a = (f1 - f0) / (2 T), u = t' - shift (reference
+          // _waveform.pyx:323-324) = cos(K t'^2 + W t' - Psi): a carrier whose phase is quadratic.  Fused
+          // where the piece can run on the lean kernel (its chirp family: the phasor advances by a phasor
+          // that itself advances by a constant -- the complex twin of the Gaussian recurrence).
+          if (!chirp_ok || pw != 1.0 || !std::isfinite(sh)) return false;
+          for (int i = 0; i < 4; ++i)
+            if (!std::isfinite(a[i])) return false;
+          if (a[2] == 0.0) return false;
+          const long double Kq = 2 * PI * ((long double)a[1] - a[0]) / (2 * (long double)a[2]);
+          const long double W0 = 2 * PI * (long double)a[0];
+          ++ncos;
+          ++ncos;      // (never a single COS factor: the group's phase reference is the term's own)
+          if (!times({{1.0L, W0 - 2 * Kq * sh, -(Kq * sh * sh - W0 * sh + (long double)a[3] - PI / 2), Kq}})) return false;
+          break;
+        }
         case WFK_DRAG: {
           // sin^2(o tau) cos(wt) + Oy sin(wt),  tau = u - t0,  Oy = -b o sin(2 o tau)
           //   = cos(wt)/2 + (-1/4 + b o/2) cos(wt + 2 o tau) + (-1/4 - b o/2) cos(wt - 2 o tau)
@@ -669,12 +703,20 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // stage the contributions; commit only if every carrier finds/creates a group
     std::vector<FceGroup> staged = groups;
     bool any_corr = false;
-    for (const Car& q : cars)
+    const double tpa = ax.at(s0) - tshift, tpb = ax.at(s1 - 1) - tshift;   // the piece on the channel's own axis
+    for (const Car& q : cars) {
+      if (q.K != 0.0L) {
+        // a chirp: largest instantaneous frequency over the piece; no rounding correction for it
+        const double wmax = (double)std::max(fabsl(q.W + 2 * q.K * tpa), fabsl(q.W + 2 * q.K * tpb));
+        if (!std::isfinite(wmax) || !rate_safe(wmax, s0, s1)) return false;
+        continue;
+      }
       if (!rate_safe((double)q.W, s0, s1)) {
         if (shortm) H.short_needs_corr = true;
         if (!corr_safe((double)q.W, s0, s1)) return false;
         any_corr = true;
       }
+    }
     // the term's weight and the reference factor whose rounding it mimics (see corr_safe)
     double wm = 0, sm = 0, weight = 0;
     if (any_corr) {
@@ -732,8 +774,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     const bool imag = part == 1;
     for (Car q : cars) {
       q.c *= amp_part;
-      if (q.W < 0) { q.W = -q.W; q.Psi = -q.Psi; }
+      if (q.W < 0 || (q.W == 0 && q.K < 0)) { q.W = -q.W; q.Psi = -q.Psi; q.K = -q.K; }
       const double W = (double)q.W;
+      const bool is_chirp = q.K != 0.0L;
       // (a sum/difference frequency is rounded to double: relative error <= 2^-53, the
       //  same class as the reference's own rounding of w*t)
       FceGroup* G = nullptr;
@@ -741,7 +784,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       for (const CosF& cf : cosf) thm = std::max(thm, cf.thmax);
       const bool heavy = 2.3e-16 * thm * weight > WFK_JITTER_TOL;   // its own phase rounding must be mimicked
       for (FceGroup& g : staged)
-        if (g.W == W && g.imag == imag && g.has_env == has_env && g.has_exp == has_exp &&
+        if (g.W == W && (double)g.K == (double)q.K && g.imag == imag && g.has_env == has_env && g.has_exp == has_exp &&
             (!has_env || (g.sigma == sigma && g.sg == sg))) {
           // a corrected group mimics ONE reference factor: a heavy term with another factor founds
           // its own group (same carrier, own op) instead of joining
@@ -754,10 +797,15 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         G = &staged.back();
         G->W = W; G->has_env = has_env; G->has_exp = has_exp; G->sigma = sigma; G->sg = sg; G->env32 = env32;
         G->imag = imag;
-        G->corr = W != 0.0 && !rate_safe(W, s0, s1);
+        G->K = q.K; G->chirp = is_chirp;
+        G->corr = !is_chirp && W != 0.0 && !rate_safe(W, s0, s1);
         G->wm = wm; G->sm = sm;
         G->sref = W == 0.0 ? 0.0 : (ncos == 1 ? cs[0] : (double)(q.Psi / q.W));
         G->psi_ref = (long double)W * G->sref;
+        if (is_chirp) {      // (the founding term's own phase; reference time = middle of the piece)
+          G->sref = 0.0; G->psi_ref = q.Psi;
+          G->tref = 0.5 * (tpa + tpb);
+        }
         if (G->corr && ncos != 1) {
           // A sum / difference frequency is rounded to double: (W_exact - W) * (x - s_ref) must stay
           // small, so a corrected carrier takes its reference time INSIDE the piece (with s_ref =
@@ -771,7 +819,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       }
       if (has_env && !env32) G->env32 = false;
       long double ca, cb;
-      if (W == 0.0) { ca = q.c * cosl(q.Psi); cb = 0.0L; }
+      if (W == 0.0 && !is_chirp) { ca = q.c * cosl(q.Psi); cb = 0.0L; }
       else {
         const long double delta = G->psi_ref - q.Psi;   // cos(th_ref + delta)
         ca = q.c * cosl(delta);
@@ -814,7 +862,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     long double A0 = G.A[0], B0 = G.B[0];
     double sref = G.sref;
     int deg = G.deg;
-    if (G.deg == 0 && G.W != 0.0 && G.corr) {
+    if (G.chirp) {
+      if (B0 != 0.0L && deg == 0) deg = 1;   // (a chirp keeps A and B: its loop has no degree-0 form with a folded shift)
+    } else if (G.deg == 0 && G.W != 0.0 && G.corr) {
       // (corrected carriers keep A and B: the folded shift s_ref + phi/W would be ROUNDED to a
       //  double next to |s_ref| -- half an ulp of a time 100 s from the origin is 7e-15 s, 3e-9 rad
       //  under a 60 kHz carrier.  The degree-0 loop has no B term: such an op runs as degree 1.)
@@ -852,7 +902,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     rec[WFK_FCE_W] = G.W;
     rec[WFK_FCE_SREF] = sref;
     rec[WFK_FCE_SLIN] = G.has_lin ? G.slin : 0.0;
-    rec[WFK_FCE_DEG] = (double)(WFK_FCE_PACK(deg, G.W != 0.0 ? 1 : 0, G.imag ? 1 : 0,
+    rec[WFK_FCE_DEG] = (double)(WFK_FCE_PACK(deg, (G.W != 0.0 || G.chirp) ? 1 : 0, G.imag ? 1 : 0,
                                              G.envmul ? 3 : (G.has_env ? 1 : 0), G.env32 ? 1 : 0) |
                                 (G.corr ? 128 : 0));
     if (G.corr) ++H.n_corr;
@@ -874,12 +924,28 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
     }
     rec[WFK_FCE_D] = dstride;
+    if (G.chirp) {
+      // phase about tref:  K tau^2 + W' tau + phi0,  tau = t' - tref;  the per-stride rotation advances by
+      // the constant phasor exp(i 2 K D^2)
+      const long double PI2 = 6.283185307179586476925286766559005768L;
+      const long double tr = G.tref;
+      rec[WFK_FCE_W] = (double)((long double)G.W + 2 * G.K * tr);
+      rec[WFK_FCE_SREF] = G.tref;
+      rec[WFK_FCE_WM] = (double)G.K;
+      rec[WFK_FCE_SM] = (double)remainderl(G.K * tr * tr + (long double)G.W * tr - G.psi_ref, PI2);
+      const long double d2 = 2 * G.K * (long double)dstride * (long double)dstride;
+      rec[WFK_FCE_TAB] = (double)cosl(d2);
+      rec[WFK_FCE_F32OK] = (double)sinl(d2);
+      rec[WFK_FCE_DEG] += (double)WFK_FCE_CHIRP;
+    }
     {
-      // per-lane state of the lean kernel: a phasor (c, s) and / or a Gaussian (g, r), 1 KB each
-      const bool cs = G.W != 0.0, gr = G.has_env || G.envmul;
-      if (B.state_units + (cs ? 1 : 0) + (gr ? 1 : 0) <= 63) {
+      // per-lane state of the lean kernel: a phasor (c, s) and / or a Gaussian (g, r), 1 KB each (a chirp:
+      // the phasor, the phasor it advances by, then the envelope)
+      const bool cs = G.W != 0.0 || G.chirp, gr = G.has_env || G.envmul;
+      const int need = (cs ? 1 : 0) + (G.chirp ? 1 : 0) + (gr ? 1 : 0);
+      if (B.state_units + need <= 63) {
         rec[WFK_FCE_DEG] += (double)((B.state_units << 19) | (cs ? WFK_FCE_HAS_CS : 0) | (gr ? WFK_FCE_HAS_GR : 0));
-        B.state_units += (cs ? 1 : 0) + (gr ? 1 : 0);
+        B.state_units += need;
       } else {
         B.state_units = 1000;   // (a block this large is never lean)
       }
@@ -887,7 +953,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     size_t at = B.body.size();
     B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
     B.fce_ats.push_back(at);
-    if (G.W != 0.0) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
+    if (G.W != 0.0 && !G.chirp) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
   };
 
   // ---- short tier: compact op records (WFK_SH_*), referenced to the first sample of each stretch ----
@@ -1000,6 +1066,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       bool piece_lean = false;
       for (int attempt = 0; attempt < 2 && !live.empty(); ++attempt) {
         const int32_t corr_before = H.n_corr;
+        chirp_ok = chirp_base && piece_chirp_ok && !cur_short && can_fuse;
         D.flags |= WFK_PF_HAS_TERMS;
         BlockBuilder B;
         auto room_for = [&](size_t need) -> int {
@@ -1165,6 +1232,12 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           break;
         }
         piece_lean = generic.empty() && !groups.empty() && groups.size() <= WFK_LEAN_OPS;
+        bool piece_has_chirp = false;
+        int piece_fam = 0;          // lean kernel family the piece needs: 0 plain ops, 1 closing ops, 2 chirps
+        for (const FceGroup& G : groups) {
+          piece_has_chirp = piece_has_chirp || G.chirp;
+          piece_fam = std::max(piece_fam, G.chirp ? 2 : ((G.erfmul || G.envmul) ? 1 : 0));
+        }
         const int32_t piece_ops = (int32_t)groups.size();
         int32_t piece_units = 0;
         for (FceGroup& G : groups) {
@@ -1195,16 +1268,18 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         ++D.n_blk;
         piece_lean = piece_lean && D.n_blk == 1 && len <= lean_par_cap && piece_units <= 63;
         (void)piece_ops;
-        if (!piece_lean && H.n_corr > corr_before && attempt == 0) {
-          // roll back and build the piece again without corrected carriers
+        if (!piece_lean && (H.n_corr > corr_before || piece_has_chirp) && attempt == 0) {
+          // roll back and build the piece again without corrected carriers / fused chirps (lean kernel only)
           H.params.resize(snap.params); H.pool.resize(snap.pool);
           H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
           sampled_at = snap.sampled;
           D = D0;
           piece_corr_ok = false;
+          piece_chirp_ok = false;
           continue;
         }
-        if (piece_lean && !shortm) {   // (a short plan has no lean launch: its other pieces all go to the general kernel)
+        if (piece_lean && !shortm) {
+          H.lean_fam = std::max(H.lean_fam, piece_fam);   // (a short plan has no lean launch: its other pieces all go to the general kernel)
           D.flags |= WFK_PF_LEAN;
           ++n_lean_pieces;
           H.lean_ops = std::max<int32_t>(H.lean_ops, piece_units);
@@ -1215,6 +1290,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         break;
       }
       piece_corr_ok = true;
+      piece_chirp_ok = true;
       if (shortm) set_geom(true);
       // fuse adjacent zero pieces
       if (D.n_blk == 0 && (int32_t)H.pieces.size() > C.piece_begin &&

@@ -60,6 +60,8 @@
 #define WFK_FCE_STOFF(fl) ((((fl) >> 19) & 63) * 128)
 #define WFK_FCE_HAS_CS (1 << 25)
 #define WFK_FCE_HAS_GR (1 << 26)
+#define WFK_FCE_CHIRP (1 << 28)    // quadratic phase: W = W' (frequency at SREF = tref), WM = K, SM = phase at tref,
+                                   // TAB / F32OK = (cos, sin)(2 K D^2); state: (c, s), the step phasor (wc, ws), then (g, r)
 #define WFK_FCE_EXPENV (1 << 27)   // the envelope is exp(alpha (t - ref)): SIGMA = alpha, SG = ref, H = alpha * D, Q = 1
 #define WFK_FCE_A 5           // A0..A3
 #define WFK_FCE_B 9           // B0..B3
@@ -221,6 +223,7 @@ struct KArgs {
   int32_t lean_par, lean_ops;  // lean kernel: doubles of parameter block / units (128 doubles) of op state to reserve in LDS
   int32_t corr;                // plan holds carriers that need the grid-rounding correction (lean kernel variant)
   int32_t reseed;              // lean kernel: tiles between exact (libm) reseeds of the carried op state
+  int32_t lean_fam;            // lean kernel family (HostPlan::lean_fam)
   int32_t mixed;               // mixed plan: the lean kernel skips the pieces without WFK_PF_LEAN, the general
                                // kernel skips the lean and the zero pieces (two launches, one output)
 };
@@ -248,6 +251,9 @@ struct HostPlan {
   int32_t n_fast = 0, n_direct = 0, n_fused = 0, n_generic = 0;
   int32_t n_corr = 0;          // fused ops carrying the grid-rounding correction
   bool lean = false;           // wave-per-workgroup fused kernel (see WFK_LEAN_*)
+  int32_t lean_fam = 0;        // instantiation of that kernel the plan needs: 0 plain ops, 1 + closing ops (erf
+                               // edges, shared envelopes), 2 + chirps -- a shape added to one family cannot move
+                               // the code generation of the others
   bool mixed = false;          // lean pieces go to the lean kernel, the rest to the general kernel
   int32_t lean_tile = 0, lean_tiles_per_chunk = 1;   // mixed: the lean launch's own chunking
   int64_t lean_chunks_per_ch = 0;

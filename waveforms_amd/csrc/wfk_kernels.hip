@@ -808,6 +808,65 @@ __device__ __forceinline__ void fce_erfmul(const double* r, FceSeeds& sd, double
   sd.r = rr;
 }
 
+// ---- fused chirp op (lean kernel, family 2): E_k (A(u_k) cos th_k + B(u_k) sin th_k) with a QUADRATIC
+// phase, th(tau) = K tau^2 + W' tau + phi0 about tau = t' - tref (reference LINEARCHIRP,
+// _waveform.pyx:323-324, times whatever carriers the term multiplies it with).  Along a lane (stride D)
+//   z_{k+1} = z_k w_k,   w_{k+1} = w_k v,   v = exp(i 2 K D^2)  (constant, from the host)
+// -- the complex twin of the Gaussian recurrence: 8 flops per sample instead of a libm sin.
+struct ChirpSeeds { double c, s, wc, ws, g, r; };
+
+__device__ __attribute__((noinline)) ChirpSeeds chirp_seeds(double th, double dth, double ea, double eb, int env) {
+  ChirpSeeds o;
+  const double2 z = sincos_phase(th), w = sincos_phase(dth);
+  o.c = z.x; o.s = z.y; o.wc = w.x; o.ws = w.y;
+  o.g = 1.0; o.r = 1.0;
+  if (env) {
+    o.g = exp(ea);
+    o.r = exp(eb);
+  }
+  return o;
+}
+
+__device__ __forceinline__ ChirpSeeds chirp_make_seeds(const double* r, double x, int fl) {
+  const double tau = x - r[WFK_FCE_SREF], K = r[WFK_FCE_WM], W = r[WFK_FCE_W], D = r[WFK_FCE_D];
+  const double th = fma(K * tau, tau, fma(W, tau, r[WFK_FCE_SM]));
+  const double dth = D * fma(K, 2.0 * tau + D, W);                 // th(tau + D) - th(tau)
+  const double Hh = r[WFK_FCE_H];
+  if (fl & WFK_FCE_EXPENV)
+    return chirp_seeds(th, dth, r[WFK_FCE_SIGMA] * (x - r[WFK_FCE_SG]), Hh, (fl >> 4) & 3);
+  const double v = (x - r[WFK_FCE_SG]) / r[WFK_FCE_SIGMA];
+  return chirp_seeds(th, dth, -(v * v), -Hh * (2.0 * v + Hh), (fl >> 4) & 3);
+}
+
+// one chirp op over the wave tile; the state (z, w, g, r) is advanced by NS strides for the next tile
+template <typename T, int NS, bool ENV>
+__device__ __forceinline__ void chirp_loop(const double* r, ChirpSeeds& sd, double u0, T (&acc)[NS]) {
+  asm volatile("" : "+v"(u0) : : "memory");      // (see fce_loop: keeps the variants' prologues apart)
+  const double A0 = r[WFK_FCE_A], A1 = r[WFK_FCE_A + 1], A2 = r[WFK_FCE_A + 2], A3 = r[WFK_FCE_A + 3];
+  const double B0 = r[WFK_FCE_B], B1 = r[WFK_FCE_B + 1], B2 = r[WFK_FCE_B + 2], B3 = r[WFK_FCE_B + 3];
+  const double vc = r[WFK_FCE_TAB], vs = r[WFK_FCE_F32OK], D = r[WFK_FCE_D], q = r[WFK_FCE_Q];
+  double c = sd.c, s = sd.s, wc = sd.wc, ws = sd.ws, g = sd.g, rr = sd.r, u = u0;
+  WFK_EACH(NS, k)
+    const double pa = fma(fma(fma(A3, u, A2), u, A1), u, A0);
+    const double pb = fma(fma(fma(B3, u, B2), u, B1), u, B0);
+    double val = fma(pa, c, pb * s);
+    if constexpr (ENV) val *= g;
+    acc[k] += (T)val;
+    const double cn = fma(c, wc, -(s * ws));
+    s = fma(s, wc, c * ws);
+    c = cn;
+    const double wn = fma(wc, vc, -(ws * vs));
+    ws = fma(ws, vc, wc * vs);
+    wc = wn;
+    u += D;
+    if constexpr (ENV) {
+      g *= rr;
+      rr *= q;
+    }
+  WFK_END
+  sd.c = c; sd.s = s; sd.wc = wc; sd.ws = ws; sd.g = g; sd.r = rr;
+}
+
 template <typename T, int NS>
 __device__ __forceinline__ void apply_fce(const double* blk, const double* r, const KArgs& a,
                                           double tshift, int64_t j0, T (&acc)[NS]) {
@@ -926,7 +985,12 @@ __device__ __forceinline__ int64_t xcd_chunk(const KArgs& a) {
 // costs 4 FMAs per op per tile; exact libm seeds are taken when a piece is entered and
 // every WFK_LEAN_RESEED tiles, in a phase where no accumulator is live (so the libm call
 // does not inflate the kernel's register allocation).  No barriers between waves at all.
-template <typename T, bool CPLX, int NS, bool CORR>
+// FAM: op families compiled into this instantiation -- 0: carrier / envelope ops only (every BASELINE
+// config), 1: + the closing ops (erf edges, shared envelopes), 2: + chirps.  The host picks the smallest
+// family a plan needs, so a shape added to one family cannot move the register allocation and code
+// layout of the others (round 2 took the chirp op out again for exactly that: inlined into the one
+// kernel it cost the multi-tone workloads 4-9 %).
+template <typename T, bool CPLX, int NS, bool CORR, int FAM>
 #ifndef WFK_LEAN_WAVES
 #define WFK_LEAN_WAVES 3   // occupancy target (waves per SIMD) for the register allocator
 #endif
@@ -1001,6 +1065,15 @@ wfk_sample_lean(const KArgs a) {
           for (int op = 0; op < nops; ++op) {
             const double* srec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
             const int sfl = uni(WFK_FCE_WORD(srec));
+            if constexpr (FAM >= 2) {
+              if (sfl & WFK_FCE_CHIRP) {      // state: (c, s), the step phasor (wc, ws), then (g, r)
+                const ChirpSeeds cd = chirp_make_seeds(srec, x, sfl);
+                double* ct = s_st + WFK_FCE_STOFF(sfl) + lane;
+                ct[0] = cd.c; ct[64] = cd.s; ct[128] = cd.wc; ct[192] = cd.ws;
+                if (sfl & WFK_FCE_HAS_GR) { ct[256] = cd.g; ct[320] = cd.r; }
+                continue;
+              }
+            }
             const FceSeeds sd = fce_make_seeds<CORR>(srec, x, sfl);
             double* st = s_st + WFK_FCE_STOFF(sfl) + lane;
             if (sfl & WFK_FCE_HAS_CS) {
@@ -1035,6 +1108,26 @@ wfk_sample_lean(const KArgs a) {
           const int fl = uni(WFK_FCE_WORD(rec));        // packed op word: one 32-bit read for all flags
           // per-lane state: (c, s) and / or (g, r), 64 doubles each, only what the op has
           double* const st = s_st + WFK_FCE_STOFF(fl) + lane;
+          if constexpr (FAM >= 2) {
+            if (fl & WFK_FCE_CHIRP) {
+              ChirpSeeds cd;
+              cd.c = st[0]; cd.s = st[64]; cd.wc = st[128]; cd.ws = st[192];
+              cd.g = 1.0; cd.r = 1.0;
+              const bool cenv = (fl & WFK_FCE_HAS_GR) != 0;
+              if (cenv) { cd.g = st[256]; cd.r = st[320]; }
+              const double cu0 = x - rec[WFK_FCE_SLIN];
+              if (fl & 8) {
+                if constexpr (CPLX) {
+                  if (cenv) chirp_loop<T, NS, true>(rec, cd, cu0, acci); else chirp_loop<T, NS, false>(rec, cd, cu0, acci);
+                }
+              } else {
+                if (cenv) chirp_loop<T, NS, true>(rec, cd, cu0, acc); else chirp_loop<T, NS, false>(rec, cd, cu0, acc);
+              }
+              st[0] = cd.c; st[64] = cd.s; st[128] = cd.wc; st[192] = cd.ws;
+              if (cenv) { st[256] = cd.g; st[320] = cd.r; }
+              continue;
+            }
+          }
           double* const stg = st + ((fl & (WFK_FCE_HAS_CS | WFK_FCE_HAS_GR)) == (WFK_FCE_HAS_CS | WFK_FCE_HAS_GR) ? 128 : 0);
           // (all four loads issue at once whatever the op has: a pair it lacks reads the pair it has,
           //  and is never used or written back)
@@ -1042,9 +1135,11 @@ wfk_sample_lean(const KArgs a) {
           sd.s = st[64];
           sd.g = stg[0];
           sd.r = stg[64];
-          if (((fl >> 4) & 3) == 3) {
-            if (fl & 3) fce_erfmul<T, NS, CPLX>(rec, sd, x, acc, acci);
-            else fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
+          if (FAM >= 1 && ((fl >> 4) & 3) == 3) {
+            if constexpr (FAM >= 1) {
+              if (fl & 3) fce_erfmul<T, NS, CPLX>(rec, sd, x, acc, acci);
+              else fce_envmul<T, NS, CPLX>(rec, sd, acc, acci);
+            }
           } else if (fl & 8) {
             if constexpr (CPLX) fce_eval<T, NS, CORR>(s_par, rec, sd, x, true, acci, fl, &cc);
           } else {
@@ -1190,12 +1285,15 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
     if (lean) {
       const size_t lds = (size_t)(a.lean_par + 128 * a.lean_ops) * sizeof(double);
       if constexpr (sizeof(T) == 8) {
-        if (a.corr) {
-          hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, true>), g, dim3(64), lds, s, a);
+        if (a.corr) {      // (corrected carriers and chirps never share a plan's lean pieces: family <= 1 here)
+          if (a.lean_fam >= 1) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, true, 1>), g, dim3(64), lds, s, a);
+          else hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, true, 0>), g, dim3(64), lds, s, a);
           return hipGetLastError() == hipSuccess ? 0 : -1;
         }
       }
-      hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false>), g, dim3(64), lds, s, a);
+      if (a.lean_fam >= 2) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 2>), g, dim3(64), lds, s, a);
+      else if (a.lean_fam == 1) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 1>), g, dim3(64), lds, s, a);
+      else hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 0>), g, dim3(64), lds, s, a);
       return hipGetLastError() == hipSuccess ? 0 : -1;
     }
   }
