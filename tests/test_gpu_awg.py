@@ -171,3 +171,37 @@ def test_random_awg_script(seed):
         back = buf.download((max(n, 1), ), np.float64)[:n]
         assert np.max(np.abs(back - 2.0 - ora), initial=0.0) <= 1e-9 * pk, seed
         buf.close()
+
+
+def test_flat_top_pulses_with_erf_edges_stay_in_the_short_tier():
+    """square(width, edge) at AWG rates: 0.5 +- 0.5 erf edges of a handful of samples (reference
+    waveform.py:1096-1112).  The short tier multiplies what the edge piece's ops accumulated by
+    m0 + m1 erf(v) per sample (libm erf); nothing goes to the general kernel."""
+    for rate, edge, tones in ((2e9, 5e-9, 1), (1e9, 3e-9, 1), (2.4e9, 8e-9, 3), (5e9, 2e-9, 2)):
+        w = wf.zero()
+        for k in range(40):
+            env = wf.square(40e-9, edge=edge) >> (30e-9 + 75e-9 * k)
+            car = wf.cos(2 * np.pi * (50e6 + 1e6 * k), 0.1 * k)
+            for j in range(1, tones):
+                car = car + 0.5 * wf.cos(2 * np.pi * (80e6 * j + 3e6 * k), 0.2 * j)
+            w = w + (0.3 + 0.01 * k) * env * car
+        # a bare flat top, a DRAG-corrected one and a Gaussian-windowed one
+        w = w + 0.4 * (wf.square(30e-9, edge=4e-9) >> 3.1e-6)
+        I, Q = wf.mixing(wf.square(50e-9, edge=6e-9) >> 3.2e-6, freq=120e6, phase=0.3, DRAGScaling=2e-10)
+        w = w + I - 0.3 * Q
+        g = _flatten.grid_arange(0.0, 3.4e-6, 1 / rate)
+        prog = _flatten.flatten([w])
+        plan = _engine.Plan(prog, grid=g)
+        assert plan.kernel_name() == 'wfk_sample_short<double,false,false,16>', plan.kernel_name()
+        assert plan.info.n_direct == 0 and plan.info.n_generic == 0
+        ora = c_oracle.eval_grid(prog, g)[0]
+        got = plan.run_host(np.float64)[0]
+        assert np.max(np.abs(got - ora)) <= 1e-10, rate
+        assert np.max(np.abs(plan.run_host(np.float32)[0] - ora)) <= 2e-6
+    # complex amplitudes and clip on top
+    w2 = (0.6 + 0.3j) * (wf.square(40e-9, edge=5e-9) >> 60e-9) * wf.cos(2 * np.pi * 70e6) + 0.2 * (wf.gaussian(20e-9) >> 160e-9)
+    g = _flatten.grid_arange(0.0, 0.3e-6, 1 / 2e9)
+    prog = _flatten.flatten([w2])
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.kernel_name(np.complex128).startswith('wfk_sample_short<double,true')
+    assert np.max(np.abs(plan.run_host(np.complex128)[0] - c_oracle.eval_grid(prog, g, True)[0])) <= 1e-10

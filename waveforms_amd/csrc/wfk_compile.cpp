@@ -975,6 +975,16 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       H.params.resize(at + (size_t)rec_len, 0.0);
       double* o = H.params.data() + at;
       for (const FceGroup& G : groups) {
+        if (G.erfmul) {
+          // closing op of a flat-top edge: everything accumulated so far *= m0 + m1 erf(v), v = v0 + koff H
+          const uint64_t word = (uint64_t)(uint32_t)((3 << 4) | (&G == &groups.back() ? WFK_SH_LAST : 0)) | ((uint64_t)(uint32_t)r0 << 32);
+          std::memcpy(&o[0], &word, sizeof word);
+          o[5] = (double)((x0 - (long double)G.sg) / G.sigma);
+          o[6] = (double)((long double)grid->step / G.sigma);
+          o[8] = G.m0; o[9] = G.m1;
+          o += WFK_SH_OP1;
+          continue;
+        }
         const int env = G.has_exp ? 2 : (G.has_env ? 1 : 0);
         const uint64_t word = (uint64_t)(uint32_t)((G.deg & 3) | ((G.W != 0.0 ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (env << 4) |
                                                    (&G == &groups.back() ? WFK_SH_LAST : 0)) |
@@ -1113,7 +1123,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         bool mod_on = false;
         double mod_sigma = 0, mod_shift = 0;
         auto erf_factor_of = [&](int32_t k, double& sg_out, double& sh_out) -> int32_t {
-          if (!erfmod_base || cur_short) return -1;
+          if (!erfmod_base) return -1;
           int32_t at = -1;
           for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
             if (P->fc_type[f] == WFK_ERF) {
@@ -1123,10 +1133,15 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           if (at < 0) return -1;
           const double sg = P->pool[P->fc_arg_off[at]], sh = P->fc_shift[at];
           if (!std::isfinite(sg) || sg == 0.0 || !std::isfinite(sh)) return -1;
-          if (!(std::fabs(dstride / sg) <= 0.09) || !rate_safe(1.13 / sg, s0, s1)) return -1;
-          bool ok64, ok32;
-          gauss_range(sg, sh, C.tshift, s0, s1, ok64, ok32);
-          if (!ok64) return -1;
+          if (!rate_safe(1.13 / sg, s0, s1)) return -1;
+          if (!cur_short) {
+            // lean kernel: the erf advances by its own Taylor step along the lane stride (fine grids only);
+            // the short tier evaluates erf itself at every sample of the (short) edge piece
+            if (!(std::fabs(dstride / sg) <= 0.09)) return -1;
+            bool ok64, ok32;
+            gauss_range(sg, sh, C.tshift, s0, s1, ok64, ok32);
+            if (!ok64) return -1;
+          }
           if (mod_on && (mod_sigma != sg || mod_shift != sh)) return -1;
           sg_out = sg; sh_out = sh;
           return at;
@@ -1213,7 +1228,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
           // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
           bool ok = generic.empty() && !groups.empty() && groups.size() <= 255;
-          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.erfmul || G.envmul);
+          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul);
           if (!ok) {
             H.params.resize(snap.params); H.pool.resize(snap.pool);
             H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;

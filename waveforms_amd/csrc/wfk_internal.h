@@ -133,7 +133,8 @@
 // are kept small: 96 B per op, 4 B per segment.  Record of a piece (or of each <= WFK_SH_SUB-sample
 // stretch of a long piece): its ops back to back, 16-B aligned, WFK_SH_OP1 doubles each
 // (WFK_SH_OP3 when deg > 1):
-//     [0] low half: deg | carrier << 2 | imag << 3 | env << 4 (0 none, 1 Gaussian, 2 exp) | last op << 6
+//     [0] low half: deg | carrier << 2 | imag << 3 | env << 4 (0 none, 1 Gaussian, 2 exp; 3: the op is the
+//         closing erf multiplier of a flat-top edge: [5] v0, [6] H as for a Gaussian, [8] m0, [9] m1) | last op << 6
 //         high half: the record's reference sample (index in the channel): a lane's segment starts
 //         koff = j0 + o - ref samples after it
 //     [1] th0/pi at the reference sample, reduced to [-1, 1]    [2] W dt / pi

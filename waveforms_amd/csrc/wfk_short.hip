@@ -212,6 +212,25 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
   SH_END
 }
 
+// libm erf behind a call: inlined sixteen times into the closing op it would triple the kernel
+__device__ __attribute__((noinline)) double erf_call(double x) { return erf(x); }
+
+// Closing op of a flat-top edge (square(width, edge): 0.5 +- 0.5 erf((t - s) / sigma), reference
+// waveform.py:1096-1112): everything the piece's ops accumulated so far is multiplied by
+// m0 + m1 erf(v_k), v_k = v0 + (koff + k) H.  At AWG rates an edge is a handful of samples and H = dt / sigma
+// is of order 1, so erf is simply evaluated per sample (the lean kernel's Taylor-step form needs H <= 0.09).
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_erfmul(const OpRec& o, double kf, double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+  const double h = o.d.x, m0 = o.e.x, m1 = o.e.y;
+  double v = fma(kf, h, o.c.y);
+  SH_EACH(R, k)
+    const double m = fma(m1, erf_call(v), m0);
+    acc[k] *= m;
+    if constexpr (CPLX) acci[k] *= m;
+    v += h;
+  SH_END
+}
+
 #ifndef WFK_SH_WAVES
 #define WFK_SH_WAVES 3
 #endif
@@ -358,11 +377,15 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         //  waiting for it -- a vmcnt(3) right behind the prefetch)
         asm volatile("" : : "v"(rc.a.x));
         const int w = op_word(rc);
-        const bool mine = lv && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
+        const bool closing = ((w >> 4) & 3) == 3;       // erf edge multiplier
+        const bool mine = lv && !closing && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
         const bool cubic = __any(mine && (w & 3) > 1);
         if (mine) {
           if (cubic) short_op<R, true, CPLX>(rc, opp, w, kf, a.step, acc, acci);
           else short_op<R, false, CPLX>(rc, opp, w, kf, a.step, acc, acci);
+        }
+        if (__any(lv && closing)) {
+          if (lv && closing) short_erfmul<R, CPLX>(rc, kf, acc, acci);
         }
         return lv && !(w & WFK_SH_LAST);
       };
