@@ -124,18 +124,22 @@ def test_clip_offset_and_accumulate_on_edge_pieces():
 
 
 def test_not_eligible_shapes_stay_exact():
-    """overlapping edges (two different erfs in one piece), a squared erf, and a grid too coarse for
-    the step series: the erf stays a per-sample libm factor (wholly or for the second one)"""
+    """overlapping edges (two different erfs in one piece) and a squared erf: the erf stays a per-sample
+    libm factor (wholly or for the second one).  A grid too coarse for the step series of the lean
+    kernel goes to the short-piece tier, whose closing op calls erf per sample."""
     narrow = wf.square(6e-9, edge=4e-9) >> 30e-9                      # width < 2 edge: both erfs in the middle piece
     sq = (wf.square(30e-9, edge=4e-9) >> 30e-9)
-    for chans, grid in (([narrow * wf.cos(2 * np.pi * 90e6)], ('linspace', 0.0, 60e-9, 500_000, False)),
-                        ([sq * sq], ('linspace', 0.0, 60e-9, 500_000, False)),
-                        ([sq * wf.cos(2 * np.pi * 90e6)], ('linspace', 0.0, 60e-9, 3_001, False))):
+    for chans, grid, short in (([narrow * wf.cos(2 * np.pi * 90e6)], ('linspace', 0.0, 60e-9, 500_000, False), False),
+                               ([sq * sq], ('linspace', 0.0, 60e-9, 500_000, False), False),
+                               ([sq * wf.cos(2 * np.pi * 90e6)], ('linspace', 0.0, 60e-9, 3_001, False), True)):
         prog = _flatten.flatten(chans)
         g = _flatten.grid_from_desc(grid)
         want = c_oracle.eval_grid(prog, g)
         plan = _engine.Plan(prog, grid=g)
-        assert plan.info.n_generic > 0
+        if short:
+            assert plan.kernel_name().startswith('wfk_sample_short<')
+        else:
+            assert plan.info.n_generic > 0
         assert np.max(np.abs(plan.run_host(np.float64) - want)) <= 1e-11
 
 

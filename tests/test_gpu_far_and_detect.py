@@ -35,7 +35,7 @@ def test_far_carriers_stay_fused(t_center, f):
         assert plan.info.n_direct == 0 and plan.info.n_generic == 0 and plan.info.n_fused > 0
         # the correction is taken exactly where the grid-rounding bound exceeds the 2.5e-10 budget
         need = 2 * np.pi * abs(f) * 1.2e-16 * (abs(t_center) + span / 2 + span) > 2.5e-10
-        assert plan.kernel_name() == 'wfk_sample_lean<double,false,16,%s>' % ('true' if need else 'false')
+        assert plan.kernel_name() == 'wfk_sample_lean<double,false,16,%s,0>' % ('true' if need else 'false')
         got = plan.run_host(np.float64)
         ora = c_oracle.eval_grid(prog, g)
         assert np.max(np.abs(got - ora)) <= 1e-9, (t_center, f, np.max(np.abs(got - ora)))

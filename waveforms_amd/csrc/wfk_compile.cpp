@@ -361,7 +361,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool corr_enabled = allow_corr && !shortm && !(nocorr_env && nocorr_env[0] == '1');
   bool piece_corr_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
   const char* nochirp_env = std::getenv("WFK_DISABLE_CHIRP");
-  const bool chirp_base = !H.tlist && ns_override == 0 && !g_no_chirp && !(nochirp_env && nochirp_env[0] == '1');
+  const bool chirp_base = !H.tlist && ns_override == 0 && !shortm && !g_no_chirp && !(nochirp_env && nochirp_env[0] == '1');
   bool piece_chirp_ok = true;  // likewise: the fused chirp op exists in the lean kernel only
   bool chirp_ok = false;
   auto corr_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {
@@ -1076,7 +1076,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       bool piece_lean = false;
       for (int attempt = 0; attempt < 2 && !live.empty(); ++attempt) {
         const int32_t corr_before = H.n_corr;
-        chirp_ok = chirp_base && piece_chirp_ok && !cur_short && can_fuse;
+        chirp_ok = chirp_base && piece_chirp_ok && can_fuse;   // (chirp_base: never in a short plan, whose other pieces run on the general kernel)
         D.flags |= WFK_PF_HAS_TERMS;
         BlockBuilder B;
         auto room_for = [&](size_t need) -> int {

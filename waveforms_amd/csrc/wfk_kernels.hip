@@ -909,7 +909,10 @@ __device__ __forceinline__ void clip_np_cplx(T& re, T& im, T lo, T hi) {
 // accumulate into `out`; lanes outside [P.start, P.stop) keep their hands off.
 // `tr`/`tc` point at the tile's first sample (wave-uniform => scalar base + lane offset).
 // PLAIN = the tile lies inside the piece, no clip, no accumulate: add + store per sample.
-template <typename T, bool CPLX, int NS, bool PLAIN>
+// NT: non-temporal stores.  A loss for the plain lean kernel (headline 3.45 -> 3.52 ms, C3 0.199 -> 0.207 on one
+// box) but a gain for its CORR variant, which runs fewer waves per SIMD and keeps re-reading nothing the stream
+// could evict (dense far-from-origin workload 0.93 -> 0.84 ms, same box): used there only.
+template <typename T, bool CPLX, int NS, bool PLAIN, bool NT = false>
 __device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel& C,
                                                 const DevPiece& P, typename OutOps<T>::Real* tr,
                                                 typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
@@ -943,16 +946,22 @@ __device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel
           w.x += old.x;
           w.y += old.y;
         }
-        tc[o] = w;
+        if constexpr (NT) {
+          __builtin_nontemporal_store(w.x, &tc[o].x);
+          __builtin_nontemporal_store(w.y, &tc[o].y);
+        } else {
+          tc[o] = w;
+        }
       } else {
         if (accum) v += tr[o];
-        tr[o] = v;
+        if constexpr (NT) __builtin_nontemporal_store(v, &tr[o]);
+        else tr[o] = v;
       }
     }
   WFK_END
 }
 
-template <typename T, bool CPLX, int NS>
+template <typename T, bool CPLX, int NS, bool NT = false>
 __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, const DevPiece& P,
                                            typename OutOps<T>::Real* tr,
                                            typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
@@ -960,9 +969,9 @@ __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, 
   const bool full = P.start <= w0 && P.stop >= w0 + 64 * NS;
   const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
   if (full && !clip && !a.accumulate)
-    store_tile_impl<T, CPLX, NS, true>(a, C, P, tr, tc, w0, lane, acc, acci);
+    store_tile_impl<T, CPLX, NS, true, NT>(a, C, P, tr, tc, w0, lane, acc, acci);
   else
-    store_tile_impl<T, CPLX, NS, false>(a, C, P, tr, tc, w0, lane, acc, acci);
+    store_tile_impl<T, CPLX, NS, false, NT>(a, C, P, tr, tc, w0, lane, acc, acci);
 }
 
 // XCD-aware workgroup -> chunk map.  Workgroups are dealt round-robin to the 8 XCDs
@@ -1160,7 +1169,7 @@ wfk_sample_lean(const KArgs a) {
       }
       // tile base pinned to SGPRs: the stores become `global_store v_lane_off, data, s[base]
       // offset:k*512` (one address VGPR instead of a hoisted 64-bit pointer pair per store)
-      if (mine) store_tile<T, CPLX, NS>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
+      if (mine) store_tile<T, CPLX, NS, CORR>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
       if (P.stop >= w1 || q + 1 >= C.piece_end) break;   // the tile ends inside this piece
       q = uni(q + 1);
       cur = load_piece(a.pieces + q);
