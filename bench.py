@@ -22,6 +22,8 @@ Workloads (SURVEY.md §8(d) / BASELINE.json configs):
                         uses): mixing(gaussian(20 ns), DRAGScaling) pulses back to back (60 samples
                         per pulse) / 100 ns apart (30 % duty); 16 distinct channels per 2048 rows,
                         every row with its own device tables (short-piece tier)
+  awg_c4                the awg rows through predistort(wav(t), ker 1024 taps): the sampler fused into
+                        the FIR transform at AWG rates (fir_short)
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); channels are
 independent, so each rank samples its own block of channels with no data-path
@@ -193,7 +195,7 @@ def workload(name, channels, points):
             np.float64, (f'{channels} ch/GPU x {points:.0e} pts at 2 GS/s, 100 pulses/ch '
                          f'({"200 ns wide, 10 us apart" if name == "far_sparse" else "10 us each, back to back"}) with '
                          f'250-350 MHz carriers out to t = {points / 2e9 * 1e3:.1f} ms')
-    if name in ('awg', 'awg_duty30'):
+    if name in ('awg', 'awg_duty30', 'awg_c4'):
         d30 = name == 'awg_duty30'
         return (lambda c: wl.awg_channel(wf, c, points, 2e9, d30)), wl.awg_grid(points, 2e9), np.float64, (
             f'{channels} rows/GPU x {points:.0e} pts at 2 GS/s (np.arange grid of Waveform.sample), '
@@ -203,12 +205,12 @@ def workload(name, channels, points):
     raise SystemExit(f'unknown workload {name}')
 
 
-TILE = {'awg': 128, 'awg_duty30': 128}     # rows = TILE copies of rows / TILE distinct channels
+TILE = {'awg': 128, 'awg_duty30': 128, 'awg_c4': 128}     # rows = TILE copies of rows / TILE distinct channels
 
 
 def default_shape(name):
-    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512, 'awg': 2048, 'awg_duty30': 2048}.get(name, 256)
-    points = {'c3': 10**6, 'far': 2 * 10**6, 'far_sparse': 2 * 10**6, 'awg': 10**5, 'awg_duty30': 10**5}.get(name, 10**7)
+    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512, 'awg': 2048, 'awg_duty30': 2048, 'awg_c4': 2048}.get(name, 256)
+    points = {'c3': 10**6, 'far': 2 * 10**6, 'far_sparse': 2 * 10**6, 'awg': 10**5, 'awg_duty30': 10**5, 'awg_c4': 10**5}.get(name, 10**7)
     return channels, points
 
 
@@ -405,12 +407,12 @@ def run_rank(args):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     out = torch.empty((bs.n_channels, bs.n), dtype=tdt, device='cuda')
     fir = chain = None
-    if name == 'c4':
+    if name in ('c4', 'awg_c4'):
         # C4 = predistort(wav(t), ker): ONE kernel when the plan is fully fused (the FIR workgroups
         # evaluate their own input windows), else sampler -> FIR
         from waveforms_amd.distortion import FirStage, SampledFir
         a0, b0 = sh.start, sh.stop
-        chain = SampledFir([make_channel(c) for c in range(a0, b0)], grid, wl.c4_kernel(), dtype)
+        chain = SampledFir([make_channel(c) for c in range(a0 // tile, b0 // tile)], grid, wl.c4_kernel(), dtype, tile=tile)
         if not chain.fused:
             fir = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
             out2 = torch.empty_like(out)
@@ -489,11 +491,13 @@ def run_rank(args):
             'timing': 'HIP events around every launch on the launch stream, mean over the timed steps'}
     if chain is not None and chain.fused:
         # fused chain: the samples never touch HBM; algorithmic traffic = the filtered output only
-        roof['kernel'] = 'fir_sampled<%s,12>' % ('double' if dtype == np.float64 else 'float')
+        roof['kernel'] = chain.plan.kernel_name()
+        roof['table_bytes_per_launch'] = chain.plan.table_bytes()
+        roof['frac_incl_tables'] = (algo_bytes + roof['table_bytes_per_launch']) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof['note'] = ('sampler fused into the FIR transform: algorithmic bytes = B_out per sample '
                         '(SURVEY 8(d) "fused sampler->FIR: B_out only"); the kernel is bound by fp64 VALU issue, '
                         'not by HBM: see roofline_valu')
-        rv = valu_roofline('c4', kern_ms, bs.n_channels * bs.n)
+        rv = valu_roofline(name, kern_ms, bs.n_channels * bs.n)
         if rv is not None:
             roof['roofline_valu'] = rv
     if fir is not None:
@@ -642,6 +646,25 @@ def run_rank(args):
                                       'msamples_per_s': b2.n_channels * b2.n / (ms3 * 1e-3) / 1e6,
                                       'frac': nbytes / 2 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 del o3
+            if wname == 'awg':
+                # the same rows through the 1024-tap FIR: predistort(wav(t), ker) at AWG rates (fir_short)
+                chn2 = SampledFir([mk(c) for c in range(wch // wt)], g, wl.c4_kernel(), np.float64, tile=wt)
+                o4 = torch.empty_like(o2)
+                ms4 = timed(lambda: chn2.launch_torch(o4), 20, 5)
+                fst2 = FirStage(wl.c4_kernel(), b2.n, b2.n_channels, np.float64)
+                msf = timed(lambda: fst2.apply_torch(o2, o4), 20, 5)
+                tb4 = chn2.plan.table_bytes()
+                also['awg_c4'] = {'workload': d_ + '; then the 1024-tap FIR of C4 (predistort(wav(t), ker))',
+                                  'kernel': chn2.plan.kernel_name(), 'fused': chn2.fused, 'step_ms': ms4,
+                                  'msamples_per_s': b2.n_channels * b2.n / (ms4 * 1e-3) / 1e6,
+                                  'algorithmic_bytes_per_launch': nbytes,
+                                  'frac': nbytes / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  'table_bytes_per_launch': tb4,
+                                  'frac_incl_tables': (nbytes + tb4) / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  'unfused': {'sampler_kernel_ms': ms, 'fir_kernel_ms': msf, 'step_ms': ms + msf}}
+                fst2.close()
+                chn2.close()
+                del o4
             del o2
             b2.close()
         line['also'] = also

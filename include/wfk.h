@@ -204,6 +204,11 @@ typedef struct wfk_chain_plan wfk_chain_plan;
 int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const double* ker_host,
                           int32_t K, int kind /* WFK_OUT_F64|F32 */, wfk_chain_plan** out);
 int wfk_chain_is_fused(const wfk_chain_plan* plan);
+/* "fir_sampled<T,HOPB>" (stride-256 chains, fine grids), "fir_short<T,HOPB>" (contiguous lane runs, AWG
+ * rates) or the two kernels of the unfused path; the string lives until the next call on this thread */
+const char* wfk_chain_kernel_name(const wfk_chain_plan* plan);
+/* bytes of device tables one launch reads besides the kernel spectrum (records, window entries) */
+int64_t wfk_chain_table_bytes(const wfk_chain_plan* plan);
 const char* wfk_chain_unfused_reason(const wfk_chain_plan* plan);
 int wfk_chain_launch(wfk_chain_plan* plan, void* out_dev, int64_t out_stride, void* hip_stream);
 int wfk_chain_plan_destroy(wfk_chain_plan* plan);

@@ -58,20 +58,74 @@ def test_many_pieces_per_window_pair_and_ragged_ends():
         grid = ('linspace', 0.0, 2 * wl.SPAN, n, endpoint)
         ker = _kernel(min(1024, 2 * n), n)
         sf = SampledFir(chans, grid, ker)
-        assert sf.fused == (n > 4000), sf.why_not     # (300 and 17 points: too coarse, two-kernel path)
+        assert sf.fused, sf.why_not
+        assert sf.plan.kernel_name().startswith('fir_sampled<' if n > 4000 else 'fir_short<')    # (300 and 17 points: coarse grid)
         assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, grid, ker))) <= 1e-12
         sf.close()
 
 
-def test_coarse_grids_fall_back():
-    # Gaussians narrower than a few window strides (256 samples) cannot be carried along the
-    # chain by the two-multiplier recurrence: such plans take the two-kernel path, same numbers
+def test_coarse_grids_fuse_through_the_short_tier():
+    # Gaussians narrower than a few window strides (256 samples) cannot be carried along a stride-256
+    # chain by the two-multiplier recurrence; such plans are in the short geometry, and the transform's
+    # workgroups sample their windows the short tier's way (fir_short): one kernel, same numbers
     chans = [wl.sum_channel(wf, 100, 1000)]
     grid = ('linspace', 0.0, 100 * wl.SPAN, 70001, False)
     ker = _kernel(1024)
     sf = SampledFir(chans, grid, ker)
-    assert not sf.fused and 'not fully fused' in sf.why_not
+    assert sf.fused and sf.plan.kernel_name() == 'fir_short<double,12>', (sf.why_not, sf.plan.kernel_name())
     assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, grid, ker))) <= 1e-12
+    sf.close()
+
+
+@pytest.mark.parametrize('rate', [1e9, 2e9, 2.4e9, 5e9])
+@pytest.mark.parametrize('duty30', [False, True])
+def test_awg_channels_fuse_at_awg_rates(rate, duty30):
+    """predistort(wav(t), ker) stays ONE kernel at 1-5 GS/s with 20 ns pulses, K = 1024"""
+    n = 60_000
+    chans = [wl.awg_channel(wf, c, n, rate, duty30) for c in range(3)]
+    grid = wl.awg_grid(n, rate)
+    ker = _kernel(1024, int(rate / 1e8))
+    sf = SampledFir(chans, grid, ker)
+    assert sf.fused and sf.plan.kernel_name() == 'fir_short<double,12>', (sf.why_not, sf.plan.kernel_name())
+    want = _oracle_chain(chans, grid, ker)
+    assert np.max(np.abs(sf.to_host() - want)) <= 1e-12
+    sf.close()
+    s32 = SampledFir(chans, grid, ker, np.float32)
+    assert s32.fused and s32.plan.kernel_name() == 'fir_short<float,12>'
+    assert np.max(np.abs(s32.to_host() - want)) <= 2e-5
+    s32.close()
+
+
+@pytest.mark.parametrize('K', [1, 2, 333, 1025, 1026, 1537])
+def test_short_chain_kernel_lengths_offsets_and_ragged_ends(K):
+    rate = 2e9
+    for n, seed in ((50_001, 3), (7169, 4), (6144, 5), (4000, 6), (257, 7)):
+        chans = [(wl.awg_channel(wf, seed + c, n, rate, c == 1) + 0.125 * c) >> (c * 0.3e-9) for c in range(2)]
+        grid = wl.awg_grid(n, rate)
+        ker = _kernel(min(K, 2 * n), n + K)
+        sf = SampledFir(chans, grid, ker)
+        assert sf.fused and sf.plan.kernel_name().startswith('fir_short<double,'), (n, sf.why_not, sf.plan.kernel_name())
+        assert np.max(np.abs(sf.to_host() - _oracle_chain(chans, grid, ker))) <= 1e-11, (n, K)   # (the short tier itself: 4e-12 on these channels)
+        sf.close()
+
+
+def test_short_chain_flat_tops_clip_and_mixed_fall_back():
+    rate, n = 2e9, 40_000
+    grid = wl.awg_grid(n, rate)
+    ker = _kernel(1024, 11)
+    flat = wf.zero()
+    for k in range(60):                      # flat-top pulses: erf edges are closing ops of the short tier
+        flat = flat + ((wf.square(40e-9, edge=5e-9) >> (100e-9 + 300e-9 * k)) * wf.cos(2 * np.pi * 150e6, 0.1 * k))
+    clipped = wf.cut(wl.awg_channel(wf, 1, n, rate), min=-0.3, max=0.45)
+    sf = SampledFir([flat, clipped], grid, ker)
+    assert sf.fused and sf.plan.kernel_name() == 'fir_short<double,12>', (sf.why_not, sf.plan.kernel_name())
+    assert np.max(np.abs(sf.to_host() - _oracle_chain([flat, clipped], grid, ker))) <= 1e-12
+    sf.close()
+    # a piece the short tier cannot take (a chirp -> general kernel in a second launch): two-kernel chain
+    mixed = wl.awg_channel(wf, 0, n, rate) + (wf.chirp(1e8, 2e8, 30e-9) >> 5e-6)
+    sf = SampledFir([mixed], grid, ker)
+    assert not sf.fused and '+ FIR' in sf.plan.kernel_name()
+    assert np.max(np.abs(sf.to_host() - _oracle_chain([mixed], grid, ker))) <= 1e-12
     sf.close()
 
 

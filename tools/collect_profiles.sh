@@ -21,9 +21,7 @@ case "$WL" in
   iir) ARGS="tools/iir_bench.py" ;;
   readout) ARGS="tools/readout_bench.py" ;;
   multitone) ARGS="tools/multitone_bench.py 10" ;;
-  awg) ARGS="tools/awg_bench.py 2048 1e5 2 0 float64" ;;
-  awg30) ARGS="tools/awg_bench.py 2048 1e5 2 1 float64" ;;
-  awg_f32) ARGS="tools/awg_bench.py 2048 1e5 2 0 float32" ;;
+  awg_f32) ARGS="bench.py --workload awg --dtype f32 --steps 5 --warmup 1 --no-cpu-baseline --no-also" ;;
 esac
 echo "== stats pass ($WL)"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/stats.log" 2>&1
@@ -33,3 +31,4 @@ for grp in WRITE_SIZE FETCH_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o run -- python3 $ARGS > "$OUT/pmc_$name.log" 2>&1
 done
 python3 tools/summarize_profiles.py "$OUT" "gpurun_out/profiles/${TAG}_${WL}"
+grep '^{' "$OUT/stats.log" | tail -1 > "gpurun_out/profiles/${TAG}_${WL}_bench.json" || true

@@ -81,6 +81,10 @@ def lib():
         l.wfk_chain_is_fused.argtypes = [VP]
         l.wfk_chain_unfused_reason.argtypes = [VP]
         l.wfk_chain_unfused_reason.restype = C.c_char_p
+        l.wfk_chain_kernel_name.argtypes = [VP]
+        l.wfk_chain_kernel_name.restype = C.c_char_p
+        l.wfk_chain_table_bytes.argtypes = [VP]
+        l.wfk_chain_table_bytes.restype = I64
         l.wfk_chain_launch.argtypes = [VP, VP, I64, VP]
         l.wfk_chain_plan_destroy.argtypes = [VP]
         l.wfk_iir_plan_create.argtypes = [I32, VP, VP, VP, I64, I32, C.c_int, P(VP)]
@@ -249,7 +253,8 @@ class FirPlan:
 
 class ChainPlan:
     """sampler -> FIR for every channel of `prog` on `grid` (predistort(wav(t), ker=ker)); fused
-    into ONE kernel when the program is fully fused and K <= 1537 (`fused`, `why_not`)."""
+    into ONE kernel when the program is fully fused (lean plan on a fine grid, or a pure short-tier
+    plan at AWG sample rates) and K <= 1537 (`fused`, `why_not`, `kernel_name()`)."""
 
     def __init__(self, prog: Program, grid: wfk_grid, ker, dtype=np.float64):
         ker = np.ascontiguousarray(ker, dtype=np.float64)
@@ -263,6 +268,13 @@ class ChainPlan:
 
     def launch(self, out_ptr: int, out_stride: int, stream: int = 0):
         check(lib().wfk_chain_launch(self._h, out_ptr, out_stride, stream))
+
+    def kernel_name(self) -> str:
+        """'fir_sampled<T,HOPB>' (fine grids), 'fir_short<T,HOPB>' (AWG rates) or the unfused pair"""
+        return lib().wfk_chain_kernel_name(self._h).decode()
+
+    def table_bytes(self) -> int:
+        return int(lib().wfk_chain_table_bytes(self._h))
 
     def close(self):
         if self._h and _lib is not None:

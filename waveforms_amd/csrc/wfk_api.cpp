@@ -296,6 +296,13 @@ int wfk_plan_channel_is_complex(const wfk_plan* p, int32_t channel) {
   return p->h.channel_complex[channel];
 }
 
+// the compiled tables of a plan, for the fused sampler -> FIR chain at AWG rates (wfk_fir_sampled.hip builds
+// its window tables from the short plan's pieces and reads the plan's own op records on the device)
+void wfk_internal_plan_tables(const wfk_plan* p, const HostPlan** h, const double** d_params) {
+  *h = p ? &p->h : nullptr;
+  *d_params = p && p->on_device ? p->d_params : nullptr;
+}
+
 int64_t wfk_plan_table_bytes(const wfk_plan* p) {
   if (!p) return fail(WFK_EINVAL, "null plan");
   const HostPlan& h = p->h;

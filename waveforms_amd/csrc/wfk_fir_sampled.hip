@@ -32,10 +32,12 @@
 #include "wfk.h"
 #include "wfk_fft4096.h"
 #include "wfk_internal.h"
+#include "wfk_short_dev.h"
 
 extern "C" void wfk_internal_set_error(const char* msg);
 extern "C" void wfk_internal_fir_tables(const wfk_fir_plan* p, const void** kspec, const void** tw,
                                         int* fused, int* nseg, int* K, int* lead);
+extern "C" void wfk_internal_plan_tables(const wfk_plan* p, const HostPlan** h, const double** d_params);
 
 namespace {
 
@@ -427,6 +429,174 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
   }
 }
 
+// ---- the same chain at AWG sample rates: fir_short ------------------------------------------------
+// At 1-5 GS/s a pulse is 20-200 samples: a chain of 28 samples 256 apart crosses 28 different pieces, and
+// the plan is in the short geometry anyway (wfk_short.hip).  Here the window is sampled the short tier's
+// way: a THREAD owns a run of <= 16 CONTIGUOUS samples of one piece (one "entry" of the window), seeds
+// its ops exactly once from the piece's compact record and steps the recurrences by dt
+// (wfk_short_dev.h); the runs land in the LDS array, from where every thread picks up the
+// stride-256 samples the transform wants from it.  The array holds 4624 elements and a pair of windows is
+// 7168 samples, so the pair is sampled in two halves of HR = CL / 2 rows (3584 samples, ~240 entries of
+// the 256 threads' one round for 60-sample pulses), padded by one element per 16 (a run of 16 starts 17
+// elements after its neighbour's: conflict-free writes, and the strided reads skip one bank per 16
+// lanes).  Zero padding and the channel offset are a prefill of the half before its entries are written.
+// The host cuts the pieces of the sampler's own short plan into per-half entry lists
+// (wfk_chain_plan_create); the op records are the plan's, read where they are.
+struct ShortWin {        // one half of one pair of windows of one channel
+  int64_t rec0;          // base of the records its entries refer to (units of 16 B)
+  int64_t e0;            // first entry
+  int32_t cnt, pad;
+};
+#define WFK_CW_ENTRY(drec, o, len) ((uint32_t)(drec) | ((uint32_t)(o) << 16) | ((uint32_t)((len) - 1) << 28))
+
+struct ChainShortArgs {
+  const DevChannel* channels;
+  const ShortWin* wins;       // [n_channels * npairs * 2]
+  const uint32_t* entries;    // drec (16 bit) | offset in the half (12 bit) | length - 1 (4 bit)
+  const double* recs;         // the sampler plan's parameter table (op records)
+  void* out;
+  int64_t out_stride, n, npairs;
+  const void* hspec;
+  const void* tw;
+  double step;
+  int32_t hop, K, lead;
+};
+
+template <typename T, int HOPB>
+__global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShortArgs a) {
+  constexpr int CL = 16 + HOPB, HR = CL / 2, HALF = 256 * HR, R = WFK_SH_R;
+  static_assert(CL % 2 == 0 && HALF + HALF / 16 <= LDS_ELEMS, "a half window must fit the transform's array");
+  static_assert(HALF <= 4096, "entry offsets are 12 bit");
+  __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.y;
+  const DevChannel C = a.channels[ch];
+  const cx<T>* hspec = static_cast<const cx<T>*>(a.hspec);
+  const cx<T>* tw = static_cast<const cx<T>*>(a.tw);
+  T* const orow = static_cast<T*>(a.out) + (int64_t)ch * a.out_stride;
+  const int M = a.hop;
+  const int64_t pair = blockIdx.x;
+  const int64_t s1 = 2 * pair * (int64_t)a.hop - a.lead;   // first sample of the first window
+  const int64_t range_end = s1 + 256 * (int64_t)CL;
+  const double base = C.offset;
+
+  // both halves' window descriptors and first entry words up front: the dependent chain
+  // descriptor -> entry -> op record is three memory round trips, two of them are taken here for
+  // both halves at once
+  const ShortWin* const wp0 = a.wins + ((int64_t)ch * a.npairs + pair) * 2;
+  int64_t w_rec0[2], w_e0[2];
+  int w_cnt[2];
+  uint32_t w_first[2];
+  CH_EACH(2, half)
+    w_rec0[half] = wp0[half].rec0;
+    w_e0[half] = wp0[half].e0;
+    w_cnt[half] = cuni(wp0[half].cnt);
+    w_first[half] = tid < w_cnt[half] ? a.entries[w_e0[half] + tid] : 0u;
+  CH_END
+
+  T x[CL];                                                 // the thread's samples: s1 + tid + 256 k
+  CH_EACH(2, half)
+    const int64_t h0 = s1 + (int64_t)HALF * half;
+    __syncthreads();                                       // the previous half has been picked up
+    // zero padding outside [0, n), the channel offset inside (skipped _zero pieces, gaps between entries)
+    if (h0 >= 0 && h0 + HALF <= a.n) {
+      CH_EACH(HR, k) lds[272 * k + tid + (tid >> 4)] = (T)base; CH_END
+    } else {
+      CH_EACH(HR, k)
+        const int64_t j = h0 + 256 * k + tid;
+        lds[272 * k + tid + (tid >> 4)] = (j >= 0 && j < a.n) ? (T)base : (T)0;
+      CH_END
+    }
+    __syncthreads();
+    const int64_t rec0 = w_rec0[half], e0 = w_e0[half];
+    const int cnt = w_cnt[half];
+    for (int eb = 0; eb < cnt; eb += 256) {                // block-uniform trip count
+      const int idx = eb + tid;
+      bool live = idx < cnt;
+      const uint32_t word = eb == 0 ? w_first[half] : (live ? a.entries[e0 + idx] : 0u);
+      const int len = live ? (int)(word >> 28) + 1 : 0;
+      const int o = (int)((word >> 16) & 0xfff);
+      const double* op = a.recs + 2 * (rec0 + (int64_t)(word & 0xffff));
+      shdev::OpRec rec = shdev::load_op(op);
+      const double kf = (double)((int)(uint32_t)(h0 + o) - shdev::op_ref(rec));   // samples from the record's reference sample
+      double acc[R], acci[1];
+      CH_EACH(R, k) acc[k] = 0.0; CH_END
+      acci[0] = 0.0;
+      auto eval = [&](const shdev::OpRec& rc, const double* opp, bool lv) -> bool {   // -> another op follows
+        const int w = shdev::op_word(rc);
+        const bool closing = ((w >> 4) & 3) == 3;          // erf edge multiplier
+        const bool mine = lv && !closing && !(w & 8);      // (real channels only: no op of an imaginary part)
+        const bool cubic = __any(mine && (w & 3) > 1);
+        if (mine) {
+          if (cubic) shdev::short_op<R, true, false>(rc, opp, w, kf, a.step, acc, acci);
+          else shdev::short_op<R, false, false>(rc, opp, w, kf, a.step, acc, acci);
+        }
+        if (__any(lv && closing)) {
+          if (lv && closing) shdev::short_erfmul<R, false>(rc, kf, acc, acci);
+        }
+        return lv && !(w & WFK_SH_LAST);
+      };
+      live = eval(rec, op, live);
+      while (__any(live)) {
+        op += (shdev::op_word(rec) & 3) > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
+        if (live) rec = shdev::load_op(op);
+        live = eval(rec, op, live);
+      }
+      if (C.do_clip) {
+        CH_EACH(R, k) acc[k] = shdev::clip_np(acc[k], C.clip_lo, C.clip_hi); CH_END
+      }
+      // element o + k of the half sits at (o + k) + ((o + k) >> 4) = swz(o) + k + [k >= 16 - (o & 15)]
+      T* const b0 = lds + (o + (o >> 4));
+      const int t = 16 - (o & 15);
+      CH_EACH(R, k)
+        if (k < len) *((k >= t ? b0 + 1 : b0) + k) = (T)(acc[k] + base);
+      CH_END
+    }
+    __syncthreads();
+    CH_EACH(HR, k) x[half * HR + k] = lds[272 * k + tid + (tid >> 4)]; CH_END
+  CH_END
+  __syncthreads();                                         // the array becomes the FFT exchange buffer
+
+  cx<T> v[16];
+  CH_EACH(16, n1)
+    v[n1].x = x[n1];
+    v[n1].y = x[n1 + HOPB];
+  CH_END
+  const int64_t b1 = 2 * pair, b2 = b1 + 1;
+  const bool interior = s1 >= 0 && range_end <= a.n && (b2 + 1) * (int64_t)M <= a.n;
+
+  // ---- transform, multiply by the kernel spectrum, inverse transform (as fir_sampled) ---------------
+  int tf = tid;
+  asm volatile("" : "+v"(tf));
+  const cx<T> wa = tw[tf], wb = tw[16 * (tf & 15)];
+  fft4096<false>(v, lds, wa, wb, tf);
+#pragma unroll
+  for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tf + 256 * k3]);
+  fft4096<true>(v, lds, wa, wb, tf);
+  if (interior) {
+    T* const o1 = orow + b1 * M + (tf - (a.K - 1));
+    T* const o2 = o1 + M;
+#pragma unroll
+    for (int q3 = 0; q3 < 16; ++q3) {
+      const int r = tf + 256 * q3 - (a.K - 1);
+      if (r >= 0 && r < M) {
+        o1[256 * q3] = v[q3].x;
+        o2[256 * q3] = v[q3].y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q3 = 0; q3 < 16; ++q3) {
+      const int r = tf + 256 * q3 - (a.K - 1);
+      if (r >= 0 && r < M) {
+        const int64_t d1 = b1 * M + r, d2 = b2 * M + r;
+        if (d1 < a.n) orow[d1] = v[q3].x;
+        if (d2 < a.n) orow[d2] = v[q3].y;
+      }
+    }
+  }
+}
+
 int chain_fail(int code, const std::string& m) {
   wfk_internal_set_error(m.c_str());
   return code;
@@ -447,6 +617,12 @@ struct wfk_chain_plan {
   DevPiece* d_pieces = nullptr;
   double* d_params = nullptr;
   int32_t* d_pair_first = nullptr;
+  // fused path at AWG rates (fir_short): half-window entry lists over the sampler plan's own op records
+  bool shortw = false;
+  ShortWin* d_wins = nullptr;
+  uint32_t* d_entries = nullptr;
+  const double* d_recs = nullptr;
+  int64_t table_bytes = 0;
   double t0 = 0, step = 0, last = 0;
   int32_t has_last = 0;
   // unfused path: the sampler's output
@@ -503,6 +679,88 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
     for (uint8_t cx_ : H.channel_complex)
       if (cx_) p->why = "complex-valued channel";
   }
+  if (!p->why.empty() && fir_fused && nseg == 1 && prog->n_channels <= 65535 && !(off && off[0] == '1')) {
+    // ---- AWG rates: the sampler's plan is in the short geometry -> fir_short ------------------------
+    const HostPlan* hs = nullptr;
+    const double* d_recs = nullptr;
+    wfk_internal_plan_tables(p->sampler, &hs, &d_recs);
+    bool real = true;
+    if (hs) for (uint8_t cx_ : hs->channel_complex) real = real && !cx_;
+    if (hs && d_recs && hs->shortp && !hs->mixed && real) {
+      const int64_t hop = 256 * (int64_t)p->hopb, HALF = 128 * (int64_t)(16 + p->hopb);
+      const int64_t nblk = (p->n + hop - 1) / hop;
+      p->npairs = (nblk + 1) / 2;
+      std::vector<ShortWin> wins((size_t)p->npairs * p->n_channels * 2);
+      std::vector<uint32_t> ents;
+      ents.reserve((size_t)(p->n / 12) * p->n_channels);
+      std::string bad;
+      for (int32_t c = 0; c < p->n_channels && bad.empty(); ++c) {
+        const int32_t pe = hs->channels[c].piece_end;
+        int32_t q = hs->channels[c].piece_begin;
+        for (int64_t pr = 0; pr < p->npairs && bad.empty(); ++pr) {
+          const int64_t s1 = 2 * pr * hop - lead;
+          while (q < pe - 1 && hs->pieces[q].stop <= s1) ++q;
+          for (int half = 0; half < 2; ++half) {
+            const int64_t h0 = s1 + HALF * half;
+            const int64_t w0 = std::max<int64_t>(h0, 0), w1 = std::min<int64_t>(h0 + HALF, p->n);
+            ShortWin W{};
+            W.rec0 = -1;
+            W.e0 = (int64_t)ents.size();
+            for (int32_t qq = q; qq < pe && hs->pieces[qq].start < w1; ++qq) {
+              const DevPiece& D = hs->pieces[qq];
+              if (D.n_blk == 0 || D.stop <= w0) continue;          // zero stretch (the prefill) / before the half
+              const int64_t a0 = std::max(D.start, w0), b0 = std::min(D.stop, w1);
+              for (int64_t m = (a0 - D.start) / WFK_SH_SUB; D.start + m * WFK_SH_SUB < b0; ++m) {
+                const int64_t r0 = D.start + m * WFK_SH_SUB, r1 = std::min<int64_t>(r0 + WFK_SH_SUB, D.stop);
+                const int64_t aa = std::max(a0, r0), bb = std::min(b0, r1), len = bb - aa;
+                if (len <= 0) continue;
+                const int64_t rec16 = (D.par_off + m * (int64_t)D.first_len) / 2;
+                if (W.rec0 < 0) W.rec0 = rec16;
+                if (rec16 - W.rec0 > 0xffff) { bad = "op records of one window span more than 1 MB"; break; }
+                const int64_t nsg = (len + WFK_SH_R - 1) / WFK_SH_R, bl = len / nsg, rem = len % nsg;
+                int64_t k0 = 0;
+                for (int64_t sg = 0; sg < nsg; ++sg) {
+                  const int64_t sl = bl + (sg < rem ? 1 : 0);
+                  ents.push_back(WFK_CW_ENTRY(rec16 - W.rec0, aa + k0 - h0, sl));
+                  k0 += sl;
+                }
+              }
+              if (!bad.empty()) break;
+            }
+            if (W.rec0 < 0) W.rec0 = 0;
+            W.cnt = (int32_t)((int64_t)ents.size() - W.e0);
+            wins[((size_t)c * p->npairs + pr) * 2 + half] = W;
+          }
+        }
+      }
+      if (bad.empty()) {
+        if (ents.empty()) ents.push_back(0);
+        auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+        const size_t b_ch = hs->channels.size() * sizeof(DevChannel), b_w = wins.size() * sizeof(ShortWin),
+                     b_e = ents.size() * sizeof(uint32_t);
+        const size_t o_w = al(b_ch), o_e = al(o_w + b_w), total = al(o_e + b_e) + 256;
+        if (hipMalloc(&p->d_tables, total) != hipSuccess ||
+            hipMemcpy(p->d_tables, hs->channels.data(), b_ch, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(static_cast<char*>(p->d_tables) + o_w, wins.data(), b_w, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(static_cast<char*>(p->d_tables) + o_e, ents.data(), b_e, hipMemcpyHostToDevice) != hipSuccess) {
+          wfk_chain_plan_destroy(p);
+          return chain_fail(WFK_ENOMEM, "chain table allocation failed");
+        }
+        char* base = static_cast<char*>(p->d_tables);
+        p->d_channels = reinterpret_cast<DevChannel*>(base);
+        p->d_wins = reinterpret_cast<ShortWin*>(base + o_w);
+        p->d_entries = reinterpret_cast<uint32_t*>(base + o_e);
+        p->d_recs = d_recs;
+        p->table_bytes = (int64_t)(b_ch + b_w + b_e + hs->params.size() * sizeof(double));
+        p->shortw = true;
+        p->fused = true;
+        p->why.clear();
+        *out = p;
+        return WFK_OK;
+      }
+      p->why += "; short geometry: " + bad;
+    }
+  }
   if (p->why.empty()) {
     const int64_t hop = 256 * (int64_t)p->hopb;
     const int64_t nblk = (p->n + hop - 1) / hop;
@@ -535,6 +793,7 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
     p->d_pieces = reinterpret_cast<DevPiece*>(base + o_pc);
     p->d_params = reinterpret_cast<double*>(base + o_pa);
     p->d_pair_first = reinterpret_cast<int32_t*>(base + o_pf);
+    p->table_bytes = (int64_t)total;
     p->fused = true;
   } else {
     // unfused: the samples go through a workspace owned by the plan (no allocation at launch)
@@ -552,6 +811,20 @@ int wfk_chain_is_fused(const wfk_chain_plan* p) { return p && p->fused ? 1 : 0; 
 
 const char* wfk_chain_unfused_reason(const wfk_chain_plan* p) { return p ? p->why.c_str() : ""; }
 
+int64_t wfk_chain_table_bytes(const wfk_chain_plan* p) {
+  if (!p) return chain_fail(WFK_EINVAL, "null plan");
+  return p->fused ? p->table_bytes : wfk_plan_table_bytes(p->sampler);
+}
+
+const char* wfk_chain_kernel_name(const wfk_chain_plan* p) {
+  if (!p) return "";
+  static thread_local std::string name;
+  const char* T = p->kind == WFK_OUT_F32 ? "float" : "double";
+  if (p->fused) name = std::string(p->shortw ? "fir_short<" : "fir_sampled<") + T + "," + std::to_string(p->hopb) + ">";
+  else name = std::string(wfk_plan_kernel_name(p->sampler, p->kind)) + " + FIR";
+  return name.c_str();
+}
+
 int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void* hip_stream) {
   if (!p) return chain_fail(WFK_EINVAL, "null plan");
   if (p->n == 0 || p->n_channels == 0) return WFK_OK;
@@ -566,6 +839,23 @@ int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void*
   const void *kspec = nullptr, *tw = nullptr;
   int fir_fused = 0, nseg = 0, K = 0, lead = 0;
   wfk_internal_fir_tables(p->fir, &kspec, &tw, &fir_fused, &nseg, &K, &lead);
+  if (p->shortw) {
+    ChainShortArgs a{};
+    a.channels = p->d_channels; a.wins = p->d_wins; a.entries = p->d_entries; a.recs = p->d_recs;
+    a.out = out_dev; a.out_stride = out_stride; a.n = p->n; a.npairs = p->npairs;
+    a.hspec = kspec; a.tw = tw; a.step = p->step;
+    a.hop = 256 * p->hopb; a.K = K; a.lead = lead;
+    const dim3 grid((unsigned)p->npairs, (unsigned)p->n_channels);
+    if (p->kind == WFK_OUT_F32) {
+      if (p->hopb == 12) hipLaunchKernelGGL((fir_short<float, 12>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((fir_short<float, 10>), grid, dim3(256), 0, s, a);
+    } else {
+      if (p->hopb == 12) hipLaunchKernelGGL((fir_short<double, 12>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((fir_short<double, 10>), grid, dim3(256), 0, s, a);
+    }
+    if (hipGetLastError() != hipSuccess) return chain_fail(WFK_EHIP, "fused sampler->FIR kernel launch failed");
+    return WFK_OK;
+  }
   ChainArgs a{};
   a.channels = p->d_channels; a.pieces = p->d_pieces; a.params = p->d_params; a.pair_first = p->d_pair_first;
   a.out = out_dev; a.out_stride = out_stride; a.n = p->n; a.npairs = p->npairs;

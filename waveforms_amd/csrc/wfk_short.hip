@@ -16,15 +16,17 @@
 //            the piece's compact record (16 doubles for a Gaussian + DRAG pulse).
 //   wave  -> one UNIT = <= 64 segments plus the zero stretches between them, a contiguous range
 //            of <= WFK_SH_LCAP samples of one channel.  Results go through LDS (lane l writes its
-//            run at its offset, stride-17 swizzle => no bank conflicts), then the wave stores the
+//            run at its offset; plain or stride-17 padded layout, chosen per unit by the host for
+//            the fewest bank conflicts), then the wave stores the
 //            range row by row: 64 consecutive samples per store instruction, rows aligned to
 //            128-B lines.  Long zero stretches are pure-fill units (no slots, no LDS).
 //   workgroup = one wave, walking `units_per_chunk` consecutive units; chunks are dealt to the
 //            XCDs in contiguous eighths (same map as the lean kernel).
 // All arithmetic is fp64 whatever the output type (the fp32 VALU rate of this part is the fp64
 // rate unless packed); T only sets the width of the LDS staging and of the stores.
-// Bound: HBM writes (8 / 4 / 16 B per sample) + the record and slot tables
-// ((128 B + 8 B x segments) per piece: +30 % at 60 samples per piece).  No contraction => no MFMA.
+// Bound: HBM writes (8 / 4 / 16 B per sample) + the record, slot and unit tables (96 B per op of a
+// piece, 128 B for cubics; 4 B per segment; 64 B per unit: +24 % at 60 samples per piece).
+// No contraction => no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -33,10 +35,11 @@
 
 #include "wfk.h"
 #include "wfk_internal.h"
+#include "wfk_short_dev.h"
 
 namespace {
 
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+[[maybe_unused]] __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int64_t uni64(int64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
@@ -53,183 +56,13 @@ __device__ __forceinline__ P* uniptr(P* p) {
   return (P*)reinterpret_cast<G>(uni64(reinterpret_cast<int64_t>(p)));
 }
 
-template <int... K, typename F>
-__device__ __forceinline__ void sh_for_impl(std::integer_sequence<int, K...>, F&& f) {
-  (f(std::integral_constant<int, K>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void sh_for(F&& f) {
-  sh_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
-#define SH_EACH(N, k) sh_for<N>([&](auto k##_) __attribute__((always_inline)) { constexpr int k = decltype(k##_)::value;
-#define SH_END });
-
-// polynomial coefficient pinned to an SGPR pair at its use (see wfk_fir_sampled.hip: left alone the
-// compiler hoists all of them into VGPRs that stay live across the sample loops)
-__device__ __forceinline__ double kc(double v) {
-  asm volatile("" : "+s"(v));
-  return v;
-}
-
-// sin(pi r), cos(pi r) for |r| <= 1/2: fold to z in [0, 1/4], Taylor in t = pi z (truncation < 5e-18)
-__device__ __forceinline__ void sincospi_small(double r, double* sn, double* cs) {
-  const double a = fabs(r);
-  const bool swap = a > 0.25;
-  const double z = swap ? 0.5 - a : a;                    // exact
-  const double t = z * 3.141592653589793116 + z * 1.2246467991473532e-16;
-  const double t2 = t * t;
-  double ps = kc(-2.8114572543455206e-15);                    // -1/17!
-  ps = fma(ps, t2, kc(7.6471637318198164e-13));
-  ps = fma(ps, t2, kc(-1.6059043836821613e-10));
-  ps = fma(ps, t2, kc(2.5052108385441720e-08));
-  ps = fma(ps, t2, kc(-2.7557319223985893e-06));
-  ps = fma(ps, t2, kc(1.9841269841269841e-04));
-  ps = fma(ps, t2, kc(-8.3333333333333332e-03));
-  ps = fma(ps, t2, kc(1.6666666666666666e-01));
-  const double s = fma(-t * t2, ps, t);
-  double pc = kc(1.5619206968586226e-16);                     //  1/18!
-  pc = fma(pc, t2, kc(-4.7794773323873853e-14));
-  pc = fma(pc, t2, kc(1.1470745597729725e-11));
-  pc = fma(pc, t2, kc(-2.0876756987868099e-09));
-  pc = fma(pc, t2, kc(2.7557319223985888e-07));
-  pc = fma(pc, t2, kc(-2.4801587301587302e-05));
-  pc = fma(pc, t2, kc(1.3888888888888889e-03));
-  pc = fma(pc, t2, kc(-4.1666666666666664e-02));
-  pc = fma(pc, t2, kc(0.5));
-  const double c = fma(-t2, pc, 1.0);
-  const double ss = swap ? c : s, cc = swap ? s : c;
-  *sn = r < 0.0 ? -ss : ss;
-  *cs = cc;
-}
-
-// exp(x), |x| < 700: Cody-Waite reduction, Taylor to r^14 on |r| <= ln2 / 2, ldexp
-__device__ __forceinline__ double exp_small(double x) {
-#pragma clang fp contract(off)   // the reduction's fma()s are explicit
-  const double n = rint(x * 1.4426950408889634);
-  double r = fma(-n, 6.93147180369123816490e-01, x);
-  r = fma(-n, 1.90821492927058770002e-10, r);
-  double p = kc(1.1470745597729725e-11);                      // 1/14!
-  p = fma(p, r, kc(1.6059043836821613e-10));
-  p = fma(p, r, kc(2.0876756987868099e-09));
-  p = fma(p, r, kc(2.5052108385441720e-08));
-  p = fma(p, r, kc(2.7557319223985888e-07));
-  p = fma(p, r, kc(2.7557319223985893e-06));
-  p = fma(p, r, kc(2.4801587301587302e-05));
-  p = fma(p, r, kc(1.9841269841269841e-04));
-  p = fma(p, r, kc(1.3888888888888889e-03));
-  p = fma(p, r, kc(8.3333333333333332e-03));
-  p = fma(p, r, kc(4.1666666666666664e-02));
-  p = fma(p, r, kc(1.6666666666666666e-01));
-  p = fma(p, r, kc(0.5));
-  p = fma(p, r, kc(1.0));
-  p = fma(p, r, kc(1.0));
-  return ldexp(p, (int)n);
-}
+using namespace shdev;
 
 template <typename T> struct ShOut;
 template <> struct ShOut<double> { using Cplx = double2; };
 template <> struct ShOut<float> { using Cplx = float2; };
 
 __device__ __forceinline__ int swz(int i) { return i + (i >> 4); }   // lane stride 16 -> 17 elements
-
-__device__ __forceinline__ double clip_np(double v, double lo, double hi) {
-  v = v < lo ? lo : v;       // np.clip: NaN propagates
-  v = v > hi ? hi : v;
-  return v;
-}
-
-// one op record in registers (the first op of the NEXT unit is fetched while this unit stores)
-struct OpRec {
-  double2 a, b, c, d, e, f;    // doubles 0..11 of the record (WFK_SH_OP1)
-};
-__device__ __forceinline__ OpRec load_op(const double* p) {
-  const double2* q = reinterpret_cast<const double2*>(p);
-  OpRec r;
-#if defined(WFK_SH_EXP) && WFK_SH_EXP == 2
-  r.a = r.b = r.c = r.d = r.e = r.f = make_double2(1.0, 0.5);   // timing experiment: no record traffic
-  return r;
-#endif
-  r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4]; r.f = q[5];
-  return r;
-}
-__device__ __forceinline__ int op_word(const OpRec& r) { return (int)__double2loint(r.a.x); }
-__device__ __forceinline__ int op_ref(const OpRec& r) { return (int)__double2hiint(r.a.x); }
-
-// one fused op over the lane's run: acc[k] += E_k (A(u_k) c_k + B(u_k) s_k), all state per lane.
-// `kf`: samples between the record's reference sample and the lane's first one.
-template <int R, bool CUBIC, bool CPLX>
-__device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w, double kf, double step,
-                                         double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
-  const int env = (w >> 4) & 3;
-  const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.x, q = o.d.y;
-  const double A0 = o.e.x, A1 = o.e.y, B0 = o.f.x, B1 = o.f.y;
-  double A2 = 0.0, A3 = 0.0, B2 = 0.0, B3 = 0.0;
-  if constexpr (CUBIC) {
-    if ((w & 3) > 1) { A2 = op[12]; A3 = op[13]; B2 = op[14]; B3 = op[15]; }
-  }
-  // exact seeds at the lane's first sample, `kf` samples after the record's reference sample
-  double c, s;
-  {
-    const double x = fma(kf, o.b.x, o.a.y);       // phase / pi
-    const double n = rint(x);
-    sincospi_small(x - n, &s, &c);
-    if (((int)n) & 1) { c = -c; s = -s; }
-  }
-  const double vv = fma(kf, Hh, o.c.y);
-  const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
-  const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
-  double g = exp_small(ea), r = exp_small(eb);
-  double u = kf * step;
-  double mr = 1.0, mi = 0.0;
-  if constexpr (CPLX) {
-    if (w & 8) { mr = 0.0; mi = 1.0; }
-  }
-  SH_EACH(R, k)
-    double pa, pb;
-    if constexpr (CUBIC) {
-      pa = fma(fma(fma(A3, u, A2), u, A1), u, A0);
-      pb = fma(fma(fma(B3, u, B2), u, B1), u, B0);
-    } else {
-      pa = fma(A1, u, A0);
-      pb = fma(B1, u, B0);
-    }
-    const double val = fma(pa, c, pb * s);
-    if constexpr (CPLX) {
-      const double t = val * g;
-      acc[k] = fma(mr, t, acc[k]);
-      acci[k] = fma(mi, t, acci[k]);
-    } else {
-      acc[k] = fma(val, g, acc[k]);
-    }
-    if constexpr (k + 1 < R) {
-      g *= r;
-      r *= q;
-      const double cn = fma(c, C1, -(s * S1));
-      s = fma(s, C1, c * S1);
-      c = cn;
-      u += step;
-    }
-  SH_END
-}
-
-// libm erf behind a call: inlined sixteen times into the closing op it would triple the kernel
-__device__ __attribute__((noinline)) double erf_call(double x) { return erf(x); }
-
-// Closing op of a flat-top edge (square(width, edge): 0.5 +- 0.5 erf((t - s) / sigma), reference
-// waveform.py:1096-1112): everything the piece's ops accumulated so far is multiplied by
-// m0 + m1 erf(v_k), v_k = v0 + (koff + k) H.  At AWG rates an edge is a handful of samples and H = dt / sigma
-// is of order 1, so erf is simply evaluated per sample (the lean kernel's Taylor-step form needs H <= 0.09).
-template <int R, bool CPLX>
-__device__ __forceinline__ void short_erfmul(const OpRec& o, double kf, double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
-  const double h = o.d.x, m0 = o.e.x, m1 = o.e.y;
-  double v = fma(kf, h, o.c.y);
-  SH_EACH(R, k)
-    const double m = fma(m1, erf_call(v), m0);
-    acc[k] *= m;
-    if constexpr (CPLX) acci[k] *= m;
-    v += h;
-  SH_END
-}
 
 #ifndef WFK_SH_WAVES
 #define WFK_SH_WAVES 3

@@ -50,7 +50,8 @@ class FirStage:
 
 class SampledFir:
     """`predistort(wav(t), ker=ker)` for many channels on one uniform grid, device-resident:
-    the sampler runs INSIDE the FIR transform when the channels are fully fused (`fused`), so
+    the sampler runs INSIDE the FIR transform when the channels are fully fused (`fused`; on fine grids
+    as stride-256 chains, at AWG sample rates the short tier's way: `plan.kernel_name()`), so
     the unfiltered samples never touch HBM (reference chain: waveform.py:529-563 ->
     distortion.py:329-337).  Build once, launch many times.
 
@@ -58,11 +59,12 @@ class SampledFir:
         sf.launch_torch(out)          # (n_channels, >= n) device tensor of the plan dtype
     """
 
-    def __init__(self, channels, grid, ker, dtype=np.float64, function_lib=None):
+    def __init__(self, channels, grid, ker, dtype=np.float64, function_lib=None, tile=1):
+        """`tile` > 1 repeats the channel list that many times (synthetic batches, as BatchSampler's)"""
         from . import _flatten
         if not isinstance(grid, _flatten.wfk_grid):
             grid = _flatten.grid_from_desc(grid)
-        self.prog = _flatten.flatten(list(channels), grid, function_lib)
+        self.prog = _flatten.tile_program(_flatten.flatten(list(channels), grid, function_lib), tile)
         self.plan = _engine.ChainPlan(self.prog, grid, ker, dtype)
         self.n, self.n_channels, self.dtype = self.plan.n, self.plan.n_channels, np.dtype(dtype)
         self.fused, self.why_not = self.plan.fused, self.plan.why_not
