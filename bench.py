@@ -662,6 +662,9 @@ def run_rank(args):
                                   'table_bytes_per_launch': tb4,
                                   'frac_incl_tables': (nbytes + tb4) / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   'unfused': {'sampler_kernel_ms': ms, 'fir_kernel_ms': msf, 'step_ms': ms + msf}}
+                rv4 = valu_roofline('awg_c4', ms4, b2.n_channels * b2.n) if chn2.fused else None
+                if rv4 is not None:
+                    also['awg_c4']['roofline_valu'] = rv4
                 fst2.close()
                 chn2.close()
                 del o4

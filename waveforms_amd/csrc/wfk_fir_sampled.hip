@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
 struct ShortWin {        // one half of one pair of windows of one channel
   int64_t rec0;          // base of the records its entries refer to (units of 16 B)
   int64_t e0;            // first entry
-  int32_t cnt, pad;
+  int32_t cnt, pad;      // pad: LDS layout of the half (1: one spare element per 16)
 };
 #define WFK_CW_ENTRY(drec, o, len) ((uint32_t)(drec) | ((uint32_t)(o) << 16) | ((uint32_t)((len) - 1) << 28))
 
@@ -485,12 +485,13 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
   // both halves at once
   const ShortWin* const wp0 = a.wins + ((int64_t)ch * a.npairs + pair) * 2;
   int64_t w_rec0[2], w_e0[2];
-  int w_cnt[2];
+  int w_cnt[2], w_pad[2];
   uint32_t w_first[2];
   CH_EACH(2, half)
     w_rec0[half] = wp0[half].rec0;
     w_e0[half] = wp0[half].e0;
     w_cnt[half] = cuni(wp0[half].cnt);
+    w_pad[half] = cuni(wp0[half].pad);
     w_first[half] = tid < w_cnt[half] ? a.entries[w_e0[half] + tid] : 0u;
   CH_END
 
@@ -498,13 +499,20 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
   CH_EACH(2, half)
     const int64_t h0 = s1 + (int64_t)HALF * half;
     __syncthreads();                                       // the previous half has been picked up
+    // Layout of the half in the array, chosen by the host for the half's own entries: plain (sample i at
+    // element i: conflict-free when the runs start an odd number of samples apart, 15 for 60-sample
+    // pulses) or padded by one element per 16 (i + (i >> 4): runs of 16 then start 17 apart).  The
+    // wrong one makes every write of a wave hit one bank pair (PMC: 27 % of the LDS pipe's time).
+    const bool sw = w_pad[half] != 0;
+    const int rs = sw ? 272 : 256;                         // row stride of the thread's own samples
+    T* const mine = lds + (sw ? tid + (tid >> 4) : tid);
     // zero padding outside [0, n), the channel offset inside (skipped _zero pieces, gaps between entries)
     if (h0 >= 0 && h0 + HALF <= a.n) {
-      CH_EACH(HR, k) lds[272 * k + tid + (tid >> 4)] = (T)base; CH_END
+      CH_EACH(HR, k) mine[rs * k] = (T)base; CH_END
     } else {
       CH_EACH(HR, k)
         const int64_t j = h0 + 256 * k + tid;
-        lds[272 * k + tid + (tid >> 4)] = (j >= 0 && j < a.n) ? (T)base : (T)0;
+        mine[rs * k] = (j >= 0 && j < a.n) ? (T)base : (T)0;
       CH_END
     }
     __syncthreads();
@@ -546,14 +554,14 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
         CH_EACH(R, k) acc[k] = shdev::clip_np(acc[k], C.clip_lo, C.clip_hi); CH_END
       }
       // element o + k of the half sits at (o + k) + ((o + k) >> 4) = swz(o) + k + [k >= 16 - (o & 15)]
-      T* const b0 = lds + (o + (o >> 4));
-      const int t = 16 - (o & 15);
+      T* const b0 = lds + (sw ? o + (o >> 4) : o);
+      const int t = sw ? 16 - (o & 15) : 99;
       CH_EACH(R, k)
         if (k < len) *((k >= t ? b0 + 1 : b0) + k) = (T)(acc[k] + base);
       CH_END
     }
     __syncthreads();
-    CH_EACH(HR, k) x[half * HR + k] = lds[272 * k + tid + (tid >> 4)]; CH_END
+    CH_EACH(HR, k) x[half * HR + k] = mine[rs * k]; CH_END
   CH_END
   __syncthreads();                                         // the array becomes the FFT exchange buffer
 
@@ -729,6 +737,21 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
             }
             if (W.rec0 < 0) W.rec0 = 0;
             W.cnt = (int32_t)((int64_t)ents.size() - W.e0);
+            {
+              // LDS layout of the half: per wave of 64 entries, the fullest of the 16 bank pairs the runs'
+              // first elements fall into, plain vs padded
+              int64_t cp = 0, cq = 0;
+              for (int64_t e = W.e0; e < (int64_t)ents.size(); e += 64) {
+                int plain[16] = {0}, padded[16] = {0}, wp = 0, wq = 0;
+                for (int64_t k = e; k < std::min<int64_t>(e + 64, (int64_t)ents.size()); ++k) {
+                  const int o = (int)((ents[(size_t)k] >> 16) & 0xfff);
+                  wp = std::max(wp, ++plain[o & 15]);
+                  wq = std::max(wq, ++padded[(o + (o >> 4)) & 15]);
+                }
+                cp += wp; cq += wq;
+              }
+              W.pad = cq < cp ? 1 : 0;
+            }
             wins[((size_t)c * p->npairs + pr) * 2 + half] = W;
           }
         }
