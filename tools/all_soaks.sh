@@ -1,6 +1,7 @@
 #!/bin/bash
 # the GPU soaks in one call (counts quoted in DESIGN.md 4):  bash tools/all_soaks.sh > gpurun_out/all_soaks.log
 python tools/fuzz_soak.py 1000 12000 | tail -n 1 | sed 's/^/fuzz_soak (random scripts x grids, f64 \/ f32 \/ tlist vs the C oracle): /'
+python tools/fuzz_soak.py 50000 4000 awg | tail -n 1 | sed 's/^/fuzz_soak awg (random pulse trains on 1-5 GS\/s grids): /'
 python tools/erf_soak.py 0 6000 | tail -n 1 | sed 's/^/erf_soak (flat tops around the admission limit): /'
 python tools/fuzz_soak_big.py | tail -n 1 | sed 's/^/fuzz_soak_big (long grids, offsets): /'
 python tools/stage_soak.py 1500 2>/dev/null | tail -n 1 | sed 's/^/stage_soak (FIR \/ IIR \/ chain vs SciPy): /'

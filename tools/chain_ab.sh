@@ -3,6 +3,6 @@
 cd "$(dirname "$0")/.."
 for v in "$@"; do
   lib=waveforms_amd/csrc/libwfk_hip.so; [ "$v" != default ] && lib=_ab/libwfk_$v.so
-  WFK_LIB=$PWD/$lib python bench.py --workload c4 --no-cpu-baseline --steps 10 2>/dev/null | python -c "
+  WFK_LIB=$PWD/$lib python bench.py --workload ${WL:-c4} --no-cpu-baseline --no-also --steps 10 2>/dev/null | python -c "
 import json,sys; l=json.loads(sys.stdin.read()); print('$v', 'kernel_ms %.3f' % l['roofline']['kernel_ms'], l['roofline']['kernel'])"
 done

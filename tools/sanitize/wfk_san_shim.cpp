@@ -4,6 +4,7 @@
 // the compiler produced, so out-of-bounds content would be read (and caught) here too.
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "wfk.h"
 #include "wfk_internal.h"
@@ -80,6 +81,50 @@ extern "C" int wfk_san_compile(const wfk_program* prog, const wfk_grid* grid, co
           next_j = 0; fp = H.channels[c].piece_begin;
           if (!skip_foreign(c, H.n)) return -1110;
         }
+      }
+    }
+    if (H.shortp && !H.mixed) {
+      // window tables of the fused sampler -> FIR chain at AWG rates (wfk_chain_windows): for K = 1024 and
+      // K = 1537 geometries, the entries of every half window are in order, disjoint, inside the half and
+      // inside [0, n), reference records inside params[], and cover exactly the evaluated pieces' samples
+      for (int geo = 0; geo < 2; ++geo) {
+        const int64_t hopb = geo ? 10 : 12, hop = 256 * hopb, half = 128 * (16 + hopb), lead = geo ? 1536 : 1023;
+        const int64_t nblk = (H.n + hop - 1) / hop, npairs = (nblk + 1) / 2;
+        std::vector<ShortWin> wins;
+        std::vector<uint32_t> ents;
+        std::string why;
+        if (wfk_chain_windows(H, H.n, hop, lead, half, npairs, wins, ents, why) != 0) { d += 1.0; continue; }   // (record span limit: a legal refusal)
+        if ((int64_t)wins.size() != npairs * H.n_channels * 2) return -1200;
+        for (int32_t c = 0; c < H.n_channels; ++c)
+          for (int64_t pr = 0; pr < npairs; ++pr)
+            for (int hf = 0; hf < 2; ++hf) {
+              const ShortWin& W = wins[((size_t)c * npairs + pr) * 2 + hf];
+              const int64_t h0 = 2 * pr * hop - lead + half * hf;
+              const int64_t w0 = h0 > 0 ? h0 : 0, w1 = h0 + half < H.n ? h0 + half : H.n;
+              if (W.cnt < 0 || W.e0 < 0 || W.e0 + W.cnt > (int64_t)ents.size() || W.rec0 < 0) return -1201;
+              int64_t covered = 0, prev = w0;
+              for (int32_t k = 0; k < W.cnt; ++k) {
+                const uint32_t w = ents[(size_t)(W.e0 + k)];
+                const int64_t o = (w >> 16) & 0xfff, len = (w >> 28) + 1, j = h0 + o;
+                if (j < prev || j + len > w1 || len > WFK_SH_R) return -1202;
+                prev = j + len; covered += len;
+                const int64_t at = 2 * (W.rec0 + (int64_t)(w & 0xffff));
+                if (at < 0 || at + WFK_SH_OP1 > (int64_t)H.params.size()) return -1203;
+                uint64_t word;
+                __builtin_memcpy(&word, &H.params[(size_t)at], sizeof word);
+                const int64_t ref = (int64_t)(word >> 32);
+                if (ref > j || j - ref >= WFK_SH_SUB) return -1204;
+              }
+              int64_t want = 0;        // evaluated samples of the channel inside the half
+              for (int32_t q = H.channels[c].piece_begin; q < H.channels[c].piece_end; ++q) {
+                const DevPiece& P = H.pieces[q];
+                if (P.n_blk == 0) continue;
+                const int64_t a = P.start > w0 ? P.start : w0, b = P.stop < w1 ? P.stop : w1;
+                if (b > a) want += b - a;
+              }
+              if (covered != want) return -1205;
+              d += (double)W.cnt + W.pad;
+            }
       }
     }
     for (const DevPiece& p : H.pieces) {

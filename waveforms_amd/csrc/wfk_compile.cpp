@@ -1613,3 +1613,71 @@ extern "C" int wfk_grid_detect(const double* t, int64_t n, wfk_grid* out) {
   }
   return 0;
 }
+
+// ---- sampler fused into the FIR transform at AWG rates: half-window entry lists ----------------------
+// (reference chain: waveform.py:190-192 -> distortion.py:329-337; consumer: fir_short, wfk_fir_sampled.hip)
+int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half_len, int64_t npairs,
+                      std::vector<ShortWin>& wins, std::vector<uint32_t>& ents, std::string& bad) {
+  bad.clear();
+  if (!H.shortp || H.mixed) { bad = "not a pure short plan"; return WFK_EINVAL; }
+  if (half_len <= 0 || half_len > 4096 || hop <= 0 || npairs < 0) { bad = "window geometry"; return WFK_EINVAL; }
+  const int32_t nch = (int32_t)H.channels.size();
+  wins.assign((size_t)npairs * nch * 2, ShortWin{});
+  ents.clear();
+  ents.reserve((size_t)(n / 12) * nch);
+  for (int32_t c = 0; c < nch && bad.empty(); ++c) {
+    const int32_t pe = H.channels[c].piece_end;
+    int32_t q = H.channels[c].piece_begin;
+    for (int64_t pr = 0; pr < npairs && bad.empty(); ++pr) {
+      const int64_t s1 = 2 * pr * hop - lead;
+      while (q < pe - 1 && H.pieces[q].stop <= s1) ++q;
+      for (int hf = 0; hf < 2; ++hf) {
+        const int64_t h0 = s1 + half_len * hf;
+        const int64_t w0 = std::max<int64_t>(h0, 0), w1 = std::min<int64_t>(h0 + half_len, n);
+        ShortWin W{};
+        W.rec0 = -1;
+        W.e0 = (int64_t)ents.size();
+        for (int32_t qq = q; qq < pe && H.pieces[qq].start < w1; ++qq) {
+          const DevPiece& D = H.pieces[qq];
+          if (D.n_blk == 0 || D.stop <= w0) continue;          // zero stretch (the prefill) / before the half
+          const int64_t a0 = std::max(D.start, w0), b0 = std::min(D.stop, w1);
+          for (int64_t m = (a0 - D.start) / WFK_SH_SUB; D.start + m * WFK_SH_SUB < b0; ++m) {
+            const int64_t r0 = D.start + m * WFK_SH_SUB, r1 = std::min<int64_t>(r0 + WFK_SH_SUB, D.stop);
+            const int64_t aa = std::max(a0, r0), bb = std::min(b0, r1), len = bb - aa;
+            if (len <= 0) continue;
+            const int64_t rec16 = (D.par_off + m * (int64_t)D.first_len) / 2;
+            if (W.rec0 < 0) W.rec0 = rec16;
+            if (rec16 - W.rec0 > 0xffff) { bad = "op records of one window span more than 1 MB"; break; }
+            const int64_t nsg = (len + WFK_SH_R - 1) / WFK_SH_R, bl = len / nsg, rem = len % nsg;
+            int64_t k0 = 0;
+            for (int64_t sg = 0; sg < nsg; ++sg) {
+              const int64_t sl = bl + (sg < rem ? 1 : 0);
+              ents.push_back(WFK_CW_ENTRY(rec16 - W.rec0, aa + k0 - h0, sl));
+              k0 += sl;
+            }
+          }
+          if (!bad.empty()) break;
+        }
+        if (W.rec0 < 0) W.rec0 = 0;
+        W.cnt = (int32_t)((int64_t)ents.size() - W.e0);
+        {
+          // LDS layout of the half: per wave of 64 entries, the fullest of the 16 bank pairs the runs'
+          // first elements fall into, plain vs padded
+          int64_t cp = 0, cq = 0;
+          for (int64_t e = W.e0; e < (int64_t)ents.size(); e += 64) {
+            int plain[16] = {0}, padded[16] = {0}, wp = 0, wq = 0;
+            for (int64_t k = e; k < std::min<int64_t>(e + 64, (int64_t)ents.size()); ++k) {
+              const int o = (int)((ents[(size_t)k] >> 16) & 0xfff);
+              wp = std::max(wp, ++plain[o & 15]);
+              wq = std::max(wq, ++padded[(o + (o >> 4)) & 15]);
+            }
+            cp += wp; cq += wq;
+          }
+          W.pad = cq < cp ? 1 : 0;
+        }
+        wins[((size_t)c * npairs + pr) * 2 + hf] = W;
+      }
+    }
+  }
+  return bad.empty() ? WFK_OK : WFK_EINVAL;
+}

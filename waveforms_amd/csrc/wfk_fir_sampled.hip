@@ -442,13 +442,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
 // lanes).  Zero padding and the channel offset are a prefill of the half before its entries are written.
 // The host cuts the pieces of the sampler's own short plan into per-half entry lists
 // (wfk_chain_plan_create); the op records are the plan's, read where they are.
-struct ShortWin {        // one half of one pair of windows of one channel
-  int64_t rec0;          // base of the records its entries refer to (units of 16 B)
-  int64_t e0;            // first entry
-  int32_t cnt, pad;      // pad: LDS layout of the half (1: one spare element per 16)
-};
-#define WFK_CW_ENTRY(drec, o, len) ((uint32_t)(drec) | ((uint32_t)(o) << 16) | ((uint32_t)((len) - 1) << 28))
-
+// (ShortWin, WFK_CW_ENTRY: wfk_internal.h; the tables are built by wfk_chain_windows, wfk_compile.cpp)
 struct ChainShortArgs {
   const DevChannel* channels;
   const ShortWin* wins;       // [n_channels * npairs * 2]
@@ -495,6 +489,12 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
     w_first[half] = tid < w_cnt[half] ? a.entries[w_e0[half] + tid] : 0u;
   CH_END
 
+  // (The third, the op record, is loaded where it is used.  Tried: half 1's record loaded a half ahead --
+  // 24 more live VGPRs on top of 168, 45 spilled, 1.05 -> 1.32 ms; one dword of each record loaded here to
+  // warm L2 -- 1.045 vs 1.052 ms, nothing.  Timing experiments on 2048 x 1e5 (-DWFK_FSH_EXP): without the
+  // evaluation 0.73 ms, i.e. the sampling phases cost 0.32 ms against 0.23 ms of pure VALU issue for
+  // their 37 instructions per sample: they are issue-bound like the transform, not latency-bound.)
+
   T x[CL];                                                 // the thread's samples: s1 + tid + 256 k
   CH_EACH(2, half)
     const int64_t h0 = s1 + (int64_t)HALF * half;
@@ -525,7 +525,16 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
       const int len = live ? (int)(word >> 28) + 1 : 0;
       const int o = (int)((word >> 16) & 0xfff);
       const double* op = a.recs + 2 * (rec0 + (int64_t)(word & 0xffff));
+#if defined(WFK_FSH_EXP) && WFK_FSH_EXP == 2
+      shdev::OpRec rec;                                    // timing experiment: no record traffic
+      rec.a = rec.b = rec.c = rec.d = rec.e = rec.f = make_double2(1.0 + word, 0.5);
+      rec.a.x = __hiloint2double(0, WFK_SH_LAST | 0x15);
+#else
       shdev::OpRec rec = shdev::load_op(op);
+#endif
+#if defined(WFK_FSH_EXP) && WFK_FSH_EXP == 1
+      live = false;                                        // timing experiment: no evaluation
+#endif
       const double kf = (double)((int)(uint32_t)(h0 + o) - shdev::op_ref(rec));   // samples from the record's reference sample
       double acc[R], acci[1];
       CH_EACH(R, k) acc[k] = 0.0; CH_END
@@ -698,64 +707,10 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
       const int64_t hop = 256 * (int64_t)p->hopb, HALF = 128 * (int64_t)(16 + p->hopb);
       const int64_t nblk = (p->n + hop - 1) / hop;
       p->npairs = (nblk + 1) / 2;
-      std::vector<ShortWin> wins((size_t)p->npairs * p->n_channels * 2);
+      std::vector<ShortWin> wins;
       std::vector<uint32_t> ents;
-      ents.reserve((size_t)(p->n / 12) * p->n_channels);
       std::string bad;
-      for (int32_t c = 0; c < p->n_channels && bad.empty(); ++c) {
-        const int32_t pe = hs->channels[c].piece_end;
-        int32_t q = hs->channels[c].piece_begin;
-        for (int64_t pr = 0; pr < p->npairs && bad.empty(); ++pr) {
-          const int64_t s1 = 2 * pr * hop - lead;
-          while (q < pe - 1 && hs->pieces[q].stop <= s1) ++q;
-          for (int half = 0; half < 2; ++half) {
-            const int64_t h0 = s1 + HALF * half;
-            const int64_t w0 = std::max<int64_t>(h0, 0), w1 = std::min<int64_t>(h0 + HALF, p->n);
-            ShortWin W{};
-            W.rec0 = -1;
-            W.e0 = (int64_t)ents.size();
-            for (int32_t qq = q; qq < pe && hs->pieces[qq].start < w1; ++qq) {
-              const DevPiece& D = hs->pieces[qq];
-              if (D.n_blk == 0 || D.stop <= w0) continue;          // zero stretch (the prefill) / before the half
-              const int64_t a0 = std::max(D.start, w0), b0 = std::min(D.stop, w1);
-              for (int64_t m = (a0 - D.start) / WFK_SH_SUB; D.start + m * WFK_SH_SUB < b0; ++m) {
-                const int64_t r0 = D.start + m * WFK_SH_SUB, r1 = std::min<int64_t>(r0 + WFK_SH_SUB, D.stop);
-                const int64_t aa = std::max(a0, r0), bb = std::min(b0, r1), len = bb - aa;
-                if (len <= 0) continue;
-                const int64_t rec16 = (D.par_off + m * (int64_t)D.first_len) / 2;
-                if (W.rec0 < 0) W.rec0 = rec16;
-                if (rec16 - W.rec0 > 0xffff) { bad = "op records of one window span more than 1 MB"; break; }
-                const int64_t nsg = (len + WFK_SH_R - 1) / WFK_SH_R, bl = len / nsg, rem = len % nsg;
-                int64_t k0 = 0;
-                for (int64_t sg = 0; sg < nsg; ++sg) {
-                  const int64_t sl = bl + (sg < rem ? 1 : 0);
-                  ents.push_back(WFK_CW_ENTRY(rec16 - W.rec0, aa + k0 - h0, sl));
-                  k0 += sl;
-                }
-              }
-              if (!bad.empty()) break;
-            }
-            if (W.rec0 < 0) W.rec0 = 0;
-            W.cnt = (int32_t)((int64_t)ents.size() - W.e0);
-            {
-              // LDS layout of the half: per wave of 64 entries, the fullest of the 16 bank pairs the runs'
-              // first elements fall into, plain vs padded
-              int64_t cp = 0, cq = 0;
-              for (int64_t e = W.e0; e < (int64_t)ents.size(); e += 64) {
-                int plain[16] = {0}, padded[16] = {0}, wp = 0, wq = 0;
-                for (int64_t k = e; k < std::min<int64_t>(e + 64, (int64_t)ents.size()); ++k) {
-                  const int o = (int)((ents[(size_t)k] >> 16) & 0xfff);
-                  wp = std::max(wp, ++plain[o & 15]);
-                  wq = std::max(wq, ++padded[(o + (o >> 4)) & 15]);
-                }
-                cp += wp; cq += wq;
-              }
-              W.pad = cq < cp ? 1 : 0;
-            }
-            wins[((size_t)c * p->npairs + pr) * 2 + half] = W;
-          }
-        }
-      }
+      (void)wfk_chain_windows(*hs, p->n, hop, lead, HALF, p->npairs, wins, ents, bad);
       if (bad.empty()) {
         if (ents.empty()) ents.push_back(0);
         auto al = [](size_t x) { return (x + 255) & ~size_t(255); };

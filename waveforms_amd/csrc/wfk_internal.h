@@ -282,6 +282,20 @@ int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tli
 int wfk_compile_geom(const wfk_program* prog, const wfk_grid* grid, int lane_stride, int ns,
                      HostPlan& out, std::string& err);
 
+// Sampler fused into the FIR transform at AWG rates (fir_short, wfk_fir_sampled.hip): the pieces of a pure
+// short plan cut into per-half-window entry lists.  Window pair `pr` of a row starts at sample
+// 2 pr hop - lead and is sampled in two halves of `half` samples; an entry is a run of <= WFK_SH_R
+// contiguous samples of one piece inside one half.
+struct ShortWin {        // one half of one pair of windows of one channel
+  int64_t rec0;          // base of the records its entries refer to (units of 16 B)
+  int64_t e0;            // first entry
+  int32_t cnt, pad;      // pad: LDS layout of the half (1: one spare element per 16)
+};
+#define WFK_CW_ENTRY(drec, o, len) ((uint32_t)(drec) | ((uint32_t)(o) << 16) | ((uint32_t)((len) - 1) << 28))
+// -> wins[(c * npairs + pr) * 2 + h], entries; returns 0, or WFK_EINVAL with the reason in err
+int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half, int64_t npairs,
+                      std::vector<ShortWin>& wins, std::vector<uint32_t>& entries, std::string& err);
+
 // kernels (wfk_kernels.hip)
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns,
                        bool lean, bool generic, bool direct, void* stream, std::string& err);
