@@ -197,7 +197,9 @@ int wfk_fir_plan_destroy(wfk_fir_plan* plan);
  * `grid`.  When every piece of the program is fully fused (carrier-envelope ops only, no clip, real
  * amplitudes) and the kernel fits one on-chip transform (K <= 1537) the FIR workgroups EVALUATE
  * their input windows instead of loading them: the samples never touch HBM and the chain moves the
- * 8 (4) B/sample of the filtered output only.  Otherwise the plan owns a workspace and runs
+ * 8 (4) B/sample of the filtered output only.  At AWG sample rates (plans in the short geometry) the
+ * windows are sampled the short tier's way (fir_short); pieces without a short form travel through a
+ * sparsely written workspace.  Otherwise the plan owns a workspace and runs
  * sampler -> workspace -> FIR (wfk_chain_is_fused() == 0, wfk_chain_unfused_reason() says why).
  * wfk_chain_launch() allocates nothing and does not synchronise.                              */
 typedef struct wfk_chain_plan wfk_chain_plan;

@@ -109,7 +109,7 @@ def test_short_chain_kernel_lengths_offsets_and_ragged_ends(K):
         sf.close()
 
 
-def test_short_chain_flat_tops_clip_and_mixed_fall_back():
+def test_short_chain_flat_tops_clip_and_mixed_plans():
     rate, n = 2e9, 40_000
     grid = wl.awg_grid(n, rate)
     ker = _kernel(1024, 11)
@@ -121,11 +121,20 @@ def test_short_chain_flat_tops_clip_and_mixed_fall_back():
     assert sf.fused and sf.plan.kernel_name() == 'fir_short<double,12>', (sf.why_not, sf.plan.kernel_name())
     assert np.max(np.abs(sf.to_host() - _oracle_chain([flat, clipped], grid, ker))) <= 1e-12
     sf.close()
-    # a piece the short tier cannot take (a chirp -> general kernel in a second launch): two-kernel chain
-    mixed = wl.awg_channel(wf, 0, n, rate) + (wf.chirp(1e8, 2e8, 30e-9) >> 5e-6)
-    sf = SampledFir([mixed], grid, ker)
+    # pieces the short tier cannot take (a chirp, a mollifier): the general kernel writes just those to the
+    # chain's workspace in a launch of its own, the transform's workgroups copy them into their windows
+    mixed = [wl.awg_channel(wf, 0, n, rate) + (wf.chirp(1e8, 2e8, 30e-9) >> 5e-6) + 0.2,
+             wl.awg_channel(wf, 1, n, rate, True) + (wf.mollifier(40e-9) >> 7.03e-6) + (wf.mollifier(8e-9) >> 3e-9),
+             wl.awg_channel(wf, 2, n, rate)]
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        sf = SampledFir(mixed, grid, ker, dt)
+        assert sf.fused and 'fir_short<' in sf.plan.kernel_name() and sf.plan.kernel_name().startswith('wfk_sample<'), \
+            (sf.why_not, sf.plan.kernel_name())
+        assert np.max(np.abs(sf.to_host() - _oracle_chain(mixed, grid, ker))) <= tol
+        sf.close()
+    # a plan dominated by such pieces is not a short plan at all: two-kernel chain
+    sf = SampledFir([(wf.square(30e-9, edge=14e-9) >> 1e-6) * wf.sinc(3e7)], grid, ker)
     assert not sf.fused and '+ FIR' in sf.plan.kernel_name()
-    assert np.max(np.abs(sf.to_host() - _oracle_chain([mixed], grid, ker))) <= 1e-12
     sf.close()
 
 
@@ -283,3 +292,28 @@ def test_erf_channels_take_the_two_kernel_path_and_exponentials_fuse():
     sx.launch_torch(out)
     torch.cuda.synchronize()
     assert float((out - two_kernels(exp_ch)).abs().max()) <= 1e-12
+
+
+def test_short_chain_fuzz_over_random_awg_pulse_trains():
+    """random pulse trains on 1-5 GS/s grids (every fusable shape, erf edges, vstacks, clips, offsets): the chain
+    against the oracle whichever kernel the plan takes; most of them must take fir_short"""
+    import cases
+    took = {}
+    for seed in range(60):
+        rng = np.random.default_rng(40_000 + seed)
+        ch, grid = cases.random_awg_channel(wf, rng)
+        prog = _flatten.flatten([ch])
+        if prog.complex_amp:
+            continue                                  # (predistort of a complex signal is not a chain case)
+        ker = _kernel(int(rng.choice([1, 7, 300, 1024, 1400])), seed)
+        g = _flatten.grid_from_desc(grid)
+        y = c_oracle.eval_grid(prog, g)[0]
+        want = c_oracle.fir(y, ker)
+        sf = SampledFir([ch], grid, ker)
+        kn = 'fir_short' if 'fir_short<' in sf.plan.kernel_name() else sf.plan.kernel_name().split('<')[0]
+        took[kn] = took.get(kn, 0) + 1
+        got = sf.to_host()[0]
+        pk = max(1.0, float(np.abs(y).max(initial=0.0)))
+        assert np.max(np.abs(got - want), initial=0.0) <= 1e-9 * pk, (seed, kn, sf.why_not)
+        sf.close()
+    assert took.get('fir_short', 0) >= 40, took

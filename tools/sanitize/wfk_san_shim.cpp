@@ -83,7 +83,7 @@ extern "C" int wfk_san_compile(const wfk_program* prog, const wfk_grid* grid, co
         }
       }
     }
-    if (H.shortp && !H.mixed) {
+    if (H.shortp) {
       // window tables of the fused sampler -> FIR chain at AWG rates (wfk_chain_windows): for K = 1024 and
       // K = 1537 geometries, the entries of every half window are in order, disjoint, inside the half and
       // inside [0, n), reference records inside params[], and cover exactly the evaluated pieces' samples
@@ -101,7 +101,8 @@ extern "C" int wfk_san_compile(const wfk_program* prog, const wfk_grid* grid, co
               const ShortWin& W = wins[((size_t)c * npairs + pr) * 2 + hf];
               const int64_t h0 = 2 * pr * hop - lead + half * hf;
               const int64_t w0 = h0 > 0 ? h0 : 0, w1 = h0 + half < H.n ? h0 + half : H.n;
-              if (W.cnt < 0 || W.e0 < 0 || W.e0 + W.cnt > (int64_t)ents.size() || W.rec0 < 0) return -1201;
+              if (W.cnt < 0 || W.ccnt < 0 || W.e0 < 0 || W.e0 + W.cnt + W.ccnt > (int64_t)ents.size() || W.rec0 < 0) return -1201;
+              if (!H.mixed && W.ccnt != 0) return -1206;
               int64_t covered = 0, prev = w0;
               for (int32_t k = 0; k < W.cnt; ++k) {
                 const uint32_t w = ents[(size_t)(W.e0 + k)];
@@ -115,14 +116,22 @@ extern "C" int wfk_san_compile(const wfk_program* prog, const wfk_grid* grid, co
                 const int64_t ref = (int64_t)(word >> 32);
                 if (ref > j || j - ref >= WFK_SH_SUB) return -1204;
               }
-              int64_t want = 0;        // evaluated samples of the channel inside the half
+              int64_t copied = 0;      // runs of the general kernel's pieces (mixed plans): in order, disjoint, inside the half
+              prev = w0;
+              for (int32_t k = 0; k < W.ccnt; ++k) {
+                const uint32_t w = ents[(size_t)(W.e0 + W.cnt + k)];
+                const int64_t o = (w >> 16) & 0xfff, len = (w >> 28) + 1, j = h0 + o;
+                if (j < prev || j + len > w1 || len > WFK_SH_R) return -1207;
+                prev = j + len; copied += len;
+              }
+              int64_t want = 0, want_copy = 0;   // evaluated / copied samples of the channel inside the half
               for (int32_t q = H.channels[c].piece_begin; q < H.channels[c].piece_end; ++q) {
                 const DevPiece& P = H.pieces[q];
                 if (P.n_blk == 0) continue;
                 const int64_t a = P.start > w0 ? P.start : w0, b = P.stop < w1 ? P.stop : w1;
-                if (b > a) want += b - a;
+                if (b > a) ((P.flags & WFK_PF_SHORT) ? want : want_copy) += b - a;
               }
-              if (covered != want) return -1205;
+              if (covered != want || copied != want_copy) return -1205;
               d += (double)W.cnt + W.pad;
             }
       }

@@ -378,7 +378,8 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
     }
     if (hip_stream) p->async_launch = true;
     std::string serr;
-    const int src = sa.n_chunks > 0 ? wfk_launch_short(sa, out_kind, hip_stream, serr) : WFK_OK;
+    const bool foreign_only = (flags & WFK_PLAN_FOREIGN_ONLY) && p->h.mixed;   // (the chain at AWG rates samples the short pieces itself)
+    const int src = sa.n_chunks > 0 && !foreign_only ? wfk_launch_short(sa, out_kind, hip_stream, serr) : WFK_OK;
     if (src) return fail(src, serr);
     if (!p->h.mixed) return WFK_OK;
   }

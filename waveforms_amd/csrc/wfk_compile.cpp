@@ -1619,7 +1619,7 @@ extern "C" int wfk_grid_detect(const double* t, int64_t n, wfk_grid* out) {
 int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half_len, int64_t npairs,
                       std::vector<ShortWin>& wins, std::vector<uint32_t>& ents, std::string& bad) {
   bad.clear();
-  if (!H.shortp || H.mixed) { bad = "not a pure short plan"; return WFK_EINVAL; }
+  if (!H.shortp) { bad = "not a short plan"; return WFK_EINVAL; }
   if (half_len <= 0 || half_len > 4096 || hop <= 0 || npairs < 0) { bad = "window geometry"; return WFK_EINVAL; }
   const int32_t nch = (int32_t)H.channels.size();
   wins.assign((size_t)npairs * nch * 2, ShortWin{});
@@ -1640,6 +1640,7 @@ int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, i
         for (int32_t qq = q; qq < pe && H.pieces[qq].start < w1; ++qq) {
           const DevPiece& D = H.pieces[qq];
           if (D.n_blk == 0 || D.stop <= w0) continue;          // zero stretch (the prefill) / before the half
+          if (!(D.flags & WFK_PF_SHORT)) continue;             // the general kernel's piece: copied, below
           const int64_t a0 = std::max(D.start, w0), b0 = std::min(D.stop, w1);
           for (int64_t m = (a0 - D.start) / WFK_SH_SUB; D.start + m * WFK_SH_SUB < b0; ++m) {
             const int64_t r0 = D.start + m * WFK_SH_SUB, r1 = std::min<int64_t>(r0 + WFK_SH_SUB, D.stop);
@@ -1674,6 +1675,16 @@ int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, i
             cp += wp; cq += wq;
           }
           W.pad = cq < cp ? 1 : 0;
+        }
+        if (H.mixed) {
+          for (int32_t qq = q; qq < pe && H.pieces[qq].start < w1; ++qq) {
+            const DevPiece& D = H.pieces[qq];
+            if (D.n_blk == 0 || D.stop <= w0 || (D.flags & WFK_PF_SHORT)) continue;
+            const int64_t a0 = std::max(D.start, w0), b0 = std::min(D.stop, w1);
+            for (int64_t at = a0; at < b0; at += WFK_SH_R)
+              ents.push_back(WFK_CW_ENTRY(0, at - h0, std::min<int64_t>(WFK_SH_R, b0 - at)));
+          }
+          W.ccnt = (int32_t)((int64_t)ents.size() - W.e0 - W.cnt);
         }
         wins[((size_t)c * npairs + pr) * 2 + hf] = W;
       }

@@ -448,6 +448,8 @@ struct ChainShortArgs {
   const ShortWin* wins;       // [n_channels * npairs * 2]
   const uint32_t* entries;    // drec (16 bit) | offset in the half (12 bit) | length - 1 (4 bit)
   const double* recs;         // the sampler plan's parameter table (op records)
+  const void* ws;             // mixed plans: rows holding the general kernel's pieces (elements of T), else null
+  int64_t ws_stride;
   void* out;
   int64_t out_stride, n, npairs;
   const void* hspec;
@@ -479,13 +481,14 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
   // both halves at once
   const ShortWin* const wp0 = a.wins + ((int64_t)ch * a.npairs + pair) * 2;
   int64_t w_rec0[2], w_e0[2];
-  int w_cnt[2], w_pad[2];
+  int w_cnt[2], w_pad[2], w_ccnt[2];
   uint32_t w_first[2];
   CH_EACH(2, half)
     w_rec0[half] = wp0[half].rec0;
     w_e0[half] = wp0[half].e0;
     w_cnt[half] = cuni(wp0[half].cnt);
     w_pad[half] = cuni(wp0[half].pad);
+    w_ccnt[half] = cuni(wp0[half].ccnt);
     w_first[half] = tid < w_cnt[half] ? a.entries[w_e0[half] + tid] : 0u;
   CH_END
 
@@ -569,6 +572,21 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
         if (k < len) *((k >= t ? b0 + 1 : b0) + k) = (T)(acc[k] + base);
       CH_END
     }
+    // pieces the short tier cannot take (mixed plans): their samples -- offset and clip applied -- were
+    // written to the workspace by the general kernel in the launch before this one; copy the runs in
+    if (w_ccnt[half] != 0) {
+      const T* const wrow = static_cast<const T*>(a.ws) + (int64_t)ch * a.ws_stride + h0;
+      for (int cb = 0; cb < w_ccnt[half]; cb += 256) {
+        const int idx = cb + tid;
+        if (idx < w_ccnt[half]) {
+          const uint32_t word = a.entries[e0 + cnt + idx];
+          const int len = (int)(word >> 28) + 1, o = (int)((word >> 16) & 0xfff);
+          T* const b0 = lds + (sw ? o + (o >> 4) : o);
+          const int t = sw ? 16 - (o & 15) : 99;
+          for (int k = 0; k < len; ++k) *((k >= t ? b0 + 1 : b0) + k) = wrow[o + k];
+        }
+      }
+    }
     __syncthreads();
     CH_EACH(HR, k) x[half * HR + k] = mine[rs * k]; CH_END
   CH_END
@@ -635,7 +653,7 @@ struct wfk_chain_plan {
   double* d_params = nullptr;
   int32_t* d_pair_first = nullptr;
   // fused path at AWG rates (fir_short): half-window entry lists over the sampler plan's own op records
-  bool shortw = false;
+  bool shortw = false, hybrid = false;   // hybrid: a mixed short plan -- the general kernel's pieces go through the workspace
   ShortWin* d_wins = nullptr;
   uint32_t* d_entries = nullptr;
   const double* d_recs = nullptr;
@@ -703,7 +721,7 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
     wfk_internal_plan_tables(p->sampler, &hs, &d_recs);
     bool real = true;
     if (hs) for (uint8_t cx_ : hs->channel_complex) real = real && !cx_;
-    if (hs && d_recs && hs->shortp && !hs->mixed && real) {
+    if (hs && d_recs && hs->shortp && real) {
       const int64_t hop = 256 * (int64_t)p->hopb, HALF = 128 * (int64_t)(16 + p->hopb);
       const int64_t nblk = (p->n + hop - 1) / hop;
       p->npairs = (nblk + 1) / 2;
@@ -730,6 +748,16 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
         p->d_entries = reinterpret_cast<uint32_t*>(base + o_e);
         p->d_recs = d_recs;
         p->table_bytes = (int64_t)(b_ch + b_w + b_e + hs->params.size() * sizeof(double));
+        if (hs->mixed) {
+          // the general kernel's pieces (few, by construction: a plan dominated by them is not short) travel
+          // through rows of a workspace, written sparsely in a launch of their own
+          const size_t es = kind == WFK_OUT_F32 ? 4 : 8;
+          if (hipMalloc(&p->workspace, (size_t)p->n_channels * (size_t)p->n * es) != hipSuccess) {
+            wfk_chain_plan_destroy(p);
+            return chain_fail(WFK_ENOMEM, "chain workspace allocation failed");
+          }
+          p->hybrid = true;
+        }
         p->shortw = true;
         p->fused = true;
         p->why.clear();
@@ -798,7 +826,10 @@ const char* wfk_chain_kernel_name(const wfk_chain_plan* p) {
   if (!p) return "";
   static thread_local std::string name;
   const char* T = p->kind == WFK_OUT_F32 ? "float" : "double";
-  if (p->fused) name = std::string(p->shortw ? "fir_short<" : "fir_sampled<") + T + "," + std::to_string(p->hopb) + ">";
+  if (p->fused) {
+    name = std::string(p->shortw ? "fir_short<" : "fir_sampled<") + T + "," + std::to_string(p->hopb) + ">";
+    if (p->hybrid) name = "wfk_sample<...> (pieces without a short form) + " + name;
+  }
   else name = std::string(wfk_plan_kernel_name(p->sampler, p->kind)) + " + FIR";
   return name.c_str();
 }
@@ -818,7 +849,12 @@ int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void*
   int fir_fused = 0, nseg = 0, K = 0, lead = 0;
   wfk_internal_fir_tables(p->fir, &kspec, &tw, &fir_fused, &nseg, &K, &lead);
   if (p->shortw) {
+    if (p->hybrid) {
+      const int rc = wfk_plan_launch(p->sampler, p->workspace, p->n, p->kind, WFK_PLAN_FOREIGN_ONLY, hip_stream);
+      if (rc) return rc;
+    }
     ChainShortArgs a{};
+    a.ws = p->workspace; a.ws_stride = p->n;
     a.channels = p->d_channels; a.wins = p->d_wins; a.entries = p->d_entries; a.recs = p->d_recs;
     a.out = out_dev; a.out_stride = out_stride; a.n = p->n; a.npairs = p->npairs;
     a.hspec = kspec; a.tw = tw; a.step = p->step;

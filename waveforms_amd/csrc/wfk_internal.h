@@ -288,9 +288,12 @@ int wfk_compile_geom(const wfk_program* prog, const wfk_grid* grid, int lane_str
 // contiguous samples of one piece inside one half.
 struct ShortWin {        // one half of one pair of windows of one channel
   int64_t rec0;          // base of the records its entries refer to (units of 16 B)
-  int64_t e0;            // first entry
+  int64_t e0;            // first entry: `cnt` runs to evaluate, then `ccnt` runs to copy
   int32_t cnt, pad;      // pad: LDS layout of the half (1: one spare element per 16)
+  int32_t ccnt, pad2;    // runs of pieces the short tier cannot take (mixed plans): the general kernel has
+                         // written their samples to the chain's workspace, the half copies them in
 };
+#define WFK_PLAN_FOREIGN_ONLY 0x80000000u   // wfk_plan_launch flag (internal): a mixed short plan launches only its general-kernel part
 #define WFK_CW_ENTRY(drec, o, len) ((uint32_t)(drec) | ((uint32_t)(o) << 16) | ((uint32_t)((len) - 1) << 28))
 // -> wins[(c * npairs + pr) * 2 + h], entries; returns 0, or WFK_EINVAL with the reason in err
 int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half, int64_t npairs,
