@@ -205,3 +205,40 @@ def test_flat_top_pulses_with_erf_edges_stay_in_the_short_tier():
     plan = _engine.Plan(prog, grid=g)
     assert plan.kernel_name(np.complex128).startswith('wfk_sample_short<double,true')
     assert np.max(np.abs(plan.run_host(np.complex128)[0] - c_oracle.eval_grid(prog, g, True)[0])) <= 1e-10
+
+
+@pytest.mark.parametrize('duty30', [False, True])
+def test_bench_shape_2048_rows_full_size(duty30):
+    """the `awg` / `awg_duty30` bench workloads as bench.py launches them: 2048 rows x 1e5 points at 2 GS/s,
+    16 distinct channels x 128 copies (every row with its own device tables), fp64 and fp32, plus the fused
+    chain (fir_short) on the same rows.  Distinct rows against the C oracle over the full row; copies equal
+    their originals bit for bit; linearity of the FIR as the size-independent property of the chain."""
+    import torch
+    from waveforms_amd.distortion import SampledFir
+    rows, n, tile = 2048, 100_000, 128
+    chans = [wl.awg_channel(wf, c, n, 2e9, duty30) for c in range(rows // tile)]
+    grid = wl.awg_grid(n, 2e9)
+    bs = BatchSampler(chans, grid, tile=tile)
+    assert bs.n_channels == rows and bs.plan.kernel_name().startswith('wfk_sample_short<')
+    ref = c_oracle.eval_grid(_flatten.flatten(chans), bs.grid)
+    out = torch.empty((rows, n), dtype=torch.float64, device='cuda')
+    bs.launch_torch(out)
+    torch.cuda.synchronize()
+    first = out[:rows // tile].cpu().numpy()
+    assert np.max(np.abs(first - ref)) <= 5e-11
+    assert bool((out.view(tile, rows // tile, n) == out[:rows // tile].unsqueeze(0)).all())
+    o32 = torch.empty((rows, n), dtype=torch.float32, device='cuda')
+    bs.launch_torch(o32)
+    torch.cuda.synchronize()
+    assert float((o32.double() - out).abs().max()) <= 2e-6
+    ker = wl.c4_kernel()
+    sf = SampledFir(chans, grid, ker, tile=tile)
+    assert sf.fused and sf.plan.kernel_name() == 'fir_short<double,12>'
+    y = torch.empty_like(out)
+    sf.launch_torch(y)
+    torch.cuda.synchronize()
+    want = np.stack([c_oracle.fir(r, ker) for r in ref[:3]])
+    assert np.max(np.abs(y[:3].cpu().numpy() - want)) <= 1e-11
+    assert bool((y.view(tile, rows // tile, n) == y[:rows // tile].unsqueeze(0)).all())
+    sf.close()
+    bs.close()
