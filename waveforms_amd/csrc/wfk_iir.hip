@@ -464,7 +464,11 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   }
   const int64_t slot = ((int64_t)row * nchunks + chunk);
   const unsigned F_AGG = epoch * 4u + 1u, F_PRE = epoch * 4u + 2u;
+#if defined(OP_EXP) && OP_EXP == 2
+  if (false) {                                           // timing experiment: nothing published either
+#else
   if (chunk > 0 && lane == 0) {
+#endif
 #pragma unroll
     for (int i = 0; i < DD; ++i) op_store(aggbuf + slot * DD + i, agg[i]);
     __builtin_amdgcn_s_waitcnt(0);                           // the state is in memory before the flag is
@@ -476,7 +480,11 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
   for (int i = 0; i < IIR_MAXD; ++i) sin_[i] = 0.0;
   bool poisoned = false;
+#if defined(OP_EXP) && OP_EXP >= 1
+  if (true) {                                            // timing experiment: no look-back at all (wrong results)
+#else
   if (chunk == 0) {
+#endif
 #pragma unroll
     for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
   } else {
@@ -497,6 +505,10 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
       unsigned st = 0;
       int kstop = -1;
       bool whole_window = false;
+#if defined(OP_EXP) && OP_EXP == 3
+      kstop = chunk - 1 < 7 ? (int)chunk - 1 : 7;          // timing experiment: 8 predecessors, nobody waited for
+      spins = spin_limit;
+#endif
       for (; spins < spin_limit; ++spins) {
         if (pc >= 0 && !(st == F_PRE)) st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool pre = pc >= 0 && st == F_PRE;
@@ -566,7 +578,11 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
     for (int i = 0; i < IIR_MAXD; ++i) so[i] = i < DD ? agg[i < DD ? i : 0] : 0.0;
     dd_matvec_add<DD>(so, lanepU, sin_, DD);                 // U^1
+#if defined(OP_EXP) && OP_EXP == 2
+    if (false) {
+#else
     if (chunk + 1 < nchunks) {
+#endif
 #pragma unroll
       for (int i = 0; i < DD; ++i) op_store(prefbuf + slot * DD + i, so[i]);
       __builtin_amdgcn_s_waitcnt(0);
