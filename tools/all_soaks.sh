@@ -8,3 +8,4 @@ python tools/stage_soak.py 1500 2>/dev/null | tail -n 1 | sed 's/^/stage_soak (F
 python tools/call_api_soak.py | tail -n 1 | sed 's/^/call_api_soak (drop-in calls): /'
 python tools/sample_api_soak.py 2>/dev/null | tail -n 1 | sed 's/^/sample_api_soak: /'
 python tools/spectral_soak.py 2>/dev/null | tail -n 1 | sed 's/^/spectral_soak: /'
+python tools/chain_soak.py 0 10000 | tail -n 1 | sed 's/^/chain_soak (random pulse trains through the sampler -> FIR chain): /'
