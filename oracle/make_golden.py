@@ -153,6 +153,39 @@ def make_awg(ref, gold):
     np.savez_compressed(os.path.join(gold, 'awg.npz'), **awg)
 
 
+def make_iir(ref, gold):
+    import cases
+    # ---- IIR stages (SURVEY.md 8(f) N1): sample(filters=) and predistort(filters=) ----
+    from scipy.signal import butter, tf2sos
+    iir = {}
+    for name, (build, start, stop, rate, order, fc, initial) in cases.iir_cases().items():
+        w = build(ref)
+        w.start, w.stop, w.sample_rate = start, stop, rate
+        b, a = butter(order, fc, 'lowpass', fs=rate)
+        w.filters = (tf2sos(b, a), initial)
+        iir[name + '.full'] = w.sample()
+        iir[name + '.chunked'] = np.concatenate(list(w.sample(chunk_size=300)))
+    dist = ref.distortion
+    for i, (n, params, initial, k) in enumerate(cases.predistort_cases()):
+        sig, ker = cases.predistort_inputs(i)      # seeded: inputs are not stored
+        filters = [dist.exp_decay_filter(A, tau, 1e9) for A, tau in params]
+        y, zf = dist.predistort(sig, filters, ker=ker, initial=initial, return_zf=True)
+        iir[f'pd{i}.out'], iir[f'pd{i}.zf'] = y, zf
+        b, a = dist.combine_filters(filters)
+        iir[f'pd{i}.ba'] = np.concatenate([b, a])
+        iir[f'pd{i}.distort'] = dist.distort(sig, np.asarray(params).reshape(-1), 1e9, initial)
+    for i, (n, params, initial, k, _, _, _) in enumerate(cases.predistort_cplx_cases()):
+        sig, ker, zi = cases.predistort_cplx_inputs(i)
+        filters = None if params is None else [dist.exp_decay_filter(A, tau, 1e9) for A, tau in params]
+        if filters is None:     # (FIR branch: return_zf=True is an UnboundLocalError upstream, distortion.py:335)
+            y, zf = dist.predistort(sig, None, ker=ker), None
+        else:
+            y, zf = dist.predistort(sig, filters, ker=ker, initial=initial, zi=zi, return_zf=True)
+        iir[f'pdc{i}.out'] = y
+        iir[f'pdc{i}.zf'] = np.zeros(0) if zf is None else zf
+    np.savez_compressed(os.path.join(gold, 'iir.npz'), **iir)
+
+
 def main():
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -171,6 +204,9 @@ def main():
         return
     if sys.argv[1:] == ['awg']:            # regenerate this fixture only
         make_awg(ref, gold)
+        return
+    if sys.argv[1:] == ['iir']:            # regenerate this fixture only
+        make_iir(ref, gold)
         return
 
     # ---- filter-design helpers of distortion.py (host-side, no sampling) ----------
@@ -340,26 +376,7 @@ def main():
         fir[f'{i}.out'] = ref.distortion.predistort(sig, ker=kr)
     np.savez_compressed(os.path.join(gold, 'fir.npz'), **fir)
 
-    # ---- IIR stages (SURVEY.md 8(f) N1): sample(filters=) and predistort(filters=) ----
-    from scipy.signal import butter, tf2sos
-    iir = {}
-    for name, (build, start, stop, rate, order, fc, initial) in cases.iir_cases().items():
-        w = build(ref)
-        w.start, w.stop, w.sample_rate = start, stop, rate
-        b, a = butter(order, fc, 'lowpass', fs=rate)
-        w.filters = (tf2sos(b, a), initial)
-        iir[name + '.full'] = w.sample()
-        iir[name + '.chunked'] = np.concatenate(list(w.sample(chunk_size=300)))
-    dist = ref.distortion
-    for i, (n, params, initial, k) in enumerate(cases.predistort_cases()):
-        sig, ker = cases.predistort_inputs(i)      # seeded: inputs are not stored
-        filters = [dist.exp_decay_filter(A, tau, 1e9) for A, tau in params]
-        y, zf = dist.predistort(sig, filters, ker=ker, initial=initial, return_zf=True)
-        iir[f'pd{i}.out'], iir[f'pd{i}.zf'] = y, zf
-        b, a = dist.combine_filters(filters)
-        iir[f'pd{i}.ba'] = np.concatenate([b, a])
-        iir[f'pd{i}.distort'] = dist.distort(sig, np.asarray(params).reshape(-1), 1e9, initial)
-    np.savez_compressed(os.path.join(gold, 'iir.npz'), **iir)
+    make_iir(ref, gold)
 
     # ---- FFT-domain ops -------------------------------------
     spec = {}

@@ -227,6 +227,35 @@ def predistort_inputs(i):
     return sig, ker
 
 
+def predistort_cplx_cases():
+    """predistort on COMPLEX inputs (scipy's lfilter / fftconvolve take them, reference distortion.py:298-337):
+    (n, [(A, tau)...] | None, initial, fir_taps, real signal?, complex kernel?, explicit complex zi?)."""
+    return [
+        (4000, [(0.02, 150e-9)], 0.0, 0, False, False, False),
+        (3000, None, 0.0, 33, False, False, False),                 # FIR branch, complex signal
+        (3000, None, 0.0, 33, True, True, False),                   # FIR branch, REAL signal, complex kernel
+        (5000, [(0.03, 40e-9), (0.01, 900e-9)], 0.3, 17, False, False, False),
+        (2500, [(0.02, 150e-9)], 0.0, 9, False, True, True),        # complex signal, kernel and state
+    ]
+
+
+def predistort_cplx_inputs(i):
+    n, params, initial, k, real_sig, cker, czi = predistort_cplx_cases()[i]
+    rng = np.random.default_rng(800 + i)
+    sig = rng.normal(size=n) + initial
+    if not real_sig:
+        sig = sig + 1j * rng.normal(size=n)
+    ker = None
+    if k:
+        ker = rng.normal(size=k) / k
+        if cker:
+            ker = ker + 1j * rng.normal(size=k) / k
+    zi = None
+    if czi:
+        zi = rng.normal(size=len(params)) * 0.01 + 1j * rng.normal(size=len(params)) * 0.01
+    return sig, ker, zi
+
+
 def spectral_cases():
     """(n, A, tau, sample_rate) for reflection / correct_reflection / shift."""
     return [(4096, 0.1, 12.5e-9, 1e9), (10007, -0.2, 31e-9, 2e9), (30000, 0.05, 3e-9, 1e9)]

@@ -97,6 +97,27 @@ def test_reference_test_filters():
     assert np.allclose(wf.WaveVStack.fromlist(vs.tolist()).sample(), pts, atol=1e-6)
 
 
+@pytest.mark.parametrize('i', range(len(cases.predistort_cplx_cases())))
+def test_predistort_on_complex_inputs(i):
+    """scipy's lfilter / fftconvolve take complex signals, kernels and states, so the reference's predistort
+    does (distortion.py:298-337); here the real and imaginary parts run as real passes on the device"""
+    n, params, initial, k, real_sig, cker, czi = cases.predistort_cplx_cases()[i]
+    sig, ker, zi = cases.predistort_cplx_inputs(i)
+    filters = None if params is None else [distortion.exp_decay_filter(A, tau, 1e9) for A, tau in params]
+    want = IIR[f'pdc{i}.out']
+    if filters is None:
+        got, zf = distortion.predistort(sig, None, ker=ker), None
+    else:
+        got, zf = distortion.predistort(sig, filters, ker=ker, initial=initial, zi=zi, return_zf=True)
+    assert got.dtype == np.complex128 and got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, np.abs(want).max())
+    if zf is not None:
+        wzf = IIR[f'pdc{i}.zf']
+        assert np.iscomplexobj(zf) and np.max(np.abs(zf - wzf)) <= 1e-10 * max(1.0, np.abs(wzf).max())
+    ora, _ = np_oracle.predistort(sig, filters, ker, initial, zi)
+    assert np.max(np.abs(got - ora)) <= 1e-10 * max(1.0, np.abs(want).max())
+
+
 @pytest.mark.parametrize('i', range(len(cases.predistort_cases())))
 def test_predistort_filters(i):
     n, params, initial, k = cases.predistort_cases()[i]

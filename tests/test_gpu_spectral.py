@@ -43,3 +43,25 @@ def test_kernel_design_and_symbolic_branch():
     assert c == 1 / 0.9 * w - 0.1 / 0.9 * (w >> 5e-9)
     with pytest.raises(ValueError):
         distortion.correct_reflection(np.zeros(8), 0.1, 1e-9)
+
+
+def test_shift_keeps_the_callers_dtype():
+    # upstream is np.convolve(signal, ker, 'same') + an integer roll with np.zeros_like(signal)
+    # (distortion.py:22-38): complex stays complex, integers stay integers when only whole samples move
+    rng = np.random.default_rng(5)
+    z = rng.normal(size=3001) + 1j * rng.normal(size=3001)
+    for delay in (2.3, -4.7, 0.4):
+        pts, delta = int(delay // 1.0), delay - int(delay // 1.0)
+        want = np.convolve(z, np.array([0, 1 - delta, delta]), mode='same')
+        if pts:
+            r = np.zeros_like(want)
+            if pts < 0:
+                r[:pts] = want[-pts:]
+            else:
+                r[pts:] = want[:-pts]
+            want = r
+        got = distortion.shift(z, delay, 1.0)
+        assert got.dtype == np.complex128 and np.max(np.abs(got - want)) <= 1e-13
+    k = np.arange(10)
+    got = distortion.shift(k, 3.0, 1.0)
+    assert got.dtype == k.dtype and list(got) == [0, 0, 0, 0, 1, 2, 3, 4, 5, 6]

@@ -171,3 +171,23 @@ def test_oracles_match_reference_on_oversampled_grids(name):
     got_c = c_oracle.eval_tlist(prog, t[pick], cplx)[0]
     far = abs(grid[1]) > 1e-5
     assert np.max(np.abs(got_c - want)) <= (1e-9 if far else 1e-12) * pk
+
+
+@pytest.mark.parametrize('i', range(len(cases.predistort_cplx_cases())))
+def test_predistort_oracle_on_complex_inputs(i):
+    """complex signals / kernels / states through predistort (scipy takes them: reference distortion.py:298-337):
+    the NumPy oracle against reference-generated vectors (iir.npz, pdc*)"""
+    import golden_io
+    gold = golden_io.npz('iir.npz')
+    n, params, initial, k, _, _, _ = cases.predistort_cplx_cases()[i]
+    sig, ker, zi = cases.predistort_cplx_inputs(i)
+    filters = None
+    if params is not None:
+        from waveforms_amd import distortion
+        filters = [distortion.exp_decay_filter(A, tau, 1e9) for A, tau in params]
+    got, zf = np_oracle.predistort(sig, filters, ker, initial, zi)
+    want = gold[f'pdc{i}.out']
+    assert got.dtype == want.dtype == np.complex128
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.abs(want).max())
+    if filters is not None:
+        assert np.max(np.abs(zf - gold[f'pdc{i}.zf'])) <= 1e-12

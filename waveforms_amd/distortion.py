@@ -95,7 +95,32 @@ class SampledFir:
 
 
 def fir_host(sig: np.ndarray, ker: np.ndarray) -> np.ndarray:
-    """NumPy in, NumPy out: upload, rocFFT overlap-save on the device, download."""
+    """NumPy in, NumPy out: upload, overlap-save FIR on the device, download.  Complex signals and / or
+    kernels (the reference's `fftconvolve` takes both, distortion.py:329-337) run as real convolutions of
+    their parts: (sr + i si) * (kr + i ki) = sr*kr - si*ki + i (sr*ki + si*kr)."""
+    sig, ker = np.asarray(sig), np.asarray(ker)
+    if np.iscomplexobj(sig) or np.iscomplexobj(ker):
+        shape = np.shape(sig)
+        rows = np.atleast_2d(sig)
+        parts = [np.ascontiguousarray(rows.real, dtype=np.float64)]
+        if np.iscomplexobj(sig):
+            parts.append(np.ascontiguousarray(rows.imag, dtype=np.float64))
+        stacked = np.concatenate(parts, axis=0)              # the parts as extra rows: one launch per kernel part
+        nb = rows.shape[0]
+        a = _fir_host_real(stacked, np.ascontiguousarray(ker.real, dtype=np.float64))
+        out = a[:nb].astype(np.complex128)
+        if len(parts) == 2:
+            out += 1j * a[nb:]
+        if np.iscomplexobj(ker):
+            b = _fir_host_real(stacked, np.ascontiguousarray(ker.imag, dtype=np.float64))
+            out += 1j * b[:nb]
+            if len(parts) == 2:
+                out -= b[nb:]
+        return out.reshape(shape)
+    return _fir_host_real(sig, ker)
+
+
+def _fir_host_real(sig: np.ndarray, ker: np.ndarray) -> np.ndarray:
     sig2 = np.ascontiguousarray(np.atleast_2d(sig), dtype=np.float64)
     batch, n = sig2.shape
     if n == 0:
@@ -156,7 +181,26 @@ def exp_decay_filter(amp, tau, sample_rate, inv=False, output='ba'):
 
 def iir_host(sig, sections, zi=None, initial=0.0, ker=None):
     """NumPy in/out: upload, IIR scan (+ optional FIR) on the device, download.
-    Returns (y, zf) with zf the final filter state (scipy layout)."""
+    Returns (y, zf) with zf the final filter state (scipy layout).  A complex signal, initial value or
+    state (scipy's lfilter / sosfilt take them; reference distortion.py:298-321) runs as two real passes:
+    the coefficients are real, so real and imaginary parts filter independently."""
+    cplx = np.iscomplexobj(sig) or np.iscomplexobj(initial) or (zi is not None and np.iscomplexobj(zi))
+    if cplx or (ker is not None and np.iscomplexobj(ker)):
+        if any(np.iscomplexobj(np.asarray(c)) for sec in sections for c in sec):
+            raise NotImplementedError('IIR sections with complex coefficients')
+        sig = np.asarray(sig)
+        kr = None if (ker is None or np.iscomplexobj(ker)) else ker
+        zr = None if zi is None else np.real(zi)
+        yr, zfr = iir_host(np.real(sig), sections, zr, float(np.real(initial)), kr)
+        if cplx:
+            zim = None if zi is None else np.imag(zi)
+            yi, zfi = iir_host(np.imag(sig), sections, zim, float(np.imag(initial)), kr)
+            y, zf = yr + 1j * yi, zfr + 1j * zfi
+        else:
+            y, zf = yr, zfr
+        if ker is not None and kr is None:
+            y = fir_host(y, ker)
+        return y, zf
     sig2 = np.ascontiguousarray(np.atleast_2d(sig), dtype=np.float64)
     batch, n = sig2.shape
     plan = _engine.IirPlan(sections, n, batch, np.float64)
@@ -228,7 +272,7 @@ def predistort(sig, filters=None, ker=None, initial=0.0, initial_x=None,
         return (sig, zf) if return_zf else sig
     if ker is None:
         return (sig, zf) if return_zf else sig
-    out = fir_host(sig, np.asarray(ker, dtype=np.float64))
+    out = fir_host(sig, np.asarray(ker))
     return (out, zf) if return_zf else out
 
 
@@ -324,7 +368,7 @@ def correct_reflection(sig, A, tau, sample_rate=None):
 def shift(signal, delay, dt):
     """Delay a sampled signal by `delay` (3-tap fractional interpolation on the device +
     integer shift; reference: distortion.py:12-39)."""
-    signal = np.asarray(signal, dtype=np.float64)
+    signal = np.asarray(signal)          # (dtype kept as upstream does: complex signals stay complex)
     points = int(delay // dt)
     delta = delay / dt - points
     if delta > 0:
