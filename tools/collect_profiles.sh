@@ -31,4 +31,4 @@ for grp in WRITE_SIZE FETCH_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o run -- python3 $ARGS > "$OUT/pmc_$name.log" 2>&1
 done
 python3 tools/summarize_profiles.py "$OUT" "gpurun_out/profiles/${TAG}_${WL}"
-grep '^{' "$OUT/stats.log" | tail -1 > "gpurun_out/profiles/${TAG}_${WL}_bench.json" || true
+grep "^{" "$OUT/stats.log" | tail -1 > "gpurun_out/profiles/${TAG}_${WL}_bench.json" || rm -f "gpurun_out/profiles/${TAG}_${WL}_bench.json"
