@@ -458,6 +458,23 @@ struct ChainShortArgs {
   int32_t hop, K, lead;
 };
 
+// runs of pieces without a short form (mixed plans), copied from the workspace into the half's LDS image.
+// Out of line: inlined, the rare path cost the common one 390 static / 10 % dynamic VALU instructions.
+template <typename T>
+__device__ __attribute__((noinline)) void chain_copy_runs(T* lds, const T* wrow, const uint32_t* ents, int ccnt,
+                                                          bool sw, int tid) {
+  for (int cb = 0; cb < ccnt; cb += 256) {
+    const int idx = cb + tid;
+    if (idx < ccnt) {
+      const uint32_t word = ents[idx];
+      const int len = (int)(word >> 28) + 1, o = (int)((word >> 16) & 0xfff);
+      T* const b0 = lds + (sw ? o + (o >> 4) : o);
+      const int t = sw ? 16 - (o & 15) : 99;
+      for (int k = 0; k < len; ++k) *((k >= t ? b0 + 1 : b0) + k) = wrow[o + k];
+    }
+  }
+}
+
 template <typename T, int HOPB>
 __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShortArgs a) {
   constexpr int CL = 16 + HOPB, HR = CL / 2, HALF = 256 * HR, R = WFK_SH_R;
@@ -507,17 +524,25 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
     // pulses) or padded by one element per 16 (i + (i >> 4): runs of 16 then start 17 apart).  The
     // wrong one makes every write of a wave hit one bank pair (PMC: 27 % of the LDS pipe's time).
     const bool sw = w_pad[half] != 0;
-    const int rs = sw ? 272 : 256;                         // row stride of the thread's own samples
-    T* const mine = lds + (sw ? tid + (tid >> 4) : tid);
+    T* const mine = lds + (sw ? tid + (tid >> 4) : tid);   // the thread's own samples: rows 272 / 256 apart
+    // (the two layouts as two copies of the row loops, under a block-uniform branch: the row offsets stay
+    //  immediates of the LDS instructions -- with a variable row stride the kernel executed 10 % more VALU
+    //  instructions, PMC 355.7 M -> 390.4 M per launch)
     // zero padding outside [0, n), the channel offset inside (skipped _zero pieces, gaps between entries)
-    if (h0 >= 0 && h0 + HALF <= a.n) {
-      CH_EACH(HR, k) mine[rs * k] = (T)base; CH_END
-    } else {
-      CH_EACH(HR, k)
-        const int64_t j = h0 + 256 * k + tid;
-        mine[rs * k] = (j >= 0 && j < a.n) ? (T)base : (T)0;
-      CH_END
-    }
+    const bool inside = h0 >= 0 && h0 + HALF <= a.n;
+    auto prefill = [&](auto rs_) __attribute__((always_inline)) {
+      constexpr int rs = decltype(rs_)::value;
+      if (inside) {
+        CH_EACH(HR, k) mine[rs * k] = (T)base; CH_END
+      } else {
+        CH_EACH(HR, k)
+          const int64_t j = h0 + 256 * k + tid;
+          mine[rs * k] = (j >= 0 && j < a.n) ? (T)base : (T)0;
+        CH_END
+      }
+    };
+    if (sw) prefill(std::integral_constant<int, 272>{});
+    else prefill(std::integral_constant<int, 256>{});
     __syncthreads();
     const int64_t rec0 = w_rec0[half], e0 = w_e0[half];
     const int cnt = w_cnt[half];
@@ -574,21 +599,15 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
     }
     // pieces the short tier cannot take (mixed plans): their samples -- offset and clip applied -- were
     // written to the workspace by the general kernel in the launch before this one; copy the runs in
-    if (w_ccnt[half] != 0) {
-      const T* const wrow = static_cast<const T*>(a.ws) + (int64_t)ch * a.ws_stride + h0;
-      for (int cb = 0; cb < w_ccnt[half]; cb += 256) {
-        const int idx = cb + tid;
-        if (idx < w_ccnt[half]) {
-          const uint32_t word = a.entries[e0 + cnt + idx];
-          const int len = (int)(word >> 28) + 1, o = (int)((word >> 16) & 0xfff);
-          T* const b0 = lds + (sw ? o + (o >> 4) : o);
-          const int t = sw ? 16 - (o & 15) : 99;
-          for (int k = 0; k < len; ++k) *((k >= t ? b0 + 1 : b0) + k) = wrow[o + k];
-        }
-      }
-    }
+    if (__builtin_expect(w_ccnt[half] != 0, 0))
+      chain_copy_runs<T>(lds, static_cast<const T*>(a.ws) + (int64_t)ch * a.ws_stride + h0, a.entries + e0 + cnt,
+                         w_ccnt[half], sw, tid);
     __syncthreads();
-    CH_EACH(HR, k) x[half * HR + k] = mine[rs * k]; CH_END
+    if (sw) {
+      CH_EACH(HR, k) x[half * HR + k] = mine[272 * k]; CH_END
+    } else {
+      CH_EACH(HR, k) x[half * HR + k] = mine[256 * k]; CH_END
+    }
   CH_END
   __syncthreads();                                         // the array becomes the FFT exchange buffer
 
