@@ -151,6 +151,19 @@ def make_awg(ref, gold):
             ys = np.asarray(w.sample())
             assert ys.shape == y.shape and np.array_equal(ys, y), name
     np.savez_compressed(os.path.join(gold, 'awg.npz'), **awg)
+    # the same real-valued channels through predistort(., ker = the 1024-tap kernel of C4): the chain at AWG
+    # rates (reference waveform.py:190-192 -> distortion.py:329-337); subset = every 3rd sample + 33 samples
+    # around every multiple of 1024 (window and half-window seams of the on-chip transform) + both ends
+    ker = wl.c4_kernel()
+    c4 = {}
+    for name, (build, rate, n) in cases.AWG_CASES.items():
+        y = awg[name + '.y']
+        if np.iscomplexobj(y):
+            continue
+        z = ref.distortion.predistort(y, ker=ker)
+        idx = cases.awg_c4_subset(n)
+        c4[name + '.z'] = z[idx]
+    np.savez_compressed(os.path.join(gold, 'awg_c4.npz'), **c4)
 
 
 def make_iir(ref, gold):

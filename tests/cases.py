@@ -785,6 +785,14 @@ def _awg_grid(n, rate):
     return ('arange', 0.0, n / rate, 1.0 / rate)
 
 
+def awg_c4_subset(n):
+    """sample indices of the awg_c4.npz vectors: every 3rd + 33 around every multiple of 1024 + both ends"""
+    idx = set(range(0, n, 3)) | set(range(min(n, 80))) | set(range(max(0, n - 80), n))
+    for m in range(0, n, 1024):
+        idx |= set(range(max(0, m - 16), min(n, m + 17)))
+    return np.array(sorted(idx), dtype=np.int64)
+
+
 AWG_CASES = {   # name -> (build(ns, rate), rate, n)
     'b2b_2g': (_awg_chan(0), 2e9, 100000),
     'duty30_2g': (_awg_chan(1, True), 2e9, 100000),

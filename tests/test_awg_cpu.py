@@ -96,3 +96,16 @@ def test_tile_program_equals_flattening_the_repeated_list():
     b = _flatten.flatten(chans * 4, g)
     for k in a.arrays:
         assert a.arrays[k].dtype == b.arrays[k].dtype and np.array_equal(a.arrays[k], b.arrays[k]), k
+
+
+@pytest.mark.parametrize('name', sorted(n for n in cases.AWG_CASES if n != 'cplx_2g'))
+def test_chain_oracle_matches_reference_at_awg_rates(name):
+    """predistort(wav(t), ker = C4's 1024 taps) on the AWG-rate grids: C oracle (sampler) + direct convolution
+    against what the REAL reference produced (tests/golden/awg_c4.npz)"""
+    build, rate, n = cases.AWG_CASES[name]
+    want = golden_io.npz('awg_c4.npz')[name + '.z']
+    g = _flatten.grid_from_desc(cases._awg_grid(n, rate))
+    y = c_oracle.eval_grid(_flatten.flatten([build(wf, rate)]), g)[0]
+    z = c_oracle.fir(y, wl.c4_kernel())[cases.awg_c4_subset(n)]
+    assert z.shape == want.shape
+    assert np.max(np.abs(z - want)) <= 1e-12 * max(1.0, np.abs(want).max())

@@ -317,3 +317,20 @@ def test_short_chain_fuzz_over_random_awg_pulse_trains():
         assert np.max(np.abs(got - want), initial=0.0) <= 1e-9 * pk, (seed, kn, sf.why_not)
         sf.close()
     assert took.get('fir_short', 0) >= 40, took
+
+
+@pytest.mark.parametrize('name', sorted(n for n in __import__('cases').AWG_CASES if n != 'cplx_2g'))
+def test_chain_at_awg_rates_against_reference_vectors(name):
+    """the chain on the AWG-rate cases against vectors of the REAL reference (awg_c4.npz: predistort of the
+    sampled channel with C4's 1024-tap kernel; every 3rd sample + the transform's seams + both ends)"""
+    import cases
+    build, rate, n = cases.AWG_CASES[name]
+    want = golden_io.npz('awg_c4.npz')[name + '.z']
+    idx = cases.awg_c4_subset(n)
+    for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+        sf = SampledFir([build(wf, rate)], cases._awg_grid(n, rate), wl.c4_kernel(), dt)
+        if not name.startswith('readme'):      # (the README pulses are a few long pieces: not a short plan)
+            assert sf.fused and 'fir_short<' in sf.plan.kernel_name(), (sf.why_not, sf.plan.kernel_name())
+        got = sf.to_host()[0][idx]
+        assert np.max(np.abs(got - want)) <= tol * max(1.0, np.abs(want).max())
+        sf.close()
