@@ -187,6 +187,11 @@ int wfk_plan_run_host(wfk_plan* plan, void* out_host, int64_t ch_stride,
 int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n,
                         int32_t batch, int kind /* WFK_OUT_F64|F32 */,
                         wfk_fir_plan** out);
+/* the same with one kernel PER ROW: kers_host[row * K + k] (every AWG line has its own predistortion kernel;
+ * upstream the call is per signal anyway).  On-chip transform only: K <= 6148, batch <= 65535.          */
+int wfk_fir_plan_create_rows(const double* kers_host, int32_t K, int64_t n,
+                             int32_t batch, int kind /* WFK_OUT_F64|F32 */,
+                             wfk_fir_plan** out);
 int wfk_fir_apply(wfk_fir_plan* plan, const void* in_dev, int64_t in_stride,
                   void* out_dev, int64_t out_stride, void* hip_stream);
 int wfk_fir_plan_destroy(wfk_fir_plan* plan);
@@ -205,6 +210,9 @@ int wfk_fir_plan_destroy(wfk_fir_plan* plan);
 typedef struct wfk_chain_plan wfk_chain_plan;
 int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const double* ker_host,
                           int32_t K, int kind /* WFK_OUT_F64|F32 */, wfk_chain_plan** out);
+/* one kernel per channel: kers_host[channel * K + k] */
+int wfk_chain_plan_create_rows(const wfk_program* prog, const wfk_grid* grid, const double* kers_host,
+                               int32_t K, int kind /* WFK_OUT_F64|F32 */, wfk_chain_plan** out);
 int wfk_chain_is_fused(const wfk_chain_plan* plan);
 /* "fir_sampled<T,HOPB>" (stride-256 chains, fine grids), "fir_short<T,HOPB>" (contiguous lane runs, AWG
  * rates) or the two kernels of the unfused path; the string lives until the next call on this thread */

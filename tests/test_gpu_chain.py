@@ -334,3 +334,44 @@ def test_chain_at_awg_rates_against_reference_vectors(name):
         got = sf.to_host()[0][idx]
         assert np.max(np.abs(got - want)) <= tol * max(1.0, np.abs(want).max())
         sf.close()
+
+
+def test_one_kernel_per_channel():
+    """every AWG line has its own predistortion kernel: ker of shape (n_channels, K) through all three chain
+    kernels and the FIR stage alone, against the oracle row by row"""
+    from waveforms_amd.distortion import FirStage
+    rng = np.random.default_rng(12)
+    for chans, grid, kname in (
+            ([wl.sum_channel(wf, 6, 1000 + c) for c in range(5)], ('linspace', 0.0, 6 * wl.SPAN, 50001, False), 'fir_sampled<'),
+            ([wl.awg_channel(wf, c, 30000, 2e9, c == 2) for c in range(5)], wl.awg_grid(30000, 2e9), 'fir_short<')):
+        for K in (1, 300, 1024, 1537):
+            kers = rng.normal(size=(len(chans), K)) / K
+            g = _flatten.grid_from_desc(grid)
+            y = c_oracle.eval_grid(_flatten.flatten(chans), g)
+            want = np.stack([c_oracle.fir(r, k) for r, k in zip(y, kers)])
+            for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+                sf = SampledFir(chans, grid, kers, dt)
+                assert sf.fused and kname in sf.plan.kernel_name(), (sf.why_not, sf.plan.kernel_name())
+                assert np.max(np.abs(sf.to_host() - want)) <= tol
+                sf.close()
+            # the stage alone, and the unfused chain
+            st = FirStage(kers, g.n, len(chans))
+            dx, dy = _engine.DeviceBuffer(y.nbytes), _engine.DeviceBuffer(y.nbytes)
+            dx.upload(np.ascontiguousarray(y))
+            st.apply(dx.ptr, g.n, dy.ptr, g.n)
+            _engine.sync()
+            assert np.max(np.abs(dy.download(y.shape, np.float64) - want)) <= 1e-12
+            st.close(); dx.close(); dy.close()
+    # a long kernel (two segments of the on-chip transform), per row
+    kers = rng.normal(size=(3, 2500)) / 2500
+    x = rng.normal(size=(3, 40000))
+    st = FirStage(kers, 40000, 3)
+    dx, dy = _engine.DeviceBuffer(x.nbytes), _engine.DeviceBuffer(x.nbytes)
+    dx.upload(x)
+    st.apply(dx.ptr, 40000, dy.ptr, 40000)
+    _engine.sync()
+    want = np.stack([c_oracle.fir(r, k) for r, k in zip(x, kers)])
+    assert np.max(np.abs(dy.download(x.shape, np.float64) - want)) <= 1e-12
+    st.close(); dx.close(); dy.close()
+    with pytest.raises(ValueError):
+        FirStage(kers, 40000, 4)

@@ -75,6 +75,8 @@ def lib():
         l.wfk_plan_launch.argtypes = [VP, VP, I64, C.c_int, C.c_uint32, VP]
         l.wfk_plan_run_host.argtypes = [VP, VP, I64, C.c_int]
         l.wfk_fir_plan_create.argtypes = [VP, I32, I64, I32, C.c_int, P(VP)]
+        l.wfk_fir_plan_create_rows.argtypes = [VP, I32, I64, I32, C.c_int, P(VP)]
+        l.wfk_chain_plan_create_rows.argtypes = [P(wfk_program), P(wfk_grid), VP, I32, C.c_int, P(VP)]
         l.wfk_fir_apply.argtypes = [VP, VP, I64, VP, I64, VP]
         l.wfk_fir_plan_destroy.argtypes = [VP]
         l.wfk_chain_plan_create.argtypes = [P(wfk_program), P(wfk_grid), VP, I32, C.c_int, P(VP)]
@@ -229,12 +231,19 @@ def pinned_empty(shape, dtype) -> np.ndarray:
 
 
 class FirPlan:
-    """out[i] = sum_k ker[k] * sig[i + K//2 - k] (zero padded) for `batch` rows."""
+    """out[i] = sum_k ker[k] * sig[i + K//2 - k] (zero padded) for `batch` rows.  A 2-D `ker` of shape
+    (batch, K) gives every row its own kernel (one predistortion kernel per AWG line)."""
 
     def __init__(self, ker, n: int, batch: int = 1, dtype=np.float64):
         ker = np.ascontiguousarray(ker, dtype=np.float64)
         self.n, self.batch, self.dtype = int(n), int(batch), np.dtype(dtype)
         self._h = C.c_void_p()
+        if ker.ndim == 2:
+            if ker.shape[0] != self.batch:
+                raise ValueError('per-row kernels: ker must have shape (batch, K)')
+            check(lib().wfk_fir_plan_create_rows(ker.ctypes.data, ker.shape[1], self.n, self.batch,
+                                                 _KIND_OF[self.dtype], C.byref(self._h)))
+            return
         check(lib().wfk_fir_plan_create(ker.ctypes.data, len(ker), self.n, self.batch,
                                         _KIND_OF[self.dtype], C.byref(self._h)))
 
@@ -261,8 +270,14 @@ class ChainPlan:
         self.prog, self.grid, self.dtype = prog, grid, np.dtype(dtype)
         self.n, self.n_channels = int(grid.n), prog.n_channels
         self._h = C.c_void_p()
-        check(lib().wfk_chain_plan_create(C.byref(prog.struct), C.byref(grid), ker.ctypes.data, len(ker),
-                                          _KIND_OF[self.dtype], C.byref(self._h)))
+        if ker.ndim == 2:          # one kernel per channel
+            if ker.shape[0] != prog.n_channels:
+                raise ValueError('per-channel kernels: ker must have shape (n_channels, K)')
+            check(lib().wfk_chain_plan_create_rows(C.byref(prog.struct), C.byref(grid), ker.ctypes.data, ker.shape[1],
+                                                   _KIND_OF[self.dtype], C.byref(self._h)))
+        else:
+            check(lib().wfk_chain_plan_create(C.byref(prog.struct), C.byref(grid), ker.ctypes.data, len(ker),
+                                              _KIND_OF[self.dtype], C.byref(self._h)))
         self.fused = bool(lib().wfk_chain_is_fused(self._h))
         self.why_not = lib().wfk_chain_unfused_reason(self._h).decode()
 

@@ -75,7 +75,7 @@ std::once_flag g_rocfft_once;
 extern "C" int wfk_internal_fir_fused_launch(int kind, const void* in, int64_t in_stride, void* out,
                                              int64_t out_stride, const void* hspec, const void* tw,
                                              int64_t n, int M, int K, int lead, int64_t nblk,
-                                             int32_t batch, int accumulate, void* stream);
+                                             int32_t batch, int accumulate, void* stream, int64_t hspec_row_stride);
 extern "C" int wfk_internal_fir_fused_len(void);
 
 struct wfk_fir_plan {
@@ -92,6 +92,8 @@ struct wfk_fir_plan {
   void* win = nullptr;
   void* spec = nullptr;
   void* kspec = nullptr;
+  int64_t krow = 0;            // per-row kernels (wfk_fir_plan_create_rows): complex elements between the
+                               // spectra of consecutive rows; 0: one kernel for every row
 };
 
 extern "C" void wfk_internal_set_error(const char* msg);  // wfk_api.cpp (thread-local)
@@ -180,6 +182,8 @@ extern "C" void wfk_internal_fir_tables(const wfk_fir_plan* p, const void** kspe
   *lead = (p->K - 1) - p->K / 2;
 }
 
+extern "C" int64_t wfk_internal_fir_krow(const wfk_fir_plan* p) { return p->krow; }
+
 extern "C" {
 
 int wfk_fir_plan_destroy(wfk_fir_plan* p) {
@@ -198,8 +202,21 @@ int wfk_fir_plan_destroy(wfk_fir_plan* p) {
   return WFK_OK;
 }
 
+static int fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t batch, int kind,
+                           wfk_fir_plan** out, bool per_row);
+
 int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t batch, int kind,
                         wfk_fir_plan** out) {
+  return fir_plan_create(ker_host, K, n, batch, kind, out, false);
+}
+
+int wfk_fir_plan_create_rows(const double* kers_host, int32_t K, int64_t n, int32_t batch, int kind,
+                             wfk_fir_plan** out) {
+  return fir_plan_create(kers_host, K, n, batch, kind, out, true);
+}
+
+static int fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t batch, int kind,
+                           wfk_fir_plan** out, bool per_row) {
   if (!out) return fir_fail(WFK_EINVAL, "null out");
   *out = nullptr;
   if (!ker_host || K < 1 || n < 0 || batch < 1) return fir_fail(WFK_EINVAL, "bad FIR arguments");
@@ -224,6 +241,10 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
   p->Kseg = (K + p->nseg - 1) / p->nseg;
   p->fused = p->nseg <= WFK_FIR_MAXSEG && batch <= 65535 && !(force && force[0] == '1');
   if (!p->fused) { p->nseg = 1; p->Kseg = K; }
+  if (per_row && !p->fused) {
+    wfk_fir_plan_destroy(p);
+    return fir_fail(WFK_EUNSUP, "per-row FIR kernels need the on-chip transform (K <= 6148, batch <= 65535, WFK_FIR_ROCFFT unset)");
+  }
   int L = 1024;
   while (L < 8 * K) L *= 2;               // hop M = L - K + 1 >= 7/8 L
   if (const char* e = getenv("WFK_FIR_L")) { int v = atoi(e); if (v >= 2 * K && (v & (v - 1)) == 0) L = v; }
@@ -258,7 +279,9 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
     return fir_fail(WFK_ENOMEM, "FIR buffer allocation failed");
   }
   }
-  if (hipMalloc(&p->kspec, (size_t)p->nseg * nf * 2 * es) != hipSuccess ||
+  const size_t nrow = per_row ? (size_t)batch : 1;
+  p->krow = per_row ? (int64_t)((size_t)p->nseg * nf) : 0;
+  if (hipMalloc(&p->kspec, nrow * (size_t)p->nseg * nf * 2 * es) != hipSuccess ||
       (p->fused && hipMalloc(&p->tw, 256 * 2 * es) != hipSuccess)) {
     wfk_fir_plan_destroy(p);
     return fir_fail(WFK_ENOMEM, "FIR buffer allocation failed");
@@ -269,8 +292,9 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
     long double th = -2.0L * 3.141592653589793238462643383279502884L * i / L;
     tw[i] = {cosl(th), sinl(th)};
   }
-  std::vector<double> ks64(2 * nf * p->nseg);
-  std::vector<float> ks32(2 * nf * p->nseg);
+  std::vector<double> ks64(2 * nf * p->nseg * nrow);
+  std::vector<float> ks32(2 * nf * p->nseg * nrow);
+  if (!per_row) {
   for (int sg = 0; sg < p->nseg; ++sg) {
     const int k0 = sg * p->Kseg, k1 = std::min(K, k0 + (p->fused ? p->Kseg : K));
     for (size_t f = 0; f < nf; ++f) {
@@ -282,6 +306,37 @@ int wfk_fir_plan_create(const double* ker_host, int32_t K, int64_t n, int32_t ba
       ks64[at] = (double)acc.real(); ks64[at + 1] = (double)acc.imag();
       ks32[at] = (float)acc.real(); ks32[at + 1] = (float)acc.imag();
     }
+  }
+  } else {
+    // one spectrum per row: a radix-2 transform in long double (K L / 2 products per kernel, as above, would
+    // be seconds for a few thousand rows); bit-reversed input, L = 4096 here (fused path only)
+    int lg = 0;
+    while ((1 << lg) < L) ++lg;
+    std::vector<std::complex<long double>> z((size_t)L);
+    for (size_t r = 0; r < nrow; ++r)
+      for (int sg = 0; sg < p->nseg; ++sg) {
+        const int k0 = sg * p->Kseg, k1 = std::min(K, k0 + p->Kseg);
+        for (int i = 0; i < L; ++i) {
+          int rev = 0;
+          for (int b = 0; b < lg; ++b) rev |= ((i >> b) & 1) << (lg - 1 - b);
+          z[(size_t)rev] = i < k1 - k0 ? (long double)ker_host[r * (size_t)K + k0 + i] : 0.0L;
+        }
+        for (int half = 1; half < L; half <<= 1) {
+          const int stepw = L / (2 * half);
+          for (int i0 = 0; i0 < L; i0 += 2 * half)
+            for (int j = 0; j < half; ++j) {
+              const std::complex<long double> t = z[(size_t)(i0 + j + half)] * tw[(size_t)(j * stepw)];
+              z[(size_t)(i0 + j + half)] = z[(size_t)(i0 + j)] - t;
+              z[(size_t)(i0 + j)] += t;
+            }
+        }
+        for (size_t f = 0; f < nf; ++f) {
+          const std::complex<long double> acc = z[f] / (long double)L;
+          const size_t at = 2 * ((r * p->nseg + sg) * nf + f);
+          ks64[at] = (double)acc.real(); ks64[at + 1] = (double)acc.imag();
+          ks32[at] = (float)acc.real(); ks32[at + 1] = (float)acc.imag();
+        }
+      }
   }
   hipError_t e = kind == WFK_OUT_F32
                      ? hipMemcpy(p->kspec, ks32.data(), ks32.size() * 4, hipMemcpyHostToDevice)
@@ -316,7 +371,7 @@ int wfk_fir_apply(wfk_fir_plan* p, const void* in_dev, int64_t in_stride, void* 
     for (int sg = 0; sg < p->nseg; ++sg)
       if (wfk_internal_fir_fused_launch(p->kind, in_dev, in_stride, out_dev, out_stride,
                                         (const char*)p->kspec + sg * seg_bytes, p->tw, p->n, p->M,
-                                        p->Kseg, p->lead + sg * p->Kseg, p->nblk, p->batch, sg > 0, s))
+                                        p->Kseg, p->lead + sg * p->Kseg, p->nblk, p->batch, sg > 0, s, p->krow))
         return fir_fail(WFK_EHIP, "fused FIR kernel launch failed");
     return WFK_OK;
   }

@@ -28,10 +28,11 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
                                                  T* __restrict__ out, int64_t out_stride,
                                                  const cx<T>* __restrict__ hspec,
                                                  const cx<T>* __restrict__ tw, int64_t n, int M,
-                                                 int K, int lead, int accumulate) {
+                                                 int K, int lead, int accumulate, int64_t hrow) {
   __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
   const int tid = threadIdx.x;
   const int64_t pair = blockIdx.x, ch = blockIdx.y;
+  hspec += ch * hrow;                 // per-row kernels (wfk_fir_plan_create_rows): this row's spectrum; else hrow = 0
   const T* row = in + ch * in_stride;
   T* orow = out + ch * out_stride;
   const int64_t b1 = 2 * pair, b2 = b1 + 1;
@@ -101,17 +102,17 @@ __global__ void __launch_bounds__(256, WFK_FIR_WAVES) fir_fused(const T* __restr
 extern "C" int wfk_internal_fir_fused_launch(int kind, const void* in, int64_t in_stride, void* out,
                                              int64_t out_stride, const void* hspec, const void* tw,
                                              int64_t n, int M, int K, int lead, int64_t nblk,
-                                             int32_t batch, int accumulate, void* stream) {
+                                             int32_t batch, int accumulate, void* stream, int64_t hspec_row_stride) {
   const dim3 grid((unsigned)((nblk + 1) / 2), (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   if (kind == WFK_OUT_F32)
     hipLaunchKernelGGL(fir_fused<float>, grid, dim3(256), 0, s, (const float*)in, in_stride,
                        (float*)out, out_stride, (const cx<float>*)hspec, (const cx<float>*)tw, n, M,
-                       K, lead, accumulate);
+                       K, lead, accumulate, hspec_row_stride);
   else
     hipLaunchKernelGGL(fir_fused<double>, grid, dim3(256), 0, s, (const double*)in, in_stride,
                        (double*)out, out_stride, (const cx<double>*)hspec, (const cx<double>*)tw, n,
-                       M, K, lead, accumulate);
+                       M, K, lead, accumulate, hspec_row_stride);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -38,6 +38,7 @@ extern "C" void wfk_internal_set_error(const char* msg);
 extern "C" void wfk_internal_fir_tables(const wfk_fir_plan* p, const void** kspec, const void** tw,
                                         int* fused, int* nseg, int* K, int* lead);
 extern "C" void wfk_internal_plan_tables(const wfk_plan* p, const HostPlan** h, const double** d_params);
+extern "C" int64_t wfk_internal_fir_krow(const wfk_fir_plan* p);
 
 namespace {
 
@@ -52,6 +53,7 @@ struct ChainArgs {
   const void* tw;
   double t0, step, last;
   int32_t has_last, hop, K, lead;
+  int64_t hrow;                // per-row kernels: complex elements between the spectra of consecutive rows (else 0)
 };
 
 template <int... K, typename F>
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
   const int tid = threadIdx.x;
   const int ch = blockIdx.y;
   const DevChannel C = a.channels[ch];
-  const cx<T>* hspec = static_cast<const cx<T>*>(a.hspec);
+  const cx<T>* hspec = static_cast<const cx<T>*>(a.hspec) + (int64_t)ch * a.hrow;
   const cx<T>* tw = static_cast<const cx<T>*>(a.tw);
   T* const orow = static_cast<T*>(a.out) + (int64_t)ch * a.out_stride;
   const int M = a.hop;
@@ -456,6 +458,7 @@ struct ChainShortArgs {
   const void* tw;
   double step;
   int32_t hop, K, lead;
+  int64_t hrow;               // per-row kernels: complex elements between the spectra of consecutive rows (else 0)
 };
 
 // runs of pieces without a short form (mixed plans), copied from the workspace into the half's LDS image.
@@ -484,7 +487,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
   const int tid = threadIdx.x;
   const int ch = blockIdx.y;
   const DevChannel C = a.channels[ch];
-  const cx<T>* hspec = static_cast<const cx<T>*>(a.hspec);
+  const cx<T>* hspec = static_cast<const cx<T>*>(a.hspec) + (int64_t)ch * a.hrow;
   const cx<T>* tw = static_cast<const cx<T>*>(a.tw);
   T* const orow = static_cast<T*>(a.out) + (int64_t)ch * a.out_stride;
   const int M = a.hop;
@@ -696,8 +699,21 @@ int wfk_chain_plan_destroy(wfk_chain_plan* p) {
   return WFK_OK;
 }
 
+static int chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const double* ker_host, int32_t K,
+                             int kind, wfk_chain_plan** out, bool per_row);
+
 int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const double* ker_host, int32_t K,
                           int kind, wfk_chain_plan** out) {
+  return chain_plan_create(prog, grid, ker_host, K, kind, out, false);
+}
+
+int wfk_chain_plan_create_rows(const wfk_program* prog, const wfk_grid* grid, const double* kers_host, int32_t K,
+                               int kind, wfk_chain_plan** out) {
+  return chain_plan_create(prog, grid, kers_host, K, kind, out, true);
+}
+
+static int chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const double* ker_host, int32_t K,
+                             int kind, wfk_chain_plan** out, bool per_row) {
   if (!out) return chain_fail(WFK_EINVAL, "null out");
   *out = nullptr;
   if (!prog || !grid || !ker_host) return chain_fail(WFK_EINVAL, "null argument");
@@ -708,7 +724,8 @@ int wfk_chain_plan_create(const wfk_program* prog, const wfk_grid* grid, const d
   if (rc) { wfk_chain_plan_destroy(p); return rc; }
   p->n = grid->n;
   p->n_channels = prog->n_channels;
-  rc = wfk_fir_plan_create(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir);
+  rc = per_row ? wfk_fir_plan_create_rows(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir)
+               : wfk_fir_plan_create(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir);
   if (rc) { wfk_chain_plan_destroy(p); return rc; }
   p->t0 = grid->t0; p->step = grid->step; p->last = grid->last; p->has_last = grid->has_last;
   if (p->n == 0 || p->n_channels == 0) { *out = p; return WFK_OK; }
@@ -876,7 +893,7 @@ int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void*
     a.ws = p->workspace; a.ws_stride = p->n;
     a.channels = p->d_channels; a.wins = p->d_wins; a.entries = p->d_entries; a.recs = p->d_recs;
     a.out = out_dev; a.out_stride = out_stride; a.n = p->n; a.npairs = p->npairs;
-    a.hspec = kspec; a.tw = tw; a.step = p->step;
+    a.hspec = kspec; a.tw = tw; a.step = p->step; a.hrow = wfk_internal_fir_krow(p->fir);
     a.hop = 256 * p->hopb; a.K = K; a.lead = lead;
     const dim3 grid((unsigned)p->npairs, (unsigned)p->n_channels);
     if (p->kind == WFK_OUT_F32) {
@@ -892,7 +909,7 @@ int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void*
   ChainArgs a{};
   a.channels = p->d_channels; a.pieces = p->d_pieces; a.params = p->d_params; a.pair_first = p->d_pair_first;
   a.out = out_dev; a.out_stride = out_stride; a.n = p->n; a.npairs = p->npairs;
-  a.hspec = kspec; a.tw = tw;
+  a.hspec = kspec; a.tw = tw; a.hrow = wfk_internal_fir_krow(p->fir);
   a.t0 = p->t0; a.step = p->step; a.last = p->last; a.has_last = p->has_last;
   a.hop = 256 * p->hopb; a.K = K; a.lead = lead;
   const dim3 grid((unsigned)((p->npairs + WFK_FIRS_PPW - 1) / WFK_FIRS_PPW), (unsigned)p->n_channels);

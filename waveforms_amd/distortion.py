@@ -21,7 +21,8 @@ from . import _engine
 
 class FirStage:
     """Device-resident FIR stage for `batch` rows of `n` samples (build once, apply
-    many times).  `apply_torch(x, y)`: x, y (batch, >= n) device tensors."""
+    many times).  `apply_torch(x, y)`: x, y (batch, >= n) device tensors.  `ker` of shape (batch, K):
+    one kernel per row."""
 
     def __init__(self, ker, n: int, batch: int = 1, dtype=np.float64):
         self.plan = _engine.FirPlan(ker, n, batch, dtype)
@@ -55,7 +56,7 @@ class SampledFir:
     the unfiltered samples never touch HBM (reference chain: waveform.py:529-563 ->
     distortion.py:329-337).  Build once, launch many times.
 
-        sf = SampledFir(channels, ('linspace', 0.0, 3e-6, 10**7, False), ker)
+        sf = SampledFir(channels, ('linspace', 0.0, 3e-6, 10**7, False), ker)   # ker (K,) or (n_channels, K)
         sf.launch_torch(out)          # (n_channels, >= n) device tensor of the plan dtype
     """
 
