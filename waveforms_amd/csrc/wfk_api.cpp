@@ -453,7 +453,14 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
 
 int wfk_plan_launch(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind, uint32_t flags,
                     void* hip_stream) {
-  return plan_launch_part(p, out_dev, ch_stride, out_kind, flags, hip_stream, 0, 1, nullptr, nullptr);
+  // (public flags only: WFK_PLAN_FOREIGN_ONLY belongs to wfk_internal_plan_launch_foreign)
+  return plan_launch_part(p, out_dev, ch_stride, out_kind, flags & WFK_ACCUMULATE, hip_stream, 0, 1, nullptr, nullptr);
+}
+
+// the general-kernel part of a mixed short plan alone (the chain at AWG rates samples the short pieces itself
+// and takes these through its workspace: wfk_fir_sampled.hip)
+int wfk_internal_plan_launch_foreign(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind, void* hip_stream) {
+  return plan_launch_part(p, out_dev, ch_stride, out_kind, WFK_PLAN_FOREIGN_ONLY, hip_stream, 0, 1, nullptr, nullptr);
 }
 
 static size_t elem_size(int kind) {

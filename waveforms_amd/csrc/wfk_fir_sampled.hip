@@ -39,6 +39,7 @@ extern "C" void wfk_internal_fir_tables(const wfk_fir_plan* p, const void** kspe
                                         int* fused, int* nseg, int* K, int* lead);
 extern "C" void wfk_internal_plan_tables(const wfk_plan* p, const HostPlan** h, const double** d_params);
 extern "C" int64_t wfk_internal_fir_krow(const wfk_fir_plan* p);
+extern "C" int wfk_internal_plan_launch_foreign(wfk_plan* p, void* out_dev, int64_t ch_stride, int out_kind, void* hip_stream);
 
 namespace {
 
@@ -886,7 +887,7 @@ int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void*
   wfk_internal_fir_tables(p->fir, &kspec, &tw, &fir_fused, &nseg, &K, &lead);
   if (p->shortw) {
     if (p->hybrid) {
-      const int rc = wfk_plan_launch(p->sampler, p->workspace, p->n, p->kind, WFK_PLAN_FOREIGN_ONLY, hip_stream);
+      const int rc = wfk_internal_plan_launch_foreign(p->sampler, p->workspace, p->n, p->kind, hip_stream);
       if (rc) return rc;
     }
     ChainShortArgs a{};
