@@ -554,8 +554,9 @@ __device__ __forceinline__ double corr_delta(const CorrCtx& cc, double dj0, doub
   const double dj = dj0 + (double)(64 * K);      // exact integer arithmetic in double
   const double m = dj * cc.step;                 // t[j] = fl(fl(j*step) + t0): two roundings
   double t = m + cc.t0;
-  if (cc.dlast >= 0.0 && dj == cc.dlast) t = cc.last;
-  if (cc.tshift != 0.0) t = t - cc.tshift;
+  if (dj == cc.dlast) t = cc.last;     // (dlast = -1 without an overridden last sample: never equal, dj >= 0)
+  t = t - cc.tshift;                   // (unconditional: t - 0.0 == t bit for bit; the reference's `if shift != 0`
+                                       //  guards an allocation, not a rounding -- 3 instructions per sample here)
   const double eps = (t - cc.xref) - (double)(cc.kbase + K) * D;
   const double um = t - sm;                      // the reference's fl(x - shift) ...
   const double bb = um - t;
