@@ -225,11 +225,39 @@ def _c_oracle_worker(job):
     return float(y.sum())
 
 
-def c_oracle_all_cores(grid_desc, n_points, procs=16):
-    """The plain-C oracle on `procs` host cores at once (one channel per process, spawned:
-    the parent holds a HIP context and must not be forked)."""
+def host_cpu_share():
+    """-> (cores this process may use, cores of the host).  A GPU box hands each GPU a share of the host
+    (cgroup quota and / or affinity mask): os.cpu_count() is the host, not the share."""
+    total = os.cpu_count() or 1
+    share = total
+    try:
+        share = min(share, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    share = min(share, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    share = min(share, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, share), total
+
+
+def c_oracle_all_cores(grid_desc, n_points, procs=None):
+    """The plain-C oracle on every core this process may use (one channel per process, spawned: the parent
+    holds a HIP context and must not be forked).  Bounded at 64 workers: one 1e7-point channel each is
+    already 5 GB of outputs in flight."""
     import multiprocessing as mp
-    procs = max(1, min(procs, os.cpu_count() or 1))
+    share, _total = host_cpu_share()
+    procs = max(1, min(procs or share, share, 64))
     ctx = mp.get_context('spawn')
     with ctx.Pool(procs) as pool:
         pool.map(_c_oracle_worker, [(1000 + c, ('linspace', 0.0, 1e-9, 8, False)) for c in range(procs)])
@@ -259,7 +287,7 @@ def cpu_baseline(chans, grid_desc, budget_s=12.0):
             'kind': 'port',
             'sample': f'{done} channel(s) x {len(t)} pts of the same workload, '
                       f'NumPy restatement of the reference pass structure, '
-                      f'{dt:.1f} s, host has {os.cpu_count()} cores'}
+                      f'{dt:.1f} s, 1 thread; this job may use {host_cpu_share()[0]} of the host\'s {os.cpu_count()} cores'}
     # second CPU figure: the plain-C scalar oracle on the flattened program (1 thread)
     try:
         from oracle import c_oracle
@@ -270,46 +298,67 @@ def cpu_baseline(chans, grid_desc, budget_s=12.0):
         c_oracle.eval_grid(prog, g)
         dc = time.perf_counter() - t1
         base['c_oracle_msamples_per_s_1thread'] = 2 * len(t) / dc / 1e6
-        # third figure: the same C oracle on 16 host cores at once (the box's CPU share)
+        # third figure: the same C oracle on every core this process may use (the box's CPU share)
         rate, procs = c_oracle_all_cores(grid_desc, len(t))
+        share, total = host_cpu_share()
         base['c_oracle_msamples_per_s_multi'] = rate
         base['c_oracle_multi_procs'] = procs
+        base['c_oracle_multi_cores'] = f'{procs} processes = {procs} of the {share} cores this job may use; the host has {total}'
     except Exception as exc:  # the C oracle is optional for the bench
         base['c_oracle_error'] = repr(exc)
     return base, outs
 
 
-def profile_traffic(key):
+def profile_traffic(key, algo_bytes=None):
     """HBM bytes per launch of this workload's dominant kernel from the committed PMC passes
     (profiles/traffic.json: rocprofv3 --pmc of this same command; counters cannot be read
-    from inside the run) -> (bytes | None, source label)."""
+    from inside the run) -> (bytes | None, source label).  The counters belong to the shape that
+    was profiled (`algo_bytes` in the entry): a run of another shape (--channels / --points /
+    --dtype) gets null, not a number that is not its own."""
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     if not os.path.exists(tfile):
         return None, None
     t = json.load(open(tfile))
     v = t.get(key)
-    if isinstance(v, dict):
-        return v.get('bytes'), 'profiles/' + v.get('source', 'traffic.json') + ' (separate rocprofv3 --pmc pass, not this run)'
-    return v, 'profiles/traffic.json (separate rocprofv3 --pmc pass, not this run)'
+    if not isinstance(v, dict):
+        return None, None
+    src = 'profiles/' + v.get('source', 'traffic.json')
+    prof = v.get('algo_bytes')
+    if algo_bytes is not None and prof is not None and abs(prof - algo_bytes) > 1e-6 * prof:
+        return None, (f'{src} was collected on another shape ({prof:.4g} algorithmic bytes per launch, this run '
+                      f'{algo_bytes:.4g}): no traffic figure for this run')
+    return v.get('bytes'), src + ' (separate rocprofv3 --pmc pass of this shape, not this run)'
+
+
+RATED_CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2.4 GHz = 78.6 TF
 
 
 def valu_roofline(key, kernel_ms, samples):
-    """Second roofline for kernels bound by fp64 VALU issue, not by HBM (the FIR transform of C4, DESIGN
-    3.7): VALU wave instructions per launch from the committed PMC pass x 4 cycles (a wave64 fp64
-    instruction occupies its SIMD for 4 cycles) / 1024 SIMDs / shader clock = the time the kernel
-    needs at 100 % VALU issue; valu_frac = that / the kernel time measured in THIS run."""
+    """Second roofline for kernels bound by fp64 VALU issue, not by HBM (the FIR transform of C4):
+    VALU wave instructions per launch from the committed PMC pass x 4 cycles (a wave64 fp64
+    instruction occupies its SIMD for 4 cycles) / 1024 SIMDs / the part's RATED clock (2.4 GHz: the
+    78.6 TF fp64 vector peak) = the time the kernel needs at 100 % VALU issue; valu_frac = that / the
+    kernel time measured in THIS run.  The clock the PMC pass itself sampled (GRBM_GUI_ACTIVE / time;
+    the part runs below its rated clock at its power cap) is reported beside it, not used."""
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     if not os.path.exists(tfile):
         return None
     v = json.load(open(tfile)).get(key)
     if not isinstance(v, dict) or 'valu_wave_instr' not in v:
         return None
-    clock = v.get('shader_clock_ghz', 1.9)
-    issue_ms = v['valu_wave_instr'] * 4 / 1024 / (clock * 1e9) * 1e3
-    return {'bound': 'valu_fp64', 'valu_instr_per_sample': v['valu_wave_instr'] * 64 / samples,
-            'issue_limited_ms': issue_ms, 'valu_frac': issue_ms / kernel_ms,
-            'shader_clock_ghz': clock, 'simds': 1024, 'cycles_per_wave_instr': 4,
-            'source': 'profiles/' + v.get('source', 'traffic.json') + ' (separate rocprofv3 --pmc pass: SQ_INSTS_VALU, GRBM_GUI_ACTIVE)'}
+    prof = v.get('algo_samples')
+    if prof is not None and prof != samples:
+        return None          # counters of another shape
+    issue_ms = v['valu_wave_instr'] * 4 / 1024 / (RATED_CLOCK_GHZ * 1e9) * 1e3
+    out = {'bound': 'valu_fp64', 'valu_instr_per_sample': v['valu_wave_instr'] * 64 / samples,
+           'issue_limited_ms': issue_ms, 'valu_frac': issue_ms / kernel_ms,
+           'clock_ghz': RATED_CLOCK_GHZ, 'clock': 'rated peak engine clock', 'simds': 1024, 'cycles_per_wave_instr': 4,
+           'source': 'profiles/' + v.get('source', 'traffic.json') + ' (separate rocprofv3 --pmc pass: SQ_INSTS_VALU, GRBM_GUI_ACTIVE)'}
+    if 'shader_clock_ghz' in v:
+        sc = v['shader_clock_ghz']
+        out['sampled_clock_ghz'] = sc
+        out['valu_frac_at_sampled_clock'] = v['valu_wave_instr'] * 4 / 1024 / (sc * 1e9) * 1e3 / kernel_ms
+    return out
 
 
 # ---------------------------------------------------------------------------------------
@@ -321,6 +370,12 @@ def run_plan_only(args, rank, world):
     import torch.distributed as dist
     from waveforms_amd import _engine, _flatten
     from waveforms_amd._dist import channel_block
+    # launcher rehearsals (tests/test_bench_launcher.py), plan-only runs alone: a rank that dies before the
+    # rendezvous, and one that never comes back (the parent's --deadline has to end it)
+    if os.environ.get('WFK_BENCH_FAIL_RANK') == str(rank):
+        raise SystemExit(7)
+    if os.environ.get('WFK_BENCH_HANG_RANK') == str(rank):
+        time.sleep(120)
     if world > 1:
         dist.init_process_group('gloo', rank=rank, world_size=world)
     name = args.workload
@@ -363,10 +418,6 @@ def run_rank(args):
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if os.environ.get('WFK_BENCH_FAIL_RANK') == str(rank):      # (tests/test_bench_launcher.py: a rank that dies early)
-        raise SystemExit(7)
-    if os.environ.get('WFK_BENCH_HANG_RANK') == str(rank):      # ... and one that never comes back
-        time.sleep(3600)
     if args.plan_only:
         return run_plan_only(args, rank, world)
     import torch
@@ -478,7 +529,7 @@ def run_rank(args):
     elem = np.dtype(dtype).itemsize
     algo_bytes = bs.n_channels * bs.n * elem            # per launch, per GPU
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_src = profile_traffic(name)
+    traffic, traffic_src = profile_traffic(name, algo_bytes)
 
     table_bytes = bs.plan.table_bytes()
     roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,

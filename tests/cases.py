@@ -14,6 +14,12 @@ from waveforms_amd import workloads as wl
 
 LIN = ('linspace', -10.0, 10.0, 1001, True)
 
+# THE fp32 bound: a float launch is within this fraction of the waveform's peak of the fp64 oracle, in every
+# test and every soak (tools/*_soak.py).  north_star's contract is 1e-3; the kernels compute in double and
+# round once on the store, so what remains is float rounding of the result (6e-8) plus the float phasor /
+# envelope recurrences of the fused tiers (worst observed over the soaks: 3.03e-5, chain_soak seed 29703).
+FP32_TOL = 5e-5
+
 
 def _ref_tolist_case(ns):          # reference tests/test_waveform.py:38-48
     p = ns.gaussian(10) >> 5

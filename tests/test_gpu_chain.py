@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import golden_io
+from cases import FP32_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten, workloads as wl
@@ -92,7 +93,7 @@ def test_awg_channels_fuse_at_awg_rates(rate, duty30):
     sf.close()
     s32 = SampledFir(chans, grid, ker, np.float32)
     assert s32.fused and s32.plan.kernel_name() == 'fir_short<float,12>'
-    assert np.max(np.abs(s32.to_host() - want)) <= 2e-5
+    assert np.max(np.abs(s32.to_host() - want)) <= FP32_TOL
     s32.close()
 
 
@@ -126,7 +127,7 @@ def test_short_chain_flat_tops_clip_and_mixed_plans():
     mixed = [wl.awg_channel(wf, 0, n, rate) + (wf.chirp(1e8, 2e8, 30e-9) >> 5e-6) + 0.2,
              wl.awg_channel(wf, 1, n, rate, True) + (wf.mollifier(40e-9) >> 7.03e-6) + (wf.mollifier(8e-9) >> 3e-9),
              wl.awg_channel(wf, 2, n, rate)]
-    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+    for dt, tol in ((np.float64, 1e-12), (np.float32, FP32_TOL)):
         sf = SampledFir(mixed, grid, ker, dt)
         assert sf.fused and 'fir_short<' in sf.plan.kernel_name() and sf.plan.kernel_name().startswith('wfk_sample<'), \
             (sf.why_not, sf.plan.kernel_name())
@@ -150,7 +151,7 @@ def test_vstack_offset_shift_and_float32():
     s32 = SampledFir(chans, grid, ker, np.float32)
     assert s32.fused
     got = s32.to_host()
-    assert got.dtype == np.float32 and np.max(np.abs(got - want)) <= 2e-5
+    assert got.dtype == np.float32 and np.max(np.abs(got - want)) <= FP32_TOL
     s32.close()
 
 
@@ -327,7 +328,7 @@ def test_chain_at_awg_rates_against_reference_vectors(name):
     build, rate, n = cases.AWG_CASES[name]
     want = golden_io.npz('awg_c4.npz')[name + '.z']
     idx = cases.awg_c4_subset(n)
-    for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+    for dt, tol in ((np.float64, 1e-11), (np.float32, FP32_TOL)):
         sf = SampledFir([build(wf, rate)], cases._awg_grid(n, rate), wl.c4_kernel(), dt)
         if not name.startswith('readme'):      # (the README pulses are a few long pieces: not a short plan)
             assert sf.fused and 'fir_short<' in sf.plan.kernel_name(), (sf.why_not, sf.plan.kernel_name())
@@ -349,7 +350,7 @@ def test_one_kernel_per_channel():
             g = _flatten.grid_from_desc(grid)
             y = c_oracle.eval_grid(_flatten.flatten(chans), g)
             want = np.stack([c_oracle.fir(r, k) for r, k in zip(y, kers)])
-            for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+            for dt, tol in ((np.float64, 1e-11), (np.float32, FP32_TOL)):
                 sf = SampledFir(chans, grid, kers, dt)
                 assert sf.fused and kname in sf.plan.kernel_name(), (sf.why_not, sf.plan.kernel_name())
                 assert np.max(np.abs(sf.to_host() - want)) <= tol

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import cases
+from cases import FP32_TOL
 import golden_io
 import waveforms_amd as wf
 from oracle import c_oracle
@@ -30,7 +31,7 @@ def _check(w, grid, tol=1e-9, want_kernel='wfk_sample_lean<double,false,16,false
     err = float(np.max(np.abs(got - ora)))
     assert err <= tol * pk, err
     g32 = plan.run_host(np.complex64 if cplx else np.float32)
-    assert np.max(np.abs(g32 - ora)) <= 3e-5 * pk
+    assert np.max(np.abs(g32 - ora)) <= FP32_TOL * pk
     return plan, err
 
 

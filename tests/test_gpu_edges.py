@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import cases
+from cases import FP32_TOL
 import golden_io
 import waveforms_amd as wf
 from oracle import np_oracle
@@ -80,7 +81,7 @@ def test_ragged_sizes_all_dtypes(n):
     close(bs.to_host(np.float64), want)
     g32 = bs.to_host(np.float32)
     assert g32.dtype == np.float32
-    assert float(np.max(np.abs(g32 - want))) <= 2e-5
+    assert float(np.max(np.abs(g32 - want))) <= FP32_TOL
     gc = bs.to_host(np.complex128)
     assert gc.dtype == np.complex128 and not gc.imag.any()
     close(gc.real, want)

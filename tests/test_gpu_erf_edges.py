@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+from cases import FP32_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -23,7 +24,7 @@ def _tones(rng, nt, lo=-300e6, hi=300e6):
     return out
 
 
-def _check(chans, grid, lean=True, tol64=2e-12, tol32=3e-5, cplx=False):
+def _check(chans, grid, lean=True, tol64=2e-12, tol32=FP32_TOL, cplx=False):
     prog = _flatten.flatten(chans)
     g = _flatten.grid_from_desc(grid)
     want = c_oracle.eval_grid(prog, g, True) if cplx else c_oracle.eval_grid(prog, g)

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from cases import FP32_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 GRID = ('linspace', 0.0, 120e-9, 400_001, False)
 
 
-def _check(chans, grid=GRID, cplx=False, tol64=1e-12, tol32=3e-5, fused=True, exp_ab=True):
+def _check(chans, grid=GRID, cplx=False, tol64=1e-12, tol32=FP32_TOL, fused=True, exp_ab=True):
     prog = _flatten.flatten(chans)
     g = _flatten.grid_from_desc(grid)
     want = c_oracle.eval_grid(prog, g, True) if cplx else c_oracle.eval_grid(prog, g)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+from cases import FP32_TOL
 import golden_io
 import waveforms_amd as wf
 from oracle import c_oracle, np_oracle
@@ -66,7 +67,7 @@ def test_far_sequence_full_length():
     ora = c_oracle.eval_grid(prog, g)
     assert np.max(np.abs(got - ora)) <= 1e-9
     f32 = plan.run_host(np.float32)
-    assert np.max(np.abs(f32 - ora)) <= 2e-5
+    assert np.max(np.abs(f32 - ora)) <= FP32_TOL
 
 
 @pytest.mark.parametrize('name', ['readme_x', 'readme_y', 'drag_block', 'vstack4', 'vstack_ops', 'mix_env', 'c2_small', 'c3_small', 'cospulse', 'clip', 'complex_amp', 'square_erf'])

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import cases
+from cases import FP32_TOL
 import golden_io
 import waveforms_amd as wf
 from oracle import c_oracle
@@ -31,7 +32,7 @@ def test_random_script(seed):
     assert np.max(np.abs(got - ora), initial=0.0) <= 1e-9 * pk, (seed, plan.info.n_fused,
                                                                plan.info.n_generic)
     got32 = plan.run_host(np.float32)[0].astype(np.float64)
-    assert np.max(np.abs(got32 - ora), initial=0.0) <= 5e-5 * pk, seed
+    assert np.max(np.abs(got32 - ora), initial=0.0) <= FP32_TOL * pk, seed
     if seed % 4 == 0:
         t = c_oracle.grid_values(g)
         tl = _engine.Plan(prog, t=t).run_host(np.float64)[0]

@@ -7,6 +7,7 @@ import pytest
 from scipy.signal import butter, lfilter, lfiltic, sosfilt, tf2sos
 
 import cases
+from cases import FP32_TOL
 import golden_io
 import waveforms_amd as wf
 from oracle import np_oracle
@@ -221,7 +222,7 @@ def test_long_cascade_fp32_initial_in_place():
     xd = torch.from_numpy(x).float().cuda()
     plan.apply(xd.data_ptr(), n, xd.data_ptr(), n, None, None, 0.3)
     torch.cuda.synchronize()
-    assert np.max(np.abs(xd.cpu().numpy().astype(np.float64) - want)) <= 2e-5
+    assert np.max(np.abs(xd.cpu().numpy().astype(np.float64) - want)) <= FP32_TOL
 
 
 def test_order_zero_and_empty_filter_lists():
@@ -351,7 +352,7 @@ def test_single_pass_chained_scan(nsec, n, rows):
     assert np.max(np.abs(got - want)) <= 1e-11 * pk
     assert np.max(np.abs(zf - zfw)) <= 1e-11 * max(1.0, np.abs(zfw).max())
     assert np.array_equal(got_ip, got)
-    assert np.max(np.abs(g32 - want)) <= 2e-5 * pk
+    assert np.max(np.abs(g32 - want)) <= FP32_TOL * pk
     os.environ['WFK_IIR_ONEPASS'] = '0'        # the three-launch form of the same plan
     try:
         three, zf3 = run(np.float64)
@@ -411,7 +412,7 @@ def test_first_order_cascades(nsec, n, rows):
     assert np.max(np.abs(got - want)) <= 1e-11 * pk
     assert np.max(np.abs(zf - zfw)) <= 1e-11 * max(1.0, np.abs(zfw).max())
     g32, _ = run(np.float32)
-    assert np.max(np.abs(g32 - want)) <= 2e-5 * pk
+    assert np.max(np.abs(g32 - want)) <= FP32_TOL * pk
 
 
 @pytest.mark.parametrize('rows,n,first', [(64, 200_003, False), (130, 150_001, True)])
@@ -486,15 +487,28 @@ def test_lookback_timeout_is_an_error_not_silent_nans():
         plan2 = _engine.IirPlan(secs, n, rows, np.float64)
         plan2.apply(dx.ptr, n, dy.ptr, n)
         _engine.sync()
-        with pytest.raises(_engine.EngineError, match='look-back timed out'):
-            plan2.apply(dx.ptr, n, dy.ptr, n)
-        plan2.apply(dx.ptr, n, dy.ptr, n)
+        assert plan2.apply(dx.ptr, n, dy.ptr, n) is False   # WFK_ETIMEOUT: refused, nothing launched
+        assert b'look-back timed out' in _engine.lib().wfk_last_error()
+        assert plan2.apply(dx.ptr, n, dy.ptr, n) is True
         assert plan2.status() is True
         assert np.max(np.abs(dy.download((rows, n), np.float64) - want)) <= 1e-10
         plan2.close()
         # the host-level stages retry by themselves
         y, _ = distortion.iir_host(x[0], secs)
         assert np.max(np.abs(y - want[0])) <= 1e-10
+        # ... also when the SECOND row of a complex waveform is the one that meets the first row's fault
+        # (its apply is refused with WFK_ETIMEOUT before status() is asked), and on a cut cascade
+        # where every part can stall
+        import waveforms_amd as wf
+        w = (wf.gaussian(2e-6) >> 5e-6) * wf.cos(2 * np.pi * 3e6) * (1 + 0.5j)
+        w.start, w.stop, w.sample_rate = 0.0, 1e-4, 2e9
+        got = w.sample(filters=(sos, 0.1))
+        ref = w.sample()
+        want_c = sosfilt(sos, ref.real - 0.1) + 0.1 + 1j * sosfilt(sos, ref.imag)
+        assert np.max(np.abs(got - want_c)) <= 1e-10
+        sos8 = butter(8, 0.1, output='sos')
+        y8, _ = distortion.iir_host(x[0], [(r[:3], r[3:]) for r in sos8])
+        assert np.max(np.abs(y8 - sosfilt(sos8, x[0]))) <= 1e-9
     finally:
         del os.environ['WFK_IIR_SPIN']
         plan.close()

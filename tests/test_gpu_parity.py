@@ -8,11 +8,12 @@ run through the drop-in API.
 Tolerances (BASELINE.json): integer piece indices bit-exact (test_abi_cpu.py);
 fp64 |err| <= 1e-9 absolute on O(1)-amplitude cases == 1e-9 * max(1, peak) in
 general (peak-relative for the README config); fp32 <= 1e-3
-relative to peak (we hold 2e-5)."""
+relative to peak (we hold cases.FP32_TOL, the one fp32 bound of tests and soaks)."""
 import numpy as np
 import pytest
 
 import cases
+from cases import FP32_TOL
 import golden_io
 import waveforms_amd as wf
 from oracle import c_oracle
@@ -23,7 +24,6 @@ pytestmark = pytest.mark.gpu
 SAMPLES = golden_io.npz('samples.npz')
 API = golden_io.npz('sample_api.npz')
 FP64_TOL = 1e-9
-FP32_TOL = 2e-5
 
 
 def peak(a):

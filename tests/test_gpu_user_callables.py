@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+from cases import FP32_TOL
 import golden_io
 import user_lib
 import waveforms_amd as wf
@@ -63,7 +64,7 @@ def test_batch_grid_mode_mixes_callables_and_fused_channels():
         _close(got[c], USER[name + '.y'])
     _close(got[1], np_oracle.call(chans[1], x), 1e-11)
     f32 = BatchSampler(chans, grid).to_host(np.float32)
-    assert np.max(np.abs(f32[0] - USER['u_tanh.y'])) <= 2e-5
+    assert np.max(np.abs(f32[0] - USER['u_tanh.y'])) <= FP32_TOL
 
 
 def test_builtin_registry_entries_evaluate_on_the_device():

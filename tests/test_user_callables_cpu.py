@@ -97,3 +97,19 @@ def test_complex_valued_callable_expands_into_real_table_factors():
     assert np.allclose(prog.arrays['tm_amp_re'], [2.0, 0.0]) and np.allclose(prog.arrays['tm_amp_im'], [0.0, 2.0])
     got = c_oracle.eval_tlist(prog, t, want_complex=True)[0]
     assert np.max(np.abs(got - 2.0 * np.exp(1j * t))) <= 1e-15
+
+
+@pytest.mark.parametrize('power', [2 + 1j, np.complex128(2 + 1j), np.complex64(2 + 1j)])
+def test_complex_power_in_any_spelling_takes_the_host_path(power):
+    # np.complex128 subclasses complex, np.complex64 does not: both must expand over (re, im) like a
+    # Python complex power instead of being cast to float64 (which drops the imaginary part)
+    t = np.linspace(0.5, 1.5, 7)
+    w = wf.function(lambda tt: 1.0 + tt) ** power
+    prog = _flatten.flatten([w], t)
+    assert prog.host_complex and prog.complex_amp
+    got = c_oracle.eval_tlist(prog, t, want_complex=True)[0]
+    assert np.max(np.abs(got - (1.0 + t)**complex(power))) <= 1e-13
+    # a built-in under such a power must not stay on the native device path either
+    if _engine.device_count() == 0:
+        with pytest.raises(Exception):
+            _flatten.flatten([wf.cos(3.0) ** power], t)

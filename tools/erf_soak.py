@@ -8,6 +8,7 @@ import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
+from cases import FP32_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -97,7 +98,7 @@ for seed in range(first, first + count):
             eab = float(np.max(np.abs(_engine.Plan(prog, grid=g).run_host(np.complex128 if cplx else np.float64) - got)))
         finally:
             del os.environ['WFK_DISABLE_ERFMUL']
-        if not (e64 <= tol * pk and e32 <= 5e-5 * pk and eab <= 2 * tol * pk) or not np.all(np.isfinite(got)):
+        if not (e64 <= tol * pk and e32 <= FP32_TOL * pk and eab <= 2 * tol * pk) or not np.all(np.isfinite(got)):
             bad.append((seed, e64 / pk, e32 / pk, eab / pk, plan.kernel_name()))
             print('FAIL', bad[-1], flush=True)
     except Exception as e:

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import cases
+from cases import FP32_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -36,7 +37,7 @@ for seed in range(first, first + count):
         plan = _engine.Plan(prog, grid=g)
         e64 = float(np.max(np.abs(plan.run_host(np.float64) - ora)))
         e32 = float(np.max(np.abs(plan.run_host(np.float32).astype(np.float64) - ora)))
-        if not (e64 <= 1e-9 * pk and e32 <= 5e-5 * pk):
+        if not (e64 <= 1e-9 * pk and e32 <= FP32_TOL * pk):
             bad.append((seed, npts, e64 / pk, e32 / pk, plan.info.n_fused, plan.info.n_generic))
             print('FAIL', bad[-1], flush=True)
         plan.close()

@@ -32,6 +32,14 @@ for arg in sys.argv[1:]:
                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles per XCD / kernel time = shader clock
                 ent['shader_clock_ghz'] = c['GRBM_GUI_ACTIVE'] / 8 / float(row['AverageNs'])
                 break
+    # the shape the pass ran on (bench.py's default shape of that workload): bench.py quotes the counters
+    # only for a run of the same algorithmic bytes
+    sys.path.insert(0, ROOT)
+    import bench
+    ch, pts = bench.default_shape(wl.split('.')[0])
+    elem = 4 if (wl.split('.')[0] == 'c3' or wl.endswith('.f32')) else 8
+    ent['algo_bytes'] = ch * pts * elem
+    ent['algo_samples'] = ch * pts
     table[wl] = ent
     print(wl, ent)
 json.dump(table, open(out_path, 'w'), indent=1)

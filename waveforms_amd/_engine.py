@@ -327,8 +327,15 @@ class IirPlan:
 
     def apply(self, in_ptr, in_stride, out_ptr, out_stride, zi_ptr=None, zf_ptr=None,
               initial=0.0, stream=0):
-        check(lib().wfk_iir_apply(self._h, in_ptr, in_stride, out_ptr, out_stride, zi_ptr,
-                                  zf_ptr, float(initial), stream))
+        """-> False when the library refused the launch with WFK_ETIMEOUT: an EARLIER launch of this plan
+        (for instance the other row of a complex waveform) ran into a look-back timeout; nothing was
+        launched, the plan has switched to the three-launch form -- treat it like `status() == False`."""
+        rc = lib().wfk_iir_apply(self._h, in_ptr, in_stride, out_ptr, out_stride, zi_ptr,
+                                 zf_ptr, float(initial), stream)
+        if rc == E_TIMEOUT:
+            return False
+        check(rc)
+        return True
 
     def status(self, stream=0) -> bool:
         """Synchronise `stream`; False if a single-pass launch since the last check ran into a look-back

@@ -76,6 +76,9 @@ class Program:
 _SIMPLE_ARGC = {k: v for k, v in _ARGC.items() if v is not None and k != _ir.DRAG}
 
 
+# a complex power in any spelling: Python complex, np.complex128 (a subclass of it) and np.complex64 (not one)
+_COMPLEX = (complex, np.complexfloating)
+
 SAMPLED = 1000   # include/wfk.h WFK_SAMPLED: a factor evaluated by the caller, (i0, values...)
 
 
@@ -213,7 +216,7 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
                     nf0, np0 = len(fc_type), len(pool)
                     for f, n in zip(factors, powers):
                         tid = f[0]
-                        if tid not in native or type(n) is complex:
+                        if tid not in native or isinstance(n, _COMPLEX):
                             break
                         fc_power.append(n)
                         fc_shift.append(f[-1])
@@ -235,13 +238,13 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
                     staged = []       # the term's other factors: (type, power, shift, args | (start, values))
                     for f, n in zip(factors, powers):
                         tid = f[0]
-                        if tid in native and not isinstance(n, complex):
+                        if tid in native and not isinstance(n, _COMPLEX):
                             argc = _SIMPLE_ARGC.get(tid)
                             staged.append((tid, n, f[-1], f[1:-1] if (argc is not None and len(f) == argc + 2)
                                            else _factor_args(f)))
                             continue
                         fn = lib[tid]     # KeyError for an unknown id, like the reference
-                        if isinstance(fn, BuiltinPrimitive) and not isinstance(n, complex):
+                        if isinstance(fn, BuiltinPrimitive) and not isinstance(n, _COMPLEX):
                             # the id is mapped onto ANOTHER device primitive
                             staged.append((fn.type_id, n, f[-1], _factor_args((fn.type_id, ) + tuple(f[1:]))))
                             continue
@@ -254,7 +257,7 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
                         if f not in cache:
                             cache[f] = host.evaluate(fn, f, xs, start, stop)
                         vals = cache[f]
-                        if isinstance(n, complex) or np.iscomplexobj(vals):
+                        if isinstance(n, _COMPLEX) or np.iscomplexobj(vals):
                             v = vals if n == 1 else vals**n
                             v = v.astype(np.complex128, copy=False)
                             cplx.append((start, np.ascontiguousarray(v.real), np.ascontiguousarray(v.imag)))

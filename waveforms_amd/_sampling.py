@@ -163,11 +163,12 @@ def _sample_filtered(w, plan, sos, initial, zi):
             plan.launch(buf.ptr, n, _engine.OUT_F64)
             if cplx:
                 plan_im.launch(buf.ptr + max(n, 1) * 8, n, _engine.OUT_F64)
+            ok = True
             for r in range(rows):
                 off, zoff = r * max(n, 1) * 8, r * max(D, 1) * 8
-                iir.apply(buf.ptr + off, n, buf.ptr + off, n, dzi.ptr + zoff, dzf.ptr + zoff,
-                          init.imag if r else init.real)                       # in place
-            if iir.status():
+                ok = iir.apply(buf.ptr + off, n, buf.ptr + off, n, dzi.ptr + zoff, dzf.ptr + zoff,
+                               init.imag if r else init.real) and ok           # in place
+            if iir.status() and ok:
                 break
             # a single-pass look-back timed out: the filter ran in place, so sample again; the plan has
             # switched to the three-launch form

@@ -271,7 +271,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // ---- geometry: short tier? ---------------------------------------------------------------------
   // Mean length of the live member pieces (samples).  Below WFK_SH_MAXLEN the plan is compiled for
   // the contiguous-lane geometry: lane stride = one sample, WFK_SH_R samples per lane.
-  if (want_short != 0 && grid && !H.tlist && !nofast && ns_override == 0 && ax.n > 0) {
+  // (the tier's records and the fir_short window entries hold sample indices as 32-bit words: a row of
+  // 2^31 samples or more stays on the standard tiers, which index in 64 bits)
+  if (want_short != 0 && grid && !H.tlist && !nofast && ns_override == 0 && ax.n > 0 && ax.n < ((int64_t)1 << 31)) {
     const char* e = std::getenv("WFK_SHORT");          // 0: never, 1: whatever the piece length
     const int mode = e ? std::atoi(e) : -1;
     int64_t live = 0, live_samples = 0;

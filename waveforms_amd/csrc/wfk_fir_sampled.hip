@@ -393,9 +393,6 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
     // ---- transform, multiply by the kernel spectrum, inverse transform (as fir_fused) -------
     // (nothing of the transform -- twiddles, exchange addresses -- may be hoisted above the sampling
     //  phase: it would be spilled there, and 150 B of scratch per thread are 16 GB per launch)
-#ifdef WFK_FIRS_PRIO
-    __builtin_amdgcn_s_setprio(WFK_FIRS_PRIO);
-#endif
     int tf = tid;                      // the transform's view of the thread index, opaque: everything
     asm volatile("" : "+v"(tf));       // derived from it is computed HERE, after the sampling phase
     const cx<T> wa = tw[tf], wb = tw[16 * (tf & 15)];
@@ -403,9 +400,6 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_sampled(const ChainAr
 #pragma unroll
     // (the 16 L2 loads of the kernel spectrum cost 3.6 %: 9.76 vs 10.12 ms with constants in their place)
     for (int k3 = 0; k3 < 16; ++k3) v[k3] = cmul(v[k3], hspec[tf + 256 * k3]);
-#ifdef WFK_FIRS_PRIO2
-    __builtin_amdgcn_s_setprio(WFK_FIRS_PRIO2);
-#endif
     fft4096<true>(v, lds, wa, wb, tf);
     if (interior) {
       T* const o1 = orow + b1 * M + (tf - (a.K - 1));       // wave-uniform base + lane offset
@@ -515,7 +509,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
 
   // (The third, the op record, is loaded where it is used.  Tried: half 1's record loaded a half ahead --
   // 24 more live VGPRs on top of 168, 45 spilled, 1.05 -> 1.32 ms; one dword of each record loaded here to
-  // warm L2 -- 1.045 vs 1.052 ms, nothing.  Timing experiments on 2048 x 1e5 (-DWFK_FSH_EXP): without the
+  // warm L2 -- 1.045 vs 1.052 ms, nothing.  Timing experiments on 2048 x 1e5 (tools/experiments/timing_switches.patch): without the
   // evaluation 0.73 ms, i.e. the sampling phases cost 0.32 ms against 0.23 ms of pure VALU issue for
   // their 37 instructions per sample: they are issue-bound like the transform, not latency-bound.)
 
@@ -557,16 +551,7 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
       const int len = live ? (int)(word >> 28) + 1 : 0;
       const int o = (int)((word >> 16) & 0xfff);
       const double* op = a.recs + 2 * (rec0 + (int64_t)(word & 0xffff));
-#if defined(WFK_FSH_EXP) && WFK_FSH_EXP == 2
-      shdev::OpRec rec;                                    // timing experiment: no record traffic
-      rec.a = rec.b = rec.c = rec.d = rec.e = rec.f = make_double2(1.0 + word, 0.5);
-      rec.a.x = __hiloint2double(0, WFK_SH_LAST | 0x15);
-#else
       shdev::OpRec rec = shdev::load_op(op);
-#endif
-#if defined(WFK_FSH_EXP) && WFK_FSH_EXP == 1
-      live = false;                                        // timing experiment: no evaluation
-#endif
       const double kf = (double)((int)(uint32_t)(h0 + o) - shdev::op_ref(rec));   // samples from the record's reference sample
       double acc[R], acci[1];
       CH_EACH(R, k) acc[k] = 0.0; CH_END

@@ -464,11 +464,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   }
   const int64_t slot = ((int64_t)row * nchunks + chunk);
   const unsigned F_AGG = epoch * 4u + 1u, F_PRE = epoch * 4u + 2u;
-#if defined(OP_EXP) && OP_EXP == 2
-  if (false) {                                           // timing experiment: nothing published either
-#else
   if (chunk > 0 && lane == 0) {
-#endif
 #pragma unroll
     for (int i = 0; i < DD; ++i) op_store(aggbuf + slot * DD + i, agg[i]);
     __builtin_amdgcn_s_waitcnt(0);                           // the state is in memory before the flag is
@@ -480,11 +476,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
   for (int i = 0; i < IIR_MAXD; ++i) sin_[i] = 0.0;
   bool poisoned = false;
-#if defined(OP_EXP) && OP_EXP >= 1
-  if (true) {                                            // timing experiment: no look-back at all (wrong results)
-#else
   if (chunk == 0) {
-#endif
 #pragma unroll
     for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
   } else {
@@ -505,10 +497,6 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
       unsigned st = 0;
       int kstop = -1;
       bool whole_window = false;
-#if defined(OP_EXP) && OP_EXP == 3
-      kstop = chunk - 1 < 7 ? (int)chunk - 1 : 7;          // timing experiment: 8 predecessors, nobody waited for
-      spins = spin_limit;
-#endif
       for (; spins < spin_limit; ++spins) {
         if (pc >= 0 && !(st == F_PRE)) st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool pre = pc >= 0 && st == F_PRE;
@@ -578,11 +566,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #pragma unroll
     for (int i = 0; i < IIR_MAXD; ++i) so[i] = i < DD ? agg[i < DD ? i : 0] : 0.0;
     dd_matvec_add<DD>(so, lanepU, sin_, DD);                 // U^1 (plain double where PLAIN allows it: 9.82 -> 9.65 ms at 256 x 1e7, inside the noise; not kept)
-#if defined(OP_EXP) && OP_EXP == 2
-    if (false) {
-#else
     if (chunk + 1 < nchunks) {
-#endif
 #pragma unroll
       for (int i = 0; i < DD; ++i) op_store(prefbuf + slot * DD + i, so[i]);
       __builtin_amdgcn_s_waitcnt(0);
@@ -1035,6 +1019,8 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
       int rc = iir_apply_impl(q, first ? in_dev : out_dev, first ? in_stride : out_stride, out_dev,
                               out_stride, zi_dev ? p->zi_tmp : nullptr, zf_dev ? p->zf_tmp : nullptr,
                               first ? initial : 0.0, last ? post : 0.0, hip_stream);
+      if (rc == WFK_ETIMEOUT)   // a part reported an earlier stall: no part of this plan may wait on a chain again
+        for (wfk_iir_plan* r : p->parts) r->onepass = false;
       if (rc) return rc;
       if (zf_dev && Di > 0 &&
           hipMemcpy2DAsync(zf_dev + off, D * 8, p->zf_tmp, Di * 8, Di * 8, (size_t)p->batch,
@@ -1129,6 +1115,11 @@ extern "C" int wfk_iir_status(wfk_iir_plan* p, void* hip_stream) {
   };
   look(p);
   for (wfk_iir_plan* q : p->parts) look(q);
+  if (fault) {
+    // one chunk chain stalled: the retry must not be able to time out in ANOTHER part either
+    p->onepass = false;
+    for (wfk_iir_plan* q : p->parts) q->onepass = false;
+  }
   if (fault)
     return iir_fail(WFK_ETIMEOUT, "IIR single pass: a look-back timed out (a stalled or preempted predecessor chunk); the outputs "
                                   "of that launch hold NaN. The plan now runs in the three-launch form: launch again");

@@ -203,10 +203,6 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
       const double* op = seg.rec;
       OpRec rec = first;
       bool live = seg.len > 0;
-#if defined(WFK_SH_EXP) && (WFK_SH_EXP == 1 || WFK_SH_EXP == 2)
-      live = false;                       // timing experiment: no evaluation
-      acc[0] = rec.a.y + rec.f.x;
-#endif
       // The first op is evaluated in straight-line code, further ops (multi-tone pieces) in a loop:
       // a loop whose body reads registers loaded before it gets a vmcnt(0) in its preheader from the
       // compiler (SIInsertWaitcnts' preheader flush), which here would wait for the slot load just
@@ -307,11 +303,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
       }
       SH_EACH(8, rr)
         constexpr int r = hb * 8 + rr;
-#if defined(WFK_SH_EXP) && WFK_SH_EXP == 3
-        if (v[rr] == (E)1.2345e-300) buf_store<E>(v[rr], ores, b0off);                 // timing experiment: no stores
-#else
         buf_store<E>(v[rr], ores, r == 0 ? b0off : b1off + 64 * (r - 1) * (int)sizeof(E));
-#endif
       SH_END
     SH_END
 

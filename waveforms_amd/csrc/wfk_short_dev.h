@@ -100,10 +100,6 @@ struct OpRec {
 __device__ __forceinline__ OpRec load_op(const double* p) {
   const double2* q = reinterpret_cast<const double2*>(p);
   OpRec r;
-#if defined(WFK_SH_EXP) && WFK_SH_EXP == 2
-  r.a = r.b = r.c = r.d = r.e = r.f = make_double2(1.0, 0.5);   // timing experiment: no record traffic
-  return r;
-#endif
   r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4]; r.f = q[5];
   return r;
 }

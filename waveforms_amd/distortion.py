@@ -224,10 +224,10 @@ def iir_host(sig, sections, zi=None, initial=0.0, ker=None):
             dzi = dev(z.nbytes)
             dzi.upload(z)
         dzf = dev(batch * D * 8)
-        plan.apply(x.ptr, n, y.ptr, n, dzi.ptr if dzi else None, dzf.ptr, initial)
-        if not plan.status():      # a single-pass look-back timed out (stalled predecessor chunk): the plan has
-            plan.apply(x.ptr, n, y.ptr, n, dzi.ptr if dzi else None, dzf.ptr, initial)   # switched form; x is intact
-            if not plan.status():
+        ok = plan.apply(x.ptr, n, y.ptr, n, dzi.ptr if dzi else None, dzf.ptr, initial)
+        if not (plan.status() and ok):   # a single-pass look-back timed out (stalled predecessor chunk): every part
+            ok = plan.apply(x.ptr, n, y.ptr, n, dzi.ptr if dzi else None, dzf.ptr, initial)  # of the plan has switched
+            if not (plan.status() and ok):                                                   # form; x is intact
                 raise _engine.EngineError('IIR stage failed twice')
         res = y
         if ker is not None and n > 0:
