@@ -25,6 +25,9 @@ Outputs
   tests/golden/logic.json         marker / mask / | / & flat lists per case
   tests/golden/user.npz           scripts with Python-callable primitives (function(), function_lib=)
   tests/golden/awg.npz            pulse trains on 1-5 GS/s arange grids (AWG_CASES): full vectors + piece edges
+  tests/golden/n4.npz             SAMPLED trees of the symbolic layer: simplify(), filter(), marker / mask / | / &,
+                                  interp(), the twins of the wave_eval texts, the CLI's arrays (PARSER_ / FILTER_ /
+                                  INTERP_ / CLI_CASES of tests/cases.py)
 """
 import json
 import os
@@ -166,6 +169,49 @@ def make_awg(ref, gold):
     np.savez_compressed(os.path.join(gold, 'awg_c4.npz'), **c4)
 
 
+def make_n4(ref, gold):
+    """SURVEY 8(f) N4, sampled: what the REFERENCE gets when it evaluates trees that went through its
+    symbolic layer -- simplify (waveform.py:384-396), filter (:398-402), marker / mask / | / & (:425-476),
+    interp (:1425-1440) -- and, for the text front-end and the CLI (waveform_parser.py / __main__.py, which
+    cannot run here: no ANTLR runtime), the twin of every text built through the reference's Python API
+    and passed through .simplify() as wave_eval does (waveform_parser.py:287)."""
+    import cases
+    from waveforms_amd import workloads as wl
+    from waveforms.waveform import WaveVStack
+    n4 = {}
+    for name, (build, grid) in cases.CASES.items():
+        try:
+            w = build(ref).simplify()
+        except Exception:
+            continue
+        n4[f'simp.{name}'] = np.asarray(w(wl.make_grid(grid)))
+    plain = [(n_, b_) for n_, (b_, _g) in cases.CASES.items() if not isinstance(b_(ref), WaveVStack)]
+    for i, (name, build) in enumerate(plain):
+        w, t = build(ref), wl.make_grid(cases.CASES[name][1])
+        other = plain[(i * 7 + 3) % len(plain)][1](ref)
+        try:
+            vals = {'marker': w.marker(t), 'mask0': w.mask()(t), 'mask_e': w.mask(0.37)(t),
+                    'or': (w | other)(t), 'and': (w & other)(t)}
+        except Exception:
+            continue
+        for k, v in vals.items():
+            v = np.asarray(v)
+            assert not np.iscomplexobj(v) and np.all((v == 0) | (v == 1)), (name, k)
+            n4[f'logic.{name}.{k}'] = v.astype(np.uint8)
+    for name, (text, twin, grid) in cases.PARSER_CASES.items():
+        w = twin(ref).simplify()
+        n4[f'parse.{name}'] = np.asarray(w(wl.make_grid(grid)))
+    for name, (build, lo, hi, grid) in cases.FILTER_CASES.items():
+        n4[f'filter.{name}'] = np.asarray(build(ref).filter(lo, hi)(wl.make_grid(grid)))
+    for name, (build, grid) in cases.INTERP_CASES.items():
+        n4[f'interp.{name}'] = np.asarray(build(ref)(wl.make_grid(grid)))
+    for name, (argv, text, twin, start, stop, rate, amp) in cases.CLI_CASES.items():
+        w = twin(ref).simplify()
+        w.start, w.stop, w.sample_rate = start, stop, rate      # __main__.py:24-30
+        n4[f'cli.{name}'] = w.sample() * amp
+    np.savez_compressed(os.path.join(gold, 'n4.npz'), **n4)
+
+
 def make_iir(ref, gold):
     import cases
     # ---- IIR stages (SURVEY.md 8(f) N1): sample(filters=) and predistort(filters=) ----
@@ -220,6 +266,9 @@ def main():
         return
     if sys.argv[1:] == ['iir']:            # regenerate this fixture only
         make_iir(ref, gold)
+        return
+    if sys.argv[1:] == ['n4']:             # regenerate this fixture only
+        make_n4(ref, gold)
         return
 
     # ---- filter-design helpers of distortion.py (host-side, no sampling) ----------
@@ -402,6 +451,7 @@ def main():
     np.savez_compressed(os.path.join(gold, 'spectral.npz'), **spec)
     make_late(ref, gold)
     make_awg(ref, gold)
+    make_n4(ref, gold)
     for f in sorted(os.listdir(gold)):
         print(f, os.path.getsize(os.path.join(gold, f)))
 

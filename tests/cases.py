@@ -812,3 +812,110 @@ AWG_CASES = {   # name -> (build(ns, rate), rate, n)
     'vstack_2g': (_awg_vstack, 2e9, 8400),
     'clip_2g': (_awg_clip, 2e9, 10000),
 }
+
+
+# ---------------------------------------------------------------------------------------------------
+# N4 on the device: the text front-end, simplify, filter, marker / mask / | / &, interp
+# and the CLI -- trees that come out of the symbolic layer, SAMPLED.  oracle/make_golden.py builds the twin
+# of every case with the real reference's Python API and stores what it samples to (tests/golden/n4.npz);
+# tests/test_gpu_frontend.py runs the product's own front-end through the HIP path against those vectors.
+# ---------------------------------------------------------------------------------------------------
+_PG = ('linspace', -130.0, 40.0, 6801, True)
+
+PARSER_CASES = {   # name -> (text for wave_eval, twin(ns) built through the Python API, grid)
+    # reference tests/test_waveform.py:141-166 (test_parser)
+    'p_one': ("one()", lambda ns: ns.one(), LIN),
+    'p_zero': ("zero()", lambda ns: ns.zero(), LIN),
+    'p_pi': ("pi", lambda ns: ns.const(pi), LIN),
+    'p_e': ("e", lambda ns: ns.const(np.e), LIN),
+    'p_ref_w2': ("(gaussian(10) << 100) + square(20, edge=5, type='linear') * cos(2*pi*23.1)",
+                 lambda ns: (ns.gaussian(10) << 100) + ns.square(20, edge=5, type='linear') * ns.cos(2 * pi * 23.1), _PG),
+    'p_ref_w3': ("((gaussian(10) << 50) + ((square(20, 5, type='linear') * cos(2*pi*23.1)) >> 50)) << 50",
+                 lambda ns: (ns.gaussian(10) << 100) + ns.square(20, edge=5, type='linear') * ns.cos(2 * pi * 23.1), _PG),
+    'p_ref_w4': ("(gaussian(10) << 100) + square(20, 5, 'linear') * cos(2*pi*23.1)",
+                 lambda ns: (ns.gaussian(10) << 100) + ns.square(20, edge=5, type='linear') * ns.cos(2 * pi * 23.1), _PG),
+    'p_ref_poly': ("poly([1, -1/2, 1/6, -1/12])", lambda ns: ns.poly([1, -1 / 2, 1 / 6, -1 / 12]), LIN),
+    'p_ref_poly_tuple': ("poly((1, -1/2, 1/6, -1/12))", lambda ns: ns.poly([1, -1 / 2, 1 / 6, -1 / 12]), LIN),
+    # the rest of the grammar: precedence quirks, keyword arguments, complex numbers, every constructor family
+    'p_unary_loosest': ("-cos(2) + gaussian(3)", lambda ns: -(ns.cos(2) + ns.gaussian(3)), LIN),
+    'p_pow_left': ("(cos(1.5) + 2) ** 2 ** 2", lambda ns: ((ns.cos(1.5) + 2)**2)**2, LIN),
+    'p_caret': ("gaussian(6) ^ 3 / 4", lambda ns: ns.gaussian(6)**3 / 4, LIN),
+    'p_shift_loosest': ("gaussian(4) * cos(3) >> 1 + 1.5", lambda ns: (ns.gaussian(4) * ns.cos(3)) >> 2.5, LIN),
+    'p_complex': ("(1 + 2j) * cos(2, 0.3) * gaussian(5) + 0.5j * sin(1)",
+                  lambda ns: (1 + 2j) * ns.cos(2, 0.3) * ns.gaussian(5) + 0.5j * ns.sin(1), LIN),
+    'p_kwargs': ("gaussian(width=4, plateau=2) * 0.7 + cosPulse(5, plateau=1.5) >> 2",
+                 lambda ns: (ns.gaussian(4, plateau=2) * 0.7 + ns.cosPulse(5, plateau=1.5)) >> 2, LIN),
+    'p_drag': ("drag(0.4, 12.0, delta=0.05, block_freq=0.9, phase=0.3, t0=-7.0)",
+               lambda ns: ns.drag(0.4, 12.0, delta=0.05, block_freq=0.9, phase=0.3, t0=-7.0), LIN),
+    'p_chirp': ("chirp(1, 2, 10, 4, 'exponential') * square(9) >> 4.5",
+                lambda ns: (ns.chirp(1, 2, 10, 4, 'exponential') * ns.square(9)) >> 4.5, LIN),
+    'p_interp': ("interp([-4, -1, 0, 2.5, 6], [0, 1, -0.5, 2, 0]) * cos(3)",
+                 lambda ns: ns.interp([-4, -1, 0, 2.5, 6], [0, 1, -0.5, 2, 0]) * ns.cos(3), LIN),
+    'p_sampling_points': ("samplingPoints(-4.0, 6.0, [0.0, 1.0, -0.5, 2.0, 0.25, -1.0, 0.0])",
+                          lambda ns: ns.samplingPoints(-4.0, 6.0, [0.0, 1.0, -0.5, 2.0, 0.25, -1.0, 0.0]), LIN),
+    'p_mollifier_sinc': ("mollifier(12.0, d=1) + 0.1 * sinc(0.8) * square(18)",
+                         lambda ns: ns.mollifier(12.0, d=1) + 0.1 * ns.sinc(0.8) * ns.square(18), LIN),
+    'p_cut': ("cut(gaussian(6) * cos(4), start=-2, stop=3, max=0.5)",
+              lambda ns: ns.cut(ns.gaussian(6) * ns.cos(4), start=-2, stop=3, max=0.5), LIN),
+    'p_deriv': ("D(gaussian(8) * cos(3), 2) / 10", lambda ns: ns.D(ns.gaussian(8) * ns.cos(3), 2) / 10, LIN),
+    'p_cosh': ("0.01 * cosh(0.4) - 0.02 * sinh(0.35) + coshPulse(9, eps=2.5)",
+               lambda ns: 0.01 * ns.cosh(0.4) - 0.02 * ns.sinh(0.35) + ns.coshPulse(9, eps=2.5), LIN),
+    'p_exp_trig': ("2 * (exp(1.01 + 22j) ** 2 << 1) * exp(1.01 + 22j)",
+                   lambda ns: 2 * (ns.exp(1.01 + 22j)**2 << 1) * ns.exp(1.01 + 22j), ('linspace', -2.0, 2.0, 1001, True)),
+    'p_general_cosine': ("general_cosine(16.0, 1.0, 0.3, 0.1) + hanning(7) >> 1",
+                         lambda ns: (ns.general_cosine(16.0, 1.0, 0.3, 0.1) + ns.hanning(7)) >> 1, LIN),
+    'p_mdrag': ("drag_sin(0.4, 14.0, 0, 0.013, (0.9, 0.55, -0.7), 0.3, -7.0)",
+                lambda ns: ns.drag_sin(0.4, 14.0, 0, 0.013, (0.9, 0.55, -0.7), 0.3, -7.0), LIN),
+    'p_pulse_train': ("(gaussian(20e-9) >> 30e-9) * cos(2*pi*150e6, 0.4) + (square(40e-9, edge=5e-9) >> 100e-9) * cos(2*pi*80e6)",
+                      lambda ns: (ns.gaussian(20e-9) >> 30e-9) * ns.cos(2 * pi * 150e6, 0.4)
+                      + (ns.square(40e-9, edge=5e-9) >> 100e-9) * ns.cos(2 * pi * 80e6),
+                      ('linspace', 0.0, 160e-9, 4001, True)),
+}
+
+
+def _tones(ns, freqs, amps=None, env=None):
+    w = ns.zero()
+    for k, f in enumerate(freqs):
+        a = 1.0 if amps is None else amps[k]
+        w = w + a * ns.cos(f, 0.1 * k)
+    return w if env is None else w * env
+
+
+FILTER_CASES = {   # name -> (build(ns), low, high, grid): w.filter(low, high), reference _waveform.pyx:638-654
+    'f_lowpass': (lambda ns: _tones(ns, [2.0, 9.0, 30.0]) + 1, 0, 5, LIN),
+    'f_highpass': (lambda ns: _tones(ns, [2.0, 9.0, 30.0]) + 1, 5, np.inf, LIN),
+    'f_band': (lambda ns: _tones(ns, [2.0, 9.0, 30.0], [0.5, 1.5, -0.7]), 5, 20, LIN),
+    'f_band_env': (lambda ns: _tones(ns, [2.0, 9.0, 30.0], [0.5, 1.5, -0.7], ns.gaussian(8)) + ns.gaussian(3), 5, 20, LIN),
+    'f_pieces': (lambda ns: (ns.square(6) << 4) * _tones(ns, [1.0, 12.0]) + (ns.square(6) >> 4) * _tones(ns, [3.0, 25.0]), 2, 20, LIN),
+    'f_products': (lambda ns: ns.cos(3) * ns.cos(11) * ns.gaussian(9) + ns.sin(1.5) * ns.sin(2.5), 6, 12, LIN),   # products reduce to sums first
+    'f_complex': (lambda ns: (1 + 0.5j) * ns.cos(7) + 2j * ns.cos(15, 0.3) + 0.25, 0, 10, LIN),
+    'f_nothing_left': (lambda ns: _tones(ns, [2.0, 9.0]), 100, 200, LIN),
+    'f_mixing': (lambda ns: ns.mixing(ns.gaussian(6), freq=8.0, phase=0.2, DRAGScaling=0.01)[0] + ns.cos(1.0) * ns.square(12), 4, 16, LIN),
+}
+
+INTERP_CASES = {   # name -> (build(ns), grid): interp() -- piecewise LINEAR segments (reference waveform.py:1425-1440)
+    'i_plain': (lambda ns: ns.interp([0.0, 1.0, 3.0, 4.5], [0.0, 2.0, -1.0, 0.5]), LIN),
+    'i_repeated_x': (lambda ns: ns.interp([-5.0, -2.0, -2.0, 1.0, 6.0], [1.0, 1.0, -1.0, 0.0, 3.0]), LIN),
+    'i_many': (lambda ns: ns.interp(np.linspace(-9, 9, 73), np.sin(np.linspace(-9, 9, 73))**3), LIN),
+    'i_mod': (lambda ns: (ns.interp([-6.0, -1.0, 2.0, 7.0], [0.0, 1.0, 1.0, 0.0]) * ns.cos(5, 0.7)) >> 0.5, LIN),
+    'i_awg': (lambda ns: ns.interp(np.arange(0, 41) * 5e-9, np.hanning(41)) * ns.cos(2 * pi * 120e6),
+              ('arange', -10e-9, 230e-9, 0.5e-9)),
+}
+
+CLI_CASES = {   # name -> (argv of `python -m waveforms_amd sample` minus EXPR OUT, EXPR, twin(ns), start, stop, rate, amplitude)
+    # ('>>' binds loosest of the binary operators: "a * b + c >> s" shifts the whole sum)
+    'cli_awg': (['-S', '2e9', '-b', '1e-6'], "(gaussian(100e-9) >> 300e-9) * cos(2*pi*50e6) + square(200e-9, edge=20e-9) >> 600e-9",
+                lambda ns: ((ns.gaussian(100e-9) >> 300e-9) * ns.cos(2 * pi * 50e6) + ns.square(200e-9, edge=20e-9)) >> 600e-9,
+                0, 1e-6, 2e9, 1),
+    'cli_defaults': ([], "cos(2*pi*440) * gaussian(0.5) >> 0.5", lambda ns: (ns.cos(2 * pi * 440) * ns.gaussian(0.5)) >> 0.5, 0, 1, 44100, 1),
+    'cli_duration': (['-S', '1000', '-a', '2', '-l', '5', '-A', '3'], "sin(7) * square(3) >> 4.5",
+                     lambda ns: (ns.sin(7) * ns.square(3)) >> 4.5, 2, 7, 1000, 3),
+}
+
+def n4_logic_names():
+    """plain-Waveform cases of CASES that tests/golden/logic.json holds marker / mask / | / & lists for"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'logic.json')) as f:
+        gold = json.load(f)
+    return sorted(n for n, v in gold.items() if 'error' not in v)

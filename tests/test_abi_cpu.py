@@ -137,8 +137,8 @@ def test_malformed_programs_are_rejected():
         _engine.Plan(good, grid=_flatten.wfk_grid(0.0, -1.0, 10, 0, 0.0))
 
 
-def test_plain_c_consumer(tmp_path):
-    """include/wfk.h is consumable from plain C (gcc), no Python/torch/HIP headers."""
+def run_c_consumer(tmp_path):
+    """Build tests/c_abi/abi_smoke.c with gcc against include/wfk.h + libwfk_hip.so, run it -> stdout."""
     import subprocess
     exe = tmp_path / 'abi_smoke'
     libdir = os.path.join(ROOT, 'waveforms_amd', 'csrc')
@@ -154,7 +154,13 @@ def test_plain_c_consumer(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=torch_lib + ':' + os.environ.get('LD_LIBRARY_PATH', ''))
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
-    assert 'abi_smoke' in r.stdout
+    return r.stdout
+
+
+def test_plain_c_consumer(tmp_path):
+    """include/wfk.h is consumable from plain C (gcc), no Python/torch/HIP headers.  (Its device branch runs
+    under `-m gpu`: tests/test_gpu_c_abi.py.)"""
+    assert 'abi_smoke' in run_c_consumer(tmp_path)
 
 
 def test_grid_detection_is_exact():
