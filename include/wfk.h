@@ -272,6 +272,12 @@ int wfk_spectral_plan_destroy(wfk_spectral_plan* plan);
 int wfk_host_alloc(void** host_ptr, size_t bytes);
 int wfk_host_free(void* host_ptr);
 
+/* 1 if every one of the n 64-bit floats at `host` is finite, 0 if one is NaN or +-inf (a few host threads;
+ * ~1 ms for 80 MB).  `Waveform.__call__(x, out=buf)` zeroes the caller's array with `out *= 0`
+ * (waveforms/waveform.py:551), which KEEPS NaN / inf: the drop-in call asks this before it lets
+ * wfk_plan_run_host overwrite `buf`, and follows the reference's two passes when the answer is 0.   */
+int wfk_host_all_finite(const double* host, int64_t n);
+
 /* -- device memory helpers for FFI callers without a HIP binding ---------- */
 int wfk_malloc(void** dev_ptr, size_t bytes);
 int wfk_free(void* dev_ptr);

@@ -233,6 +233,29 @@ def predistort_inputs(i):
     return sig, ker
 
 
+def predistort_high_cases():
+    """predistort(filters=) of combined order 17 and 20 where the reference's direct-form lfilter is still
+    finite and accurate: poles spread over 0.01..0.6 (time constants of 0.2-2 samples; the generator prints
+    |reference - scipy cascade| <= 2e-11 for these.  With poles up to 0.8 the reference is already 3e-9 off
+    the cascade, up to 0.95 it is 1e-3 off, with 40-sample time constants it returns 1e70):
+    (n, [(A, tau)...], initial).  Bounds the product's cascade form against the reference by a number."""
+    out = []
+    for order, seed, initial in ((17, 0, 0.0), (20, 1, 0.25), (18, 2, -0.4 + 0.3j)):
+        rng = np.random.default_rng(900 + seed)
+        poles = np.linspace(0.01, 0.6, order) * rng.uniform(0.98, 1.02, order)
+        taus = -1.0 / np.log(poles) / 1e9
+        amps = rng.uniform(-0.02, 0.02, order)
+        out.append((3000, list(zip(amps, taus)), initial))
+    return out
+
+
+def predistort_high_input(i):
+    n, _, initial = predistort_high_cases()[i]
+    rng = np.random.default_rng(950 + i)
+    sig = np.concatenate([np.zeros(50), np.ones(n - 50)]) * 0.5 + 0.05 * rng.normal(size=n) + initial
+    return sig
+
+
 def predistort_cplx_cases():
     """predistort on COMPLEX inputs (scipy's lfilter / fftconvolve take them, reference distortion.py:298-337):
     (n, [(A, tau)...] | None, initial, fir_taps, real signal?, complex kernel?, explicit complex zi?)."""
@@ -911,6 +934,25 @@ CLI_CASES = {   # name -> (argv of `python -m waveforms_amd sample` minus EXPR O
     'cli_duration': (['-S', '1000', '-a', '2', '-l', '5', '-A', '3'], "sin(7) * square(3) >> 4.5",
                      lambda ns: (ns.sin(7) * ns.square(3)) >> 4.5, 2, 7, 1000, 3),
 }
+
+def out_nonfinite_cases():
+    """wav(x, out=buf) with NaN / inf sitting in `buf`: the reference zeroes with `out *= 0` (waveform.py:551),
+    which keeps them.  name -> (build(ns), x, buf)"""
+    x = np.linspace(-10, 10, 2001)
+    real = np.linspace(3, 4, 2001)
+    real[[3, 700, 1999]] = [np.nan, np.inf, -np.inf]
+    longer = np.concatenate([real, [1.0, np.nan, 2.0, -np.inf]])           # len(out) > len(x)
+    cplx = (np.linspace(0, 1, 2001) + 1j * np.linspace(1, 2, 2001))
+    cplx[5] = np.nan
+    cplx[900] = complex(np.inf, 1.0)
+    cplx[1500] = complex(2.0, -np.inf)
+    return {
+        'real': (lambda ns: ns.gaussian(6) * ns.cos(3) + 0.25, x, real),
+        'longer': (lambda ns: ns.gaussian(6) * ns.cos(3) + 0.25, x, longer),
+        'cplx': (lambda ns: (1 + 2j) * ns.gaussian(6) * ns.cos(3), x, cplx),
+        'finite': (lambda ns: ns.gaussian(6) * ns.cos(3) + 0.25, x, np.linspace(3, 4, 2001)),
+    }
+
 
 def n4_logic_names():
     """plain-Waveform cases of CASES that tests/golden/logic.json holds marker / mask / | / & lists for"""

@@ -207,3 +207,33 @@ def test_parsed_tree_through_sample_and_chunks():
     close(full, N4['cli.cli_awg'])
     chunks = np.concatenate(list(w.sample(chunk_size=257)))
     assert chunks.shape == full.shape and np.max(np.abs(chunks - full)) <= 1e-12
+
+
+@pytest.mark.parametrize('name', sorted(cases.out_nonfinite_cases()))
+def test_out_buffer_holding_non_finite_values(name):
+    """`wav(x, out=buf)`: the reference zeroes buf with `out *= 0` (waveform.py:551), which keeps NaN / inf;
+    the result must be the reference's, element by element (NaN positions included)."""
+    build, x, buf = cases.out_nonfinite_cases()[name]
+    want = N4[f'outbuf.{name}']
+    buf = buf.copy()
+    with np.errstate(invalid='ignore'):
+        r = build(wf)(x, out=buf)
+    assert r is buf and buf.dtype == want.dtype
+    assert np.array_equal(np.isnan(buf.real), np.isnan(want.real)) and np.array_equal(np.isnan(buf.imag), np.isnan(want.imag))
+    ok = np.isfinite(want)
+    assert np.max(np.abs(buf[ok] - want[ok])) <= 1e-12
+
+
+def test_all_finite_scan():
+    for n in (0, 1, 63, 4097, 3_000_001):
+        a = np.random.default_rng(n).normal(size=n)
+        assert _engine.all_finite(a)
+        for bad in (np.nan, np.inf, -np.inf):
+            for pos in {0, n // 2, n - 1} if n else ():
+                b = a.copy()
+                b[pos] = bad
+                assert not _engine.all_finite(b)
+    c = np.zeros(1000, dtype=np.complex128)
+    assert _engine.all_finite(c)
+    c[999] = complex(0.0, np.nan)
+    assert not _engine.all_finite(c)

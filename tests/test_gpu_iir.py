@@ -267,6 +267,28 @@ def test_long_cascades_split_into_passes():
     assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize('i', range(len(cases.predistort_high_cases())))
+def test_predistort_order_17_to_20_against_the_reference(i):
+    """The product runs a combined order > 16 as the cascade of the caller's sections (DESIGN: deviations);
+    where the reference's direct-form lfilter is still accurate (poles 0.01..0.6) the two agree: the
+    deviation is bounded by 1e-9 against reference-generated vectors (iir.npz pdh*), real and complex
+    `initial` included.  A plain ndarray as `zi` is refused on this path (it would be misread)."""
+    n, params, initial = cases.predistort_high_cases()[i]
+    sig = cases.predistort_high_input(i)
+    filters = [distortion.exp_decay_filter(A, tau, 1e9) for A, tau in params]
+    want = IIR[f'pdh{i}.out']
+    got, zf = distortion.predistort(sig, filters, initial=initial, return_zf=True)
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, np.abs(want).max())
+    assert isinstance(zf, distortion.CascadeState) and zf.shape == (len(params), )
+    with pytest.raises(ValueError, match='CascadeState'):
+        distortion.predistort(sig, filters, zi=np.asarray(zf))
+    # two pieces == the whole, through the state type
+    y1, z1 = distortion.predistort(sig[:1234], filters, initial=initial, return_zf=True)
+    y2 = distortion.predistort(sig[1234:], filters, zi=z1)
+    assert np.max(np.abs(np.concatenate([y1, y2]) - want)) <= 1e-9 * max(1.0, np.abs(want).max())
+
+
 def test_predistort_combined_order_above_16():
     # 20 first-order exp-decay sections: the reference multiplies them into one order-20
     # polynomial pair and calls lfilter; zero initial state -> the cascade is the same system

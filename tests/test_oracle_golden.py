@@ -191,3 +191,19 @@ def test_predistort_oracle_on_complex_inputs(i):
     assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.abs(want).max())
     if filters is not None:
         assert np.max(np.abs(zf - gold[f'pdc{i}.zf'])) <= 1e-12
+
+
+@pytest.mark.parametrize('i', range(len(cases.predistort_high_cases())))
+def test_predistort_oracle_combined_order_17_to_20(i):
+    """combined order > 16 where the reference's direct form is still accurate (iir.npz, pdh*): the oracle's
+    restatement (product polynomials -> one lfilter, as distortion.py:298-321) against the reference's own output"""
+    import golden_io
+    from waveforms_amd import distortion
+    gold = golden_io.npz('iir.npz')
+    n, params, initial = cases.predistort_high_cases()[i]
+    sig = cases.predistort_high_input(i)
+    filters = [distortion.exp_decay_filter(A, tau, 1e9) for A, tau in params]
+    got, _ = np_oracle.predistort(sig, filters, None, initial)
+    want = gold[f'pdh{i}.out']
+    assert got.dtype == want.dtype
+    assert np.max(np.abs(got - want)) <= 1e-10 * max(1.0, np.abs(want).max())

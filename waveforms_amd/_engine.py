@@ -99,6 +99,7 @@ def lib():
         l.wfk_spectral_plan_destroy.argtypes = [VP]
         l.wfk_host_alloc.argtypes = [P(VP), C.c_size_t]
         l.wfk_host_free.argtypes = [VP]
+        l.wfk_host_all_finite.argtypes = [VP, I64]
         l.wfk_malloc.argtypes = [P(VP), C.c_size_t]
         l.wfk_free.argtypes = [VP]
         l.wfk_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
@@ -211,6 +212,12 @@ class Plan:
 
 
 PINNED_MIN_BYTES = 4 << 20
+
+
+def all_finite(a: np.ndarray) -> bool:
+    """no NaN / inf in a C-contiguous float64 / complex128 array (threaded scan inside the library)"""
+    n = a.size * (2 if a.dtype == np.complex128 else 1)
+    return bool(lib().wfk_host_all_finite(a.ctypes.data, n))
 
 
 def pinned_empty(shape, dtype) -> np.ndarray:

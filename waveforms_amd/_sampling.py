@@ -53,10 +53,11 @@ def _finish(w, plan, frag, out, accumulate):
     live = _live_pieces(plan, 0, w.seq)
     dtype = np.complex128 if (_result_dtype(live) is np.complex128 or plan.prog.host_complex) else np.float64
     if not frag and out is not None and not accumulate and isinstance(out, np.ndarray) and out.ndim == 1 \
-            and out.dtype == dtype and out.flags.c_contiguous and out.flags.writeable and len(out) >= plan.n:
+            and out.dtype == dtype and out.flags.c_contiguous and out.flags.writeable and len(out) >= plan.n \
+            and _engine.all_finite(out):
         # `out *= 0; out[:n] += res` of the reference (waveform.py:548-563) without a temporary and without two
-        # more passes over 80 MB: the samples are copied straight into the caller's array.  (One difference:
-        # a NaN / inf already sitting in `out` is overwritten, where `out *= 0` would have kept it.)
+        # more passes over 80 MB: the samples are copied straight into the caller's array.  (`out *= 0` keeps a
+        # NaN / inf that sits in `out`: an array holding one takes the reference's own two passes below.)
         plan.run_host_into(out[:plan.n])
         if len(out) > plan.n:
             out[plan.n:] *= 0

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -635,6 +636,30 @@ int wfk_plan_run_host(wfk_plan* p, void* out_host, int64_t ch_stride, int out_ki
                         (size_t)p->h.n * es, (size_t)p->h.n_channels, hipMemcpyDeviceToHost));
   }
   return WFK_OK;
+}
+
+int wfk_host_all_finite(const double* host, int64_t n) {
+  if (!host || n <= 0) return 1;
+  // finite <=> exponent field != all ones; OR-reduce "exponent is all ones" over slices on a few threads
+  auto scan = [host](int64_t a, int64_t b) -> bool {
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(host);
+    for (int64_t i = a; i < b;) {
+      const int64_t e = std::min(b, i + 4096);
+      uint64_t bad = 0;
+      for (; i < e; ++i) bad |= (uint64_t)(((p[i] >> 52) & 0x7ff) == 0x7ff);
+      if (bad) return false;
+    }
+    return true;
+  };
+  const int nt = n < (int64_t(1) << 20) ? 1 : (int)std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt == 1) return scan(0, n) ? 1 : 0;
+  std::vector<std::thread> th;
+  std::vector<char> ok((size_t)nt, 1);
+  for (int k = 0; k < nt; ++k)
+    th.emplace_back([&, k] { ok[(size_t)k] = scan(n * k / nt, n * (k + 1) / nt) ? 1 : 0; });
+  for (auto& t : th) t.join();
+  for (char c : ok) if (!c) return 0;
+  return 1;
 }
 
 int wfk_malloc(void** dev_ptr, size_t bytes) {

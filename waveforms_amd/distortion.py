@@ -246,9 +246,29 @@ def iir_host(sig, sections, zi=None, initial=0.0, ker=None):
     return out.reshape(np.shape(sig)), (zf[0] if np.ndim(sig) == 1 else zf)
 
 
+class CascadeState(np.ndarray):
+    """The `zf` that `predistort(..., return_zf=True)` hands out for a combined filter order > 16: the
+    direct-form-II-transposed states of the caller's sections back to back (NOT scipy.signal.lfilter's state
+    of the combined polynomials, which has the same length).  Only such an array is accepted back as `zi`
+    on that path, so an lfilter-format state cannot be misread silently."""
+
+
 def predistort(sig, filters=None, ker=None, initial=0.0, initial_x=None,
                initial_y=None, zi=None, return_zf=False):
-    """reference: waveforms/distortion.py:289-337, both branches on the GPU."""
+    """reference: waveforms/distortion.py:289-337, both branches on the GPU.
+
+    Combined filter order <= 16 (every exp-decay correction with up to 16 time constants): the reference's
+    semantics to the letter -- `zi` / the returned `zf` are scipy.signal.lfilter's state of the combined
+    (b, a), `initial` / `initial_x` / `initial_y` seed it through lfiltic.
+
+    Combined order > 16: a direct form of that order is not usable in double precision (the reference's own
+    lfilter returns 1e125 / NaN once poles crowd z = 1), so the caller's sections run as a cascade:
+      * `initial=c` starts every section in its steady state for the level that reaches it (c times the DC
+        gains before it).  For sections of unit DC gain -- every exp_decay_filter -- this IS the reference's
+        `initial_x = initial_y = c`; tests/golden/iir.npz holds reference runs of order 17 and 20 where its
+        direct form is still accurate, and the cascade agrees with them to 1e-9.
+      * `return_zf` hands out a `CascadeState`; `zi` must be one (ValueError otherwise).
+      * `initial_x` / `initial_y` histories cannot be expressed: ValueError."""
     sig = np.asarray(sig)
     zf = None
     if filters is not None:
@@ -261,7 +281,11 @@ def predistort(sig, filters=None, ker=None, initial=0.0, initial_x=None,
             if initial_x is not None or initial_y is not None:
                 raise ValueError('predistort: a combined filter of order > 16 has no usable direct form in double '
                                  'precision; initial_x / initial_y histories cannot be honoured -- use initial=')
-            return _predistort_high_order(sig, filters, zi, ker, return_zf, float(initial) if zi is None else None)
+            if zi is not None and not isinstance(zi, CascadeState):
+                raise ValueError('predistort: for a combined filter order > 16 `zi` must be the CascadeState that '
+                                 'return_zf=True handed out (the sections\' states back to back); an lfilter-format '
+                                 'state of the combined polynomials has the same length but another meaning')
+            return _predistort_high_order(sig, filters, zi, ker, return_zf, complex(initial) if zi is None else None)
         if zi is None:
             ix = (np.full((len(b) - 1, ), initial) if initial_x is None else
                   np.asarray(initial_x)[:len(b) - 1])
@@ -295,8 +319,10 @@ def _predistort_high_order(sig, filters, zi, ker, return_zf, steady):
     zsec = None
     if steady is not None:
         if steady != 0:
+            # (a complex level -- scipy takes a complex `initial` -- seeds real and imaginary parts alike:
+            #  the sections are real and lfiltic is linear in its histories)
             from scipy.signal import lfiltic
-            level, parts = float(steady), []
+            level, parts = (steady if steady.imag != 0 else steady.real), []
             for (b_, a_), m in zip(secs, orders):
                 gain = b_.sum() / a_.sum()
                 z = lfiltic(b_, a_, np.full(len(a_) - 1, level * gain), np.full(len(b_) - 1, level))
@@ -304,11 +330,11 @@ def _predistort_high_order(sig, filters, zi, ker, return_zf, steady):
                 level *= gain
             zsec = np.concatenate(parts)
     elif zi is not None:
-        zsec = np.asarray(zi, dtype=np.float64).reshape(-1)
+        zsec = np.asarray(zi).reshape(-1)
         if len(zsec) != sum(orders):
             raise ValueError(f'predistort: zi must hold the {sum(orders)} cascade state values')
     out, zf = iir_host(sig, secs, zi=zsec, ker=ker)
-    return (out, zf) if return_zf else out
+    return (out, np.asarray(zf).view(CascadeState)) if return_zf else out
 
 
 def distort(points, params, sample_rate, initial=0.0):
