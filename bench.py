@@ -202,15 +202,29 @@ def workload(name, channels, points):
             f'mixing(gaussian(20 ns), DRAGScaling) pulses ' + ('100 ns apart (30 % duty)' if d30 else 'back to back') +
             f', 60 samples per pulse; {channels // TILE[name]} distinct channels x {TILE[name]} copies, every row with '
             f'its own device tables')
+    if name == 'multitone':
+        return (lambda c: wl.multitone_channel(wf, c)), wl.c2_grid(points), np.float64, (
+            f'{channels} rows/GPU ({channels // TILE[name]} distinct x {TILE[name]}) x {points:.0e} pts, 100 gaussian pulses per row, 10 tones under every pulse')
+    if name.startswith('direct_'):
+        shape = name[len('direct_'):]
+        return (lambda c: wl.direct_channel(wf, shape, c)), ('linspace', 0.0, wl.DIRECT_T, points, False), np.float64, (
+            f'{channels} rows/GPU ({channels // TILE[name]} distinct x {TILE[name]}) x {points:.0e} pts over 3 us: {shape} pulses (direct tier)')
+    if name == 'tlist':
+        # (the time axis itself is made in run_rank: an explicit array, not a grid descriptor)
+        return (lambda c: wl.sum_channel(wf, 100, 1000 + c)), ('tlist', points), np.float64, (
+            f'{channels} ch/GPU x {points:.0e} explicit non-uniform times (C2 grid jittered by 0.3 dt, sorted), 100 gaussian+DRAG '
+            f'pulses/ch: Waveform.__call__(x) on a non-grid x; 16 B/sample (t is read)')
     raise SystemExit(f'unknown workload {name}')
 
 
-TILE = {'awg': 128, 'awg_duty30': 128, 'awg_c4': 128}     # rows = TILE copies of rows / TILE distinct channels
+TILE = {'awg': 128, 'awg_duty30': 128, 'awg_c4': 128, 'multitone': 8, 'direct_sinc': 8, 'direct_mollifier': 8, 'direct_interp': 8}     # rows = TILE copies of rows / TILE distinct channels
 
 
 def default_shape(name):
-    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512, 'awg': 2048, 'awg_duty30': 2048, 'awg_c4': 2048}.get(name, 256)
-    points = {'c3': 10**6, 'far': 2 * 10**6, 'far_sparse': 2 * 10**6, 'awg': 10**5, 'awg_duty30': 10**5, 'awg_c4': 10**5}.get(name, 10**7)
+    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512, 'awg': 2048, 'awg_duty30': 2048, 'awg_c4': 2048, 'tlist': 64,
+                'multitone': 64, 'direct_sinc': 64, 'direct_mollifier': 64, 'direct_interp': 64}.get(name, 256)
+    points = {'c3': 10**6, 'far': 2 * 10**6, 'far_sparse': 2 * 10**6, 'awg': 10**5, 'awg_duty30': 10**5, 'awg_c4': 10**5,
+              'tlist': 2 * 10**6}.get(name, 10**7)
     return channels, points
 
 
@@ -223,6 +237,11 @@ def _c_oracle_worker(job):
     prog = _flatten.flatten([wl.sum_channel(wf, 100, seed)])
     y = c_oracle.eval_grid(prog, _flatten.grid_from_desc(grid_desc))
     return float(y.sum())
+
+
+def wf_mod():
+    import waveforms_amd
+    return waveforms_amd
 
 
 def host_cpu_share():
@@ -410,6 +429,25 @@ def run_plan_only(args, rank, world):
     return 0
 
 
+class TlistBlock:
+    """The rank-local channel block of a time-list job: the same interface as _dist.ShardedSampler /
+    BatchSampler for the pieces run_rank uses (n, n_channels, plan, launch_torch)."""
+
+    def __init__(self, n_channels, make_channel, t, rank, world):
+        from waveforms_amd import _engine, _flatten
+        from waveforms_amd._dist import channel_block
+        self.start, self.stop = channel_block(n_channels, rank, world)
+        self.plan = _engine.Plan(_flatten.flatten([make_channel(c) for c in range(self.start, self.stop)]), t=t)
+        self.n, self.n_channels, self.local = self.plan.n, self.plan.n_channels, self
+
+    def launch_torch(self, out, accumulate=False):
+        import torch
+        from waveforms_amd import _engine
+        self.plan.launch(out.data_ptr(), out.stride(0), _engine.OUT_F64 if out.dtype == torch.float64 else _engine.OUT_F32,
+                         accumulate, torch.cuda.current_stream(out.device).cuda_stream)
+        return out
+
+
 # ---------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------
@@ -452,7 +490,10 @@ def run_rank(args):
     tile = TILE.get(name, 1)
     if channels % tile:
         raise SystemExit(f'--channels must be a multiple of {tile} for workload {name}')
-    sh = ShardedSampler(channels * world, make_channel, grid, rank, world, tile=tile)
+    if name == 'tlist':
+        sh = TlistBlock(channels * world, make_channel, wl.jittered_times(points), rank, world)
+    else:
+        sh = ShardedSampler(channels * world, make_channel, grid, rank, world, tile=tile)
     bs = sh.local
     chans = [make_channel(c) for c in range(min(channels // tile, 32))] if rank == 0 else []
     tdt = torch.float64 if dtype == np.float64 else torch.float32
@@ -527,7 +568,7 @@ def run_rank(args):
 
     samples_per_step = bs.n_channels * bs.n * world
     elem = np.dtype(dtype).itemsize
-    algo_bytes = bs.n_channels * bs.n * elem            # per launch, per GPU
+    algo_bytes = bs.n_channels * bs.n * (elem + (8 if name == 'tlist' else 0))   # per launch, per GPU (a time list is read: + 8 B/sample)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     traffic, traffic_src = profile_traffic(name, algo_bytes)
 
@@ -721,6 +762,49 @@ def run_rank(args):
                 del o4
             del o2
             b2.close()
+        # ---- tiers beside the BASELINE configs: explicit non-uniform sample times (the tlist tier: what any `x`
+        # that is not np.linspace / np.arange output takes; 16 B/sample, t is read), primitives without a
+        # recurrence form (direct tier) and 10-tone multiplexed pulses; kernel time by HIP events
+        from waveforms_amd import _flatten
+        stream = torch.cuda.current_stream().cuda_stream
+        tt = wl.jittered_times()
+        tch = [wl.sum_channel(wf_mod(), 100, 1000 + c) for c in range(64)]
+        tplan = _engine.Plan(_flatten.flatten(tch), t=tt)
+        o2 = torch.empty((64, len(tt)), device='cuda', dtype=torch.float64)
+        ms = timed(lambda: tplan.launch(o2.data_ptr(), len(tt), _engine.OUT_F64, stream=stream), 20, 3)
+        nb = 64 * len(tt) * 16
+        also['tlist'] = {'workload': '64 ch x 2e6 explicit non-uniform times (the C2 grid jittered by 0.3 dt, sorted), headline channels '
+                                     '(100 gaussian+DRAG pulses): Waveform.__call__(x) on a non-grid x',
+                         'kernel': tplan.kernel_name(), 'kernel_ms': ms, 'msamples_per_s': 64 * len(tt) / (ms * 1e-3) / 1e6,
+                         'algorithmic_bytes_per_launch': nb, 'bytes_per_sample': 16,
+                         'frac': nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'dtype': 'f64',
+                         'fused_ops': int(tplan.info.n_fused), 'generic_terms': int(tplan.info.n_generic)}
+        tplan.close()
+        del o2
+        direct = {}
+        for shape in ('sinc', 'mollifier', 'interp'):
+            b2 = BatchSampler([wl.direct_channel(wf_mod(), shape, c) for c in range(8)], ('linspace', 0.0, wl.DIRECT_T, 10**7, False), tile=8)
+            o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)
+            ms = timed(lambda: b2.launch_torch(o2), 5, 2)
+            nb = b2.n_channels * b2.n * 8
+            direct[shape] = {'kernel': b2.plan.kernel_name(), 'kernel_ms': ms, 'msamples_per_s': b2.n_channels * b2.n / (ms * 1e-3) / 1e6,
+                             'algorithmic_bytes_per_launch': nb, 'frac': nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'fused_ops': int(b2.plan.info.n_fused), 'generic_terms': int(b2.plan.info.n_generic)}
+            b2.close()
+            del o2
+        direct['workload'] = ('64 rows (8 distinct x 8) x 1e7 pts over 3 us: 25 overlapping sinc pulses / 100 mollifier pulses / '
+                              '100 samplingPoints envelopes of 1000 knots under carriers')
+        also['direct'] = direct
+        b2 = BatchSampler([wl.multitone_channel(wf_mod(), c) for c in range(8)], wl.c2_grid(), tile=8)
+        o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)
+        ms = timed(lambda: b2.launch_torch(o2), 10, 3)
+        nb = b2.n_channels * b2.n * 8
+        also['multitone'] = {'workload': '64 rows (8 distinct x 8) x 1e7 pts, 100 gaussian pulses per row, 10 tones under every pulse',
+                             'kernel': b2.plan.kernel_name(), 'kernel_ms': ms, 'msamples_per_s': b2.n_channels * b2.n / (ms * 1e-3) / 1e6,
+                             'algorithmic_bytes_per_launch': nb, 'frac': nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'dtype': 'f64',
+                             'fused_ops': int(b2.plan.info.n_fused), 'generic_terms': int(b2.plan.info.n_generic)}
+        b2.close()
+        del o2
         line['also'] = also
     if rank == 0 and not args.no_cpu_baseline and name in (
             'sampler256', 'c4', 'c5', 'c2', 'far', 'far_sparse', 'awg', 'awg_duty30'):

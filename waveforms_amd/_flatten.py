@@ -198,8 +198,14 @@ def flatten(channels, axis=None, function_lib=None) -> Program:
         native = {tid for tid, fn in lib.items()
                   if isinstance(fn, BuiltinPrimitive) and fn.type_id == tid}
         for bounds, seq in members:
-            if len(bounds) != len(seq) or not bounds or bounds[-1] != math.inf:
-                raise ValueError('bounds/seq mismatch or last bound is not +inf')
+            if len(bounds) != len(seq):
+                raise ValueError('bounds/seq mismatch')
+            if not bounds or bounds[-1] != math.inf:
+                # The reference's calc_parts (_waveform.pyx:155-169) walks whatever bounds it is given and leaves
+                # the samples behind the last one untouched (zero): trees whose last bound is finite, or that
+                # have no piece at all -- `mask()` of a waveform that never returns to zero builds such ones,
+                # waveform.py:456-482 -- evaluate to 0 there.  Same thing, said explicitly: a zero piece to +inf.
+                bounds, seq = tuple(bounds) + (math.inf, ), tuple(seq) + (_ir.ZERO, )
             xs = edges = None
             for ip, (b, (terms, amps)) in enumerate(zip(bounds, seq)):
                 pc_bound.append(float(b))

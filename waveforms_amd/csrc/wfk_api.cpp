@@ -333,11 +333,16 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   if (!h.tlist && h.lean) {
     name = lean_name;
   } else {
-    const bool direct = h.tlist || h.n_direct > 0, generic = direct || h.n_generic > 0;
+    // (a time-list plan whose every term fused runs the pointwise-ops-only build; any generic term brings
+    //  the build with the direct tier, as before)
+    const bool tl_full = h.tlist && (h.n_direct > 0 || h.n_generic > 0);
+    const bool direct = tl_full || (!h.tlist && h.n_direct > 0), generic = direct || (!h.tlist && h.n_generic > 0);
     name = std::string("wfk_sample<") + T + "," + cplx + "," + (h.tlist ? "true" : "false") + "," +
            (generic ? "true" : "false") + "," + (direct ? "true" : "false") + "," +
            std::to_string(h.ns) + ">";
-    if (h.mixed) name = lean_name + " + " + name;   // two launches over disjoint pieces
+    if (h.mixed && h.tlist)
+      name = std::string("wfk_sample<") + T + "," + cplx + ",true,false,false," + std::to_string(h.ns) + "> + " + name;
+    else if (h.mixed) name = lean_name + " + " + name;   // two launches over disjoint pieces
   }
   return name.c_str();
 }
@@ -422,6 +427,13 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
   int rc = WFK_OK;
   if (p->h.shortp) {
     a.mixed = 1;      // the short launch above wrote its pieces and the zero stretches; now the rest
+  } else if (p->h.mixed && p->h.tlist) {
+    // time list: the fully fused and the zero pieces on the pointwise-ops build (same chunking) ...
+    KArgs l = a;
+    l.mixed = 1;
+    rc = wfk_launch_sampler(l, p->h.n_channels, out_kind, true, p->h.ns, false, false, false, hip_stream, err);
+    if (rc) return fail(rc, err);
+    a.mixed = 1;   // ... then the pieces with generic terms on the build with the direct tier
   } else if (p->h.mixed) {
     // lean and zero pieces first (own chunking: one wave per workgroup) ...
     KArgs l = a;
@@ -446,8 +458,8 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
     if (a.n_chunks == 0) return WFK_OK;
   }
   rc = wfk_launch_sampler(a, p->h.n_channels, out_kind, p->h.tlist, p->h.ns, p->h.lean,
-                          p->h.n_generic > 0,
-                          p->h.n_direct > 0,
+                          p->h.n_generic > 0 || (p->h.tlist && p->h.n_direct > 0),   // (time lists: either generic + direct or neither)
+                          p->h.n_direct > 0 || (p->h.tlist && p->h.n_generic > 0),
                           hip_stream, err);
   return rc ? fail(rc, err) : WFK_OK;
 }

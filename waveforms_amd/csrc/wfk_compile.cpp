@@ -105,6 +105,7 @@ struct FceGroup {
   double tref = 0;              // chirp: reference time inside the piece (the device works in t' - tref)
   bool corr = false;            // carrier needs the per-sample rounding correction (WFK_FCE_PACK bit 7)
   double wm = 0, sm = 0;        // corr: the reference COS factor (w, shift) whose rounded phase fl(w*fl(x-shift)) is mimicked
+  double tl_thmax = INFINITY;   // time-list plans: largest |W (t' - s_ref)| over the piece (cheap phase reduction below 1.6e6)
 };
 
 struct BlockBuilder {
@@ -341,7 +342,14 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // WFK_JITTER_TOL the factor keeps the exact per-sample time (device libm) instead.
   constexpr double WFK_JITTER_TOL = 2.5e-10;
   auto grid_jitter = [&](int64_t s0, int64_t s1) -> double {
-    if (!grid || s1 <= s0) return 0.0;
+    if (s1 <= s0) return 0.0;
+    if (!grid) {
+      // time list: every sample is evaluated AT its own time; what separates a fused group from the
+      // reference there is the rounding of the reference's own phase fl(w fl(t' - shift)) and of the group's
+      // W (t' - s_ref): about an ulp of the phase, i.e. of |t'| times the rate
+      const double m = std::max(std::fabs(ax.at(s0)), std::fabs(ax.at(s1 - 1)));
+      return 2.4e-16 * m;
+    }
     const double m = std::max(std::fabs(ax.at(s0)), std::fabs(ax.at(s1 - 1)));
     return 1.2e-16 * (m + std::fabs((double)(s1 - 1) * grid->step));
   };
@@ -360,11 +368,12 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // after the correction is d^2 / 2.  (fl(x - s_m) is not exact when the carrier is referenced to
   // t = 0, as mixing()'s is: what the subtraction rounds away is recovered with a TwoSum.)
   const char* nocorr_env = std::getenv("WFK_DISABLE_CORR");
-  const bool corr_enabled = allow_corr && !shortm && !(nocorr_env && nocorr_env[0] == '1');
+  const bool corr_enabled = allow_corr && !shortm && !H.tlist && !(nocorr_env && nocorr_env[0] == '1');
   bool piece_corr_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
   const char* nochirp_env = std::getenv("WFK_DISABLE_CHIRP");
   const bool chirp_base = !H.tlist && ns_override == 0 && !shortm && !g_no_chirp && !(nochirp_env && nochirp_env[0] == '1');
   bool piece_chirp_ok = true;  // likewise: the fused chirp op exists in the lean kernel only
+  bool piece_fuse_ok = true;   // time lists: cleared for the second attempt at a piece that kept a generic term (see below)
   bool chirp_ok = false;
   auto corr_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {
     const double x = std::fabs(rate) * grid_jitter(s0, s1);
@@ -528,12 +537,16 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const char* nolean_env = std::getenv("WFK_DISABLE_LEAN");
   const bool nolean = nolean_env && nolean_env[0] == '1';
   const char* nofuse_env = std::getenv("WFK_DISABLE_FUSE");
-  const bool can_fuse = !H.tlist && !nofast && !(nofuse_env && nofuse_env[0] == '1');
+  // (time-list plans fuse too: their ops are evaluated pointwise -- one sincos + one exp per group and
+  //  sample instead of a libm call per factor; WFK_DISABLE_TLFUSE=1: every factor on device libm, as before)
+  const char* notlfuse_env = std::getenv("WFK_DISABLE_TLFUSE");
+  const bool can_fuse = (!H.tlist || !(notlfuse_env && notlfuse_env[0] == '1')) && !nofast &&
+                        !(nofuse_env && nofuse_env[0] == '1');
 
   const char* noexp_env = std::getenv("WFK_DISABLE_EXPFUSE");
   const bool expfuse = !(noexp_env && noexp_env[0] == '1');
   const char* noerf_env = std::getenv("WFK_DISABLE_ERFMUL");
-  const bool erfmod_base = can_fuse && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
+  const bool erfmod_base = can_fuse && !H.tlist && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
 
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
                        int64_t s1, int32_t skip = -1) -> bool {   // skip: a factor handled by the caller
@@ -926,6 +939,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
     }
     rec[WFK_FCE_D] = dstride;
+    if (H.tlist) {
+      double lim = 1.6e6;       // (tests: WFK_TLSMALL_LIMIT=0 sends every carrier through the two-term 1/pi reduction)
+      if (const char* e = std::getenv("WFK_TLSMALL_LIMIT")) lim = std::atof(e);
+      if (G.tl_thmax <= lim) rec[WFK_FCE_DEG] += (double)WFK_FCE_TLSMALL;
+    }
     if (G.chirp) {
       // phase about tref:  K tau^2 + W' tau + phi0,  tau = t' - tref;  the per-stride rotation advances by
       // the constant phasor exp(i 2 K D^2)
@@ -955,7 +973,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     size_t at = B.body.size();
     B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
     B.fce_ats.push_back(at);
-    if (G.W != 0.0 && !G.chirp) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
+    if (G.W != 0.0 && !G.chirp && !H.tlist) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
   };
 
   // ---- short tier: compact op records (WFK_SH_*), referenced to the first sample of each stretch ----
@@ -1151,12 +1169,25 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         for (int32_t k : order) {
           if (P->tm_amp_im[k] != 0.0) H.channel_complex[c] = 1;
           double esg = 0, esh = 0;
-          const int32_t fe = can_fuse ? erf_factor_of(k, esg, esh) : -1;
+          const bool fuse_now = can_fuse && piece_fuse_ok;
+          const int32_t fe = fuse_now ? erf_factor_of(k, esg, esh) : -1;
           if (fe >= 0 && fuse_term(mgroups, k, C.tshift, s0, s1, fe)) {
             mod_on = true; mod_sigma = esg; mod_shift = esh;
             ++H.n_fused;
-          } else if (can_fuse && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
+          } else if (fuse_now && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
           else generic.push_back(k);
+        }
+        if (H.tlist && !generic.empty() && !groups.empty() && attempt == 0) {
+          // Time lists evaluate fused ops pointwise in a build of the general kernel that holds nothing else
+          // (with every libm shape of the direct tier next to them the kernel spills: measured 1.2 -> 2.3 ms on
+          // flat-top pulses).  A piece is therefore either fused completely or not at all; a plan with both
+          // kinds runs as two launches over disjoint pieces (H.mixed).
+          H.params.resize(snap.params); H.pool.resize(snap.pool);
+          H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
+          sampled_at = snap.sampled;
+          D = D0;
+          piece_fuse_ok = false;
+          continue;
         }
         if (mod_on) {
           // out = S0 + erf S1.  Where every group of S1 has a twin in S0 with the same coefficients
@@ -1259,6 +1290,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         int32_t piece_units = 0;
         for (FceGroup& G : groups) {
           if (room_for(WFK_FCE_REC + 2 * (NS + 1)) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
+          if (H.tlist) {
+            const double ta = ax.at(s0) - C.tshift, tb = ax.at(s1 - 1) - C.tshift;
+            G.tl_thmax = std::fabs(G.W) * std::max(std::fabs(ta - G.sref), std::fabs(tb - G.sref)) + 4.0;
+          }
           emit_group(B, G);
           ++B.n_terms;
           piece_units = B.state_units;
@@ -1295,7 +1330,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           piece_chirp_ok = false;
           continue;
         }
-        if (piece_lean && !shortm) {
+        if (H.tlist) {
+          // time lists: "lean" = the piece consists of fused ops only (any number of blocks): pointwise build
+          if (generic.empty() && !groups.empty()) { D.flags |= WFK_PF_LEAN; ++n_lean_pieces; }
+          else lean_ok = false;
+        } else if (piece_lean && !shortm) {
           H.lean_fam = std::max(H.lean_fam, piece_fam);   // (a short plan has no lean launch: its other pieces all go to the general kernel)
           D.flags |= WFK_PF_LEAN;
           ++n_lean_pieces;
@@ -1308,6 +1347,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       }
       piece_corr_ok = true;
       piece_chirp_ok = true;
+      piece_fuse_ok = true;
       if (shortm) set_geom(true);
       // fuse adjacent zero pieces
       if (D.n_blk == 0 && (int32_t)H.pieces.size() > C.piece_begin &&
@@ -1323,13 +1363,17 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // ---- workgroup chunking ------------------------------------------------------
   // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
   // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
-  H.lean = lean_ok && !nolean && H.n_fused > 0;
+  H.lean = lean_ok && !nolean && H.n_fused > 0 && !H.tlist;     // (time lists: fused ops run pointwise in the general kernel)
   // mixed plans: some pieces are lean, some are not (the erf edges of a flat-top pulse next to its
   // multi-tone plateau).  Two launches over the same output: the lean kernel takes the lean and the
   // zero pieces, the general kernel the rest -- every sample is still written exactly once.
   const char* nomix_env = std::getenv("WFK_DISABLE_MIXED");
-  H.mixed = !H.lean && can_fuse && !nolean && n_lean_pieces > 0 && ns_override == 0 &&
+  H.mixed = !H.lean && !H.tlist && can_fuse && !nolean && n_lean_pieces > 0 && ns_override == 0 &&
             !(nomix_env && nomix_env[0] == '1');
+  // time lists: fully fused pieces on the pointwise build, the others on the build with the direct tier
+  // (same chunking for both launches); all of one kind: a single launch of that build
+  const bool tl_mixed = H.tlist && n_lean_pieces > 0 && !lean_ok;
+  if (tl_mixed) H.mixed = true;
   H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
   H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
   auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
@@ -1465,8 +1509,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   }
 
   chunking(H.lean, H.tile, H.tiles_per_chunk, H.chunks_per_ch, H.chunk_first);
-  if (H.mixed) chunking(true, H.lean_tile, H.lean_tiles_per_chunk, H.lean_chunks_per_ch, H.lean_chunk_first);
-  if ((H.lean || H.mixed) && ns_override == 0) {
+  if (H.mixed && !H.tlist) chunking(true, H.lean_tile, H.lean_tiles_per_chunk, H.lean_chunks_per_ch, H.lean_chunk_first);
+  if ((H.lean || H.mixed) && ns_override == 0 && !H.tlist) {
     // the lean launch's chunking for float outputs (longer chunks, see HostPlan)
     int32_t tile32 = 0;
     int cap32 = WFK_LEAN_TPC_F32;

@@ -878,6 +878,136 @@ __device__ __forceinline__ void apply_fce(const double* blk, const double* r, co
   fce_eval<T, NS>(blk, r, sd, x, false, acc, fl);
 }
 
+// ---- fused ops evaluated POINTWISE (tlist plans: arbitrary sorted sample times) ------------------
+// The host's fusion pass turns the terms of a piece into groups  E(t') (A(u) cos th + B(u) sin th),
+// th = W (t' - s_ref), u = t' - s_lin, E = 1 | exp(-((t' - s_g)/sigma)^2) | exp(alpha (t' - ref))  -- on a
+// grid those advance by recurrences; on a time LIST every sample is evaluated from its own time, but still
+// as ONE sincos + ONE exp per group instead of one libm call per factor (a DRAG pulse: 1 + 1 against 3 + 3).
+
+// (cos, sin) of a phase |th| <= 1.6e6 (host-checked, WFK_FCE_TLSMALL): pi/2 in three parts, reduced with
+// fma (n P1 is formed exactly inside the fma: one rounding per step, absolute error of r <= 1.2e-16),
+// then the fdlibm kernels on |r| <= pi/4.  ~35 VALU instructions against ~130 of libm's sincos.
+__device__ __forceinline__ void sincos_small(double th, double& c, double& s) {
+  const double n = rint(th * 0.63661977236758138);
+  double r = fma(-n, 1.57079632679489655800e+00, th);
+  r = fma(-n, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)n;
+  const double a = (q & 1) ? sr : cr, b = (q & 1) ? cr : sr;     // |cos|, |sin| of the quadrant
+  c = ((q + 1) & 2) ? -a : a;
+  s = (q & 2) ? -b : b;
+}
+
+// exp(x) inline: x = n ln2 + r, |r| <= 0.347, exp(r) by its Taylor polynomial of degree 13 (next term 4e-18),
+// scaled by v_ldexp_f64 (which also does the gradual underflow).  ~20 VALU instructions, no table, no call;
+// <= 2 ulp against libm's <= 1 (the Gaussian and exponential envelopes of the pointwise ops).
+__device__ __forceinline__ double exp_inline(double x) {
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = fma(r, 1.6059043836821613e-10, 2.08767569878681e-09);      // 1/13!, 1/12!
+  p = fma(r, p, 2.505210838544172e-08);
+  p = fma(r, p, 2.755731922398589e-07);
+  p = fma(r, p, 2.7557319223985893e-06);
+  p = fma(r, p, 2.48015873015873e-05);
+  p = fma(r, p, 1.984126984126984e-04);
+  p = fma(r, p, 1.3888888888888889e-03);
+  p = fma(r, p, 8.333333333333333e-03);
+  p = fma(r, p, 4.1666666666666664e-02);
+  p = fma(r, p, 1.6666666666666666e-01);
+  p = fma(r, p, 0.5);
+  p = fma(r, p, 1.0);
+  p = fma(r, p, 1.0);
+  double e = ldexp(p, (int)n);
+  e = x < -746.0 ? 0.0 : e;                       // (also x = -inf, where r is NaN)
+  e = x > 710.0 ? __builtin_inf() : e;
+  return e;
+}
+
+// value of one group at time x (on the channel's own axis); everything wave-uniform comes in by value
+struct FcePoint {
+  double W, sref, slin, sigma, sg;
+  int deg, env;
+  bool carrier, expenv, small;
+};
+__device__ __forceinline__ double fce_point_value(const double* r, const FcePoint& g, double x) {
+  double A = r[WFK_FCE_A], Bq = r[WFK_FCE_B];
+  if (g.deg > 0) {
+    const double u = x - g.slin;
+    A = r[WFK_FCE_A + g.deg];
+    Bq = r[WFK_FCE_B + g.deg];
+    for (int i = g.deg - 1; i >= 0; --i) {
+      A = fma(A, u, r[WFK_FCE_A + i]);
+      Bq = fma(Bq, u, r[WFK_FCE_B + i]);
+    }
+  }
+  double v = A;
+  if (g.carrier) {
+    const double th = g.W * (x - g.sref);
+    double c, s;
+    if (g.small) sincos_small(th, c, s);
+    else { const double2 cs = sincos_phase(th); c = cs.x; s = cs.y; }      // (out of line: two-term 1/pi reduction)
+    v = fma(Bq, s, A * c);
+  }
+  if (g.env == 1) {
+    const double d = x - g.sg;
+    double q = g.sigma * d;                                                // exp(alpha (t' - ref))
+    if (!g.expenv) { q = d / g.sigma; q = -(q * q); }                      // exp(-((t' - s_g)/sigma)^2), as the reference forms it
+    v *= exp_inline(q);
+  }
+  return v;
+}
+
+// One group over the lane's NS samples (the pointwise-ops-only build of the general kernel; a time-list plan
+// that also holds generic terms runs as two launches: this build takes the fully fused pieces, the build
+// with the direct tier the others).
+template <typename T, int NS, bool CPLX>
+__device__ __forceinline__ void fce_point(const double* r, const double (&x)[NS], T (&acc)[NS],
+                                          T (&acci)[CPLX ? NS : 1]) {
+  const int fl = uni(WFK_FCE_WORD(r));
+  const int deg = fl & 3, env = (fl >> 4) & 3;
+  const bool carrier = (fl & 4) != 0, imag = (fl & 8) != 0;
+  if (imag && !CPLX) return;                       // a real-output launch drops the imaginary groups
+  const double sigma = r[WFK_FCE_SIGMA], sg = r[WFK_FCE_SG];
+  if (env == 3) {
+    // closing op of a piece whose carriers share one Gaussian: multiply what they accumulated by it
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const double v = (x[k] - sg) / sigma;
+      const T e = (T)exp_inline(-(v * v));
+      acc[k] *= e;
+      if constexpr (CPLX) acci[k] *= e;
+    }
+    return;
+  }
+  FcePoint g;
+  g.W = r[WFK_FCE_W]; g.sref = r[WFK_FCE_SREF]; g.slin = r[WFK_FCE_SLIN]; g.sigma = sigma; g.sg = sg;
+  g.deg = deg; g.env = env; g.carrier = carrier; g.expenv = (fl & WFK_FCE_EXPENV) != 0;
+  g.small = (fl & WFK_FCE_TLSMALL) != 0;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const T v = (T)fce_point_value(r, g, x[k]);
+    if constexpr (CPLX) {
+      if (imag) acci[k] += v;
+      else acc[k] += v;
+    } else {
+      acc[k] += v;
+    }
+  }
+}
+
 template <typename T> struct OutOps;
 template <> struct OutOps<double> {
   using Real = double;
@@ -1179,11 +1309,14 @@ wfk_sample_lean(const KArgs a) {
   }
 }
 
+#ifndef WFK_TL_WGS
+#define WFK_TL_WGS 3
+#endif
 template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
 // (the build with direct primitives inlines all of device libm's shapes: left alone it takes 280 VGPRs = ONE
 // workgroup per CU, one wave per SIMD walking serial libm chains; capped at 256 it runs two: direct tier 1.8x.
 // The tlist builds (no fused code, 8 samples per lane) fit three at 168: 4.80 -> 3.45 ms on 64 x 2e6 times.)
-__global__ void __launch_bounds__(WFK_WG, TLIST ? 3 : ((DIRECT || (GENERIC && CPLX)) ? 2 : 1)) wfk_sample(const KArgs a) {
+__global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || (GENERIC && CPLX)) ? 2 : 1)) wfk_sample(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
   __shared__ double s_val[DIRECT ? NS * WFK_WG : 1];   // direct-factor values (apply_factor)
   constexpr int WT = 64 * NS;
@@ -1218,7 +1351,12 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? 3 : ((DIRECT || (GENERIC && CP
       const DevPiece P = load_piece(a.pieces + q);
       if (P.start >= g1) break;
       // (mixed plans: the lean / short and the zero pieces were written by the other kernel's launch)
-      if (a.mixed && (P.n_blk == 0 || (P.flags & (WFK_PF_LEAN | WFK_PF_SHORT)))) continue;
+      if constexpr (TLIST && !GENERIC && !DIRECT) {
+        // (mixed time-list plans: this build takes the fully fused and the zero pieces, the other build the rest)
+        if (a.mixed && P.n_blk != 0 && !(P.flags & WFK_PF_LEAN)) continue;
+      } else {
+        if (a.mixed && (P.n_blk == 0 || (P.flags & (WFK_PF_LEAN | WFK_PF_SHORT)))) continue;
+      }
       const bool active = w0 < a.n && P.start < w0 + WT && P.stop > w0;  // wave-uniform
 
       T acc[NS], acci[CPLX ? NS : 1];
@@ -1227,6 +1365,19 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? 3 : ((DIRECT || (GENERIC && CP
       if (CPLX) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) acci[k] = (T)0;
+      }
+
+      // fused-only tlist plans: the lane's sample times on the channel's own axis, once per piece and tile
+      // (the pointwise fused ops all read them; the build with the direct tier reloads them per op instead)
+      double tx[(TLIST && !GENERIC && !DIRECT) ? NS : 1];
+      if constexpr (TLIST && !GENERIC && !DIRECT) {
+        if (active) {
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            tx[i] = time_at<true>(a, j0 + 64 * (int64_t)i);
+            if (C.tshift != 0.0) tx[i] = tx[i] - C.tshift;
+          }
+        }
       }
 
       int64_t off = P.par_off;
@@ -1243,6 +1394,13 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? 3 : ((DIRECT || (GENERIC && CP
           int pos = WFK_BLK_HDR;
           for (int k = 0; k < nops; ++k) {
             const int kind = uni((int)s_par[pos]);
+            if constexpr (TLIST && !GENERIC && !DIRECT) {
+              if (kind == WFK_OP_FCE) {      // fused group, evaluated from each sample's own time
+                fce_point<T, NS, CPLX>(s_par + pos, tx, acc, acci);
+                pos += WFK_FCE_REC;
+                continue;
+              }
+            }
             if (!TLIST && kind == WFK_OP_FCE) {
               const int fl = uni(WFK_FCE_WORD(s_par + pos));
               if (((fl >> 4) & 3) == 3) {
@@ -1307,7 +1465,9 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
       return hipGetLastError() == hipSuccess ? 0 : -1;
     }
   }
-  if (TLIST || direct)
+  if (TLIST && !generic && !direct)      // every term of the plan fused: pointwise ops only, no libm shapes of the direct tier
+    hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, false, false, NS>), g, b, 0, s, a);
+  else if (TLIST || direct)
     hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, true, true, NS>), g, b, 0, s, a);
   else if (generic)
     hipLaunchKernelGGL((wfk_sample<T, CPLX, false, true, false, NS>), g, b, 0, s, a);
@@ -1336,18 +1496,18 @@ int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tl
     }
   } else if (ns == WFK_NS_TLIST_SMALL) {
     switch (out_kind) {
-      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
-      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
-      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
-      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, generic, direct); break;
+      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, generic, direct); break;
+      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, generic, direct); break;
+      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST_SMALL>(a, blocks, s, false, generic, direct); break;
       default: err = "bad out_kind"; return WFK_EINVAL;
     }
   } else {
     switch (out_kind) {
-      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
-      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
-      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
-      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST>(a, blocks, s, false, true, true); break;
+      case WFK_OUT_F64: rc = launch<double, false, true, WFK_NS_TLIST>(a, blocks, s, false, generic, direct); break;
+      case WFK_OUT_F32: rc = launch<float, false, true, WFK_NS_TLIST>(a, blocks, s, false, generic, direct); break;
+      case WFK_OUT_C128: rc = launch<double, true, true, WFK_NS_TLIST>(a, blocks, s, false, generic, direct); break;
+      case WFK_OUT_C64: rc = launch<float, true, true, WFK_NS_TLIST>(a, blocks, s, false, generic, direct); break;
       default: err = "bad out_kind"; return WFK_EINVAL;
     }
   }

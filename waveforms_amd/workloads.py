@@ -140,3 +140,57 @@ def make_grid(desc):
         _, a, b, step = desc
         return np.arange(a, b, step)
     raise ValueError(kind)
+
+
+# ---- tiers beside the BASELINE configs (bench.py `also.tlist / direct / multitone`) -------------------
+def _tree_sum(ws):
+    while len(ws) > 1:
+        nxt = [ws[i] + ws[i + 1] for i in range(0, len(ws) - 1, 2)]
+        if len(ws) % 2:
+            nxt.append(ws[-1])
+        ws = nxt
+    return ws[0]
+
+
+def jittered_times(n=2 * 10**6, seed=0):
+    """A sorted NON-uniform time axis over the C2 span: the C2 grid of n points with every sample moved by
+    N(0, 0.3 dt) -- what `Waveform.__call__(x)` gets when x is not np.linspace / np.arange output (measured
+    timestamps, a warped axis).  Time-list plans read it from HBM: 16 B/sample algorithmic."""
+    g = make_grid(c2_grid(n))
+    rng = np.random.default_rng(seed)
+    return np.sort(g + rng.normal(size=n) * (g[1] - g[0]) * 0.3)
+
+
+def multitone_channel(ns, c, ntones=10, nseg=100):
+    """Frequency-multiplexed drive: every gaussian(W) pulse carries `ntones` tones (a ntones-qubit bus)."""
+    rng = np.random.default_rng(3000 + c)
+    ws = []
+    for k in range(nseg):
+        tones = None
+        for _ in range(ntones):
+            tone = rng.uniform(0.05, 0.2) * ns.cos(2 * np.pi * rng.uniform(-300e6, 300e6), rng.uniform(0, 6))
+            tones = tone if tones is None else tones + tone
+        ws.append((ns.gaussian(W) >> ((k + 0.5) * SPAN)) * tones)
+    return _tree_sum(ws)
+
+
+DIRECT_T = 3e-6      # time span of the direct-tier shapes (100 pulses of 30 ns)
+
+
+def direct_channel(ns, shape, c=0):
+    """Primitives without a recurrence form, 100 pulses back to back over DIRECT_T:
+    'sinc' (25 overlapping unbounded sinc pulses), 'mollifier', 'interp' (samplingPoints envelopes of
+    1000 knots -- numerically optimised pulse shapes -- under a carrier)."""
+    rng = np.random.default_rng(4000 + c)
+    if shape == 'sinc':
+        return _tree_sum([ns.sinc(4 / W) >> ((k + 0.5) * SPAN * 4) for k in range(25)])
+    if shape == 'mollifier':
+        return _tree_sum([rng.uniform(0.5, 1) * ns.mollifier(W) >> ((k + 0.5) * SPAN) for k in range(100)])
+    if shape == 'interp':
+        ws = []
+        for k in range(100):
+            env = ns.samplingPoints(-SPAN / 2, SPAN / 2, np.hanning(1000) * rng.uniform(0.5, 1))
+            I, _ = ns.mixing(env >> ((k + 0.5) * SPAN), freq=rng.uniform(-200e6, 200e6), phase=rng.uniform(0, 6))
+            ws.append(I)
+        return _tree_sum(ws)
+    raise ValueError(shape)
