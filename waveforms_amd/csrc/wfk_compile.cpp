@@ -419,6 +419,14 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           rec[9] = ok32 ? 1.0 : 0.0;
           fast = true;
         }
+      } else if (type == WFK_SINC && std::isfinite(a[0]) && a[0] != 0.0 && rate_safe(3.141592653589793 * a[0], s0, s1) &&
+                 !std::getenv("WFK_NO_SINC_TAB")) {
+        // sin(pi b u) from the phasor table, the argument pi b u advanced by the very same phase step (so the two
+        // stay consistent where the argument passes through zero), one reciprocal per sample instead of libm's
+        // sin + a division (reference _waveform.pyx:303-305: np.sinc)
+        const double dphase = 3.141592653589793 * a[0] * dstride;
+        rec[0] = WFK_M_SINC_TAB; rec[3] = a[0]; rec[4] = dphase; fast = true;
+        table = table_for(B, dphase);
       } else if (type == WFK_EXP && std::isfinite(a[0]) && rate_safe(a[0], s0, s1)) {
         double ext = std::fabs(a[0]) * (umax + dstride * NS);
         if (ext <= 600.0) {
@@ -428,6 +436,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         }
       }
     }
+    bool interp_lin = false;
     if (!fast) {
       switch (type) {
         case WFK_INTERP: {
@@ -457,8 +466,27 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             H.pool.push_back(0.0);
             // grid mode: same arithmetic, but the knot/slope loads (L2 latency) of four samples
             // are in flight together instead of one dependent load pair per sample
-            if (!H.tlist && !nofast && pw == 1.0 && m < (int64_t(1) << 31) && !std::getenv("WFK_NO_INTERP_GRID"))
+            if (!H.tlist && !nofast && pw == 1.0 && m < (int64_t(1) << 31) && !std::getenv("WFK_NO_INTERP_GRID")) {
               rec[0] = WFK_M_INTERP_GRID;
+              // A finite table is a CONTINUOUS piecewise-linear function: next to a knot the two adjoining
+              // segments agree to rounding, so the knot index may come straight from the O(1) guess, without
+              // the comparisons against the exact knot abscissae that make up most of the exact lookup (an
+              // error of one segment there costs |slope difference| x a few ulp of x).  Admitted while
+              // max |slope| x (rounding of x) stays inside the jitter budget; counted as a fast factor: the plan
+              // then runs the build of the general kernel without the direct tier.
+              double smax = 0.0;
+              bool finite = true;
+              for (int64_t j = 0; j < m && finite; ++j) finite = std::isfinite(fp[j]);
+              for (int64_t j = 0; j + 1 < m && finite; ++j) {
+                const double sl = H.pool[(size_t)rec[7] + (size_t)j];
+                finite = std::isfinite(sl);
+                smax = std::max(smax, std::fabs(sl));
+              }
+              if (finite && s1 > s0 && rate_safe(4.0 * smax, s0, s1) && !std::getenv("WFK_NO_INTERP_LIN")) {
+                rec[0] = WFK_M_INTERP_LIN;
+                interp_lin = true;
+              }
+            }
           }
           break;
         }
@@ -495,7 +523,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         default:
           for (int64_t k = 0; k < na && k < 6; ++k) rec[3 + k] = a[k];
       }
-      ++H.n_direct;
+      if (interp_lin) ++H.n_fast; else ++H.n_direct;
       std::vector<double> sig(rec, rec + WFK_FREC);
       const bool pooled = type == WFK_INTERP || type == WFK_MOLLIFIER || type == WFK_DRAG_SIN ||
                           type == WFK_DRAG_SINX || type == WFK_SAMPLED;             // records point into the pool: never equal

@@ -85,6 +85,10 @@
 #define WFK_M_SAMPLED 20      // caller-evaluated factor (WFK_SAMPLED): a0 = pool offset of the values, a1 = i0, a2 = m
 #define WFK_M_REUSE 1000      // added to a direct factor's type: same record as the previous direct factor of
                               // the block -> its values are still in the LDS value buffer
+#define WFK_M_SINC_TAB 110    // sinc(b u) = sin(pi b u) / (pi b u): sin by the phasor table (as COS_TAB), the argument advanced by the
+                              // SAME per-stride phase, one reciprocal per sample   a0 = b, a1 = pi b D (the table's phase step), aux = table
+#define WFK_M_INTERP_LIN 109  // the same table (finite values) read as a continuous piecewise-linear function: knot index from
+                              // the O(1) guess alone, x clamped to [start, stop]; same record layout as INTERP_GRID
 #define WFK_M_INTERP_GRID 108 // np.interp on linspace knots, exact per-sample times, knot/slope loads
                               // batched 4 samples deep: a0=start a1=stop a2=m a3=pool(fp) a4=pool(slopes) a5=1/step
 

@@ -118,6 +118,21 @@ __device__ __attribute__((noinline)) double2 sincos_phase(double theta) {
 // stay live across the whole sampling loop.
 __device__ __attribute__((noinline)) double exp_seed(double x) { return exp(x); }
 
+// (sin, cos)(pi x): libm's exact reduction, out of line like the other seed functions
+__device__ __attribute__((noinline)) double2 sincospi_seed(double x) {
+  double ss, cc;
+  sincospi(x, &ss, &cc);
+  return make_double2(cc, ss);
+}
+
+// 1 / y to double precision: the hardware estimate + two Newton steps (the IEEE division sequence is 2-3x longer)
+__device__ __forceinline__ double rcp_nr(double y) {
+  double r = __builtin_amdgcn_rcp(y);
+  r = fma(fma(-y, r, 1.0), r, r);
+  r = fma(fma(-y, r, 1.0), r, r);
+  return r;
+}
+
 template <bool TLIST>
 __device__ __forceinline__ double time_at(const KArgs& a, int64_t j) {
   if (TLIST) {
@@ -402,6 +417,48 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
           prod[k] *= e;
           e *= rho;
         }
+      }
+    } else if (mode == WFK_M_SINC_TAB) {
+      // np.sinc(b u) = sin(pi x) / (pi x), x = b u (reference _waveform.pyx:303-305).  Seed: sincospi of the
+      // lane's own x (rounded as the reference rounds it); sample k: the seed rotated by the table entry, the
+      // argument th0 + k dth with the table's own dth -- numerator and denominator then belong to the same
+      // argument to 1e-16 of IT, also where it passes through zero in mid-stride.  Below 1e-3 the quotient
+      // is taken from its series (sin's absolute 1e-16 divided by a tiny argument would show).
+      const double x0 = r[3] * u0;
+      const double2 cs0 = sincospi_seed(x0);
+      const double th0 = 3.141592653589793 * x0, dth = r[4];
+      const double2* tab = reinterpret_cast<const double2*>(blk + uni((int)r[9]));
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const double2 cs = tab[k];  // wave-wide LDS broadcast
+        const double sn = fma(cs0.y, cs.x, cs0.x * cs.y);
+        const double y = fma((double)k, dth, th0);
+        const double y2 = y * y;
+        double v = sn * rcp_nr(y);
+        const double ser = fma(y2, fma(y2, 8.3333333333333332e-03, -1.6666666666666666e-01), 1.0);
+        v = y2 < 1e-6 ? ser : v;
+        prod[k] *= (T)v;
+      }
+    } else if (mode == WFK_M_INTERP_LIN) {
+      // np.interp on linspace knots with a finite table (reference _waveform.pyx:309-311), as a continuous
+      // piecewise-linear function: segment from the O(1) guess, x clamped into [start, stop] (the constant
+      // continuation np.interp applies outside), 2 gathers per sample, all NS samples' loads in flight
+      const double start = r[3], stop = r[4], inv_step = r[8], step = r[9];
+      const int last = (int)r[5] - 2;                // last segment
+      const double* fp = a.pool + (int64_t)r[6];
+      const double* sl = a.pool + (int64_t)r[7];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        double x = grid_time(a, j0 + 64 * (int64_t)k);
+        if (tshift != 0.0) x = x - tshift;
+        x = x - shift;
+        const double xc = fmin(fmax(x, start), stop);
+        int j = (int)((xc - start) * inv_step);
+        j = j > last ? last : j;
+        const double d = xc - fma((double)j, step, start);
+        double v = fma(sl[j], d, fp[j]);
+        v = x != x ? x : v;
+        prod[k] *= (T)v;
       }
     } else if (mode == WFK_M_INTERP_GRID) {
       // np.interp (reference _waveform.pyx:309-311) at the exact per-sample grid times; same
