@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WFK_ABI_VERSION 1
+#define WFK_ABI_VERSION 2   /* 2: wfk_grid.i0 (time slices of a grid) */
 
 /* error codes */
 #define WFK_OK 0
@@ -118,6 +118,11 @@ typedef struct wfk_grid {
   int64_t n;
   int32_t has_last;
   double last;
+  int64_t i0;      /* index of this grid's first sample in the caller's FULL grid: t[i] = fl(fl((i0 + i)*step) + t0).
+                    * 0 for a whole grid; > 0 for a time slice of one (time-axis sharding, chunked sampling):
+                    * the slice's samples and piece indices are then bit-identical to the same samples of the
+                    * whole grid.  has_last refers to the slice's own last sample (set it only where the slice
+                    * ends with the full grid's overridden last sample).                                     */
 } wfk_grid;
 
 enum { WFK_OUT_F64 = 0, WFK_OUT_F32 = 1, WFK_OUT_C128 = 2, WFK_OUT_C64 = 3 };

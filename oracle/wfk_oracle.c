@@ -29,7 +29,7 @@
 /* ---- grid ------------------------------------------------------------- */
 static double grid_t(const wfk_grid* g, int64_t i) {
   if (g->has_last && i == g->n - 1) return g->last;
-  volatile double m = (double)i * g->step; /* two roundings, no FMA */
+  volatile double m = (double)(i + g->i0) * g->step; /* two roundings, no FMA; i0: index of the slice's first sample in the full grid */
   return m + g->t0;
 }
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.wfk_abi_version() == 1
+    assert lib.wfk_abi_version() == 2
 
 
 def _indices(plan, prog):

@@ -50,6 +50,25 @@ def _worker(rank, world, port, q):
         assert full.shape == (nch, 5)
         assert torch.equal(full[:, 0], torch.arange(nch, dtype=torch.float64))
         assert max_over_ranks(1.0 + rank) == float(world)
+        # chunked placement on root's host: slabs of 2 rows per rank (7 rows over 2 ranks: blocks of 4 and 3)
+        from waveforms_amd._dist import gather_rows_to_host
+        host = gather_rows_to_host(rows, nch, root=0, slab_bytes=2 * 5 * 8)
+        if rank == 0:
+            assert host.shape == (nch, 5) and np.array_equal(host[:, 3], np.arange(nch, dtype=np.float64))
+        else:
+            assert host is None
+        # time-slice-per-rank: rank r compiles samples [a_r, b_r) (+ FIR halo) of the SAME grid as a slice
+        # (wfk_grid.i0): piece indices are those of the whole plan, shifted and clipped -- bit for bit
+        from waveforms_amd._dist import fir_halo
+        g = _flatten.grid_from_desc(grid)
+        hl, hr = fir_halo(1024)
+        sa, sb = channel_block(int(g.n), rank, world)
+        lo, hi = max(0, sa - hl), min(int(g.n), sb + hr)
+        sl = _flatten.grid_slice(g, lo, hi)
+        assert np.array_equal(_flatten.grid_values(sl), _flatten.grid_values(g)[lo:hi])
+        part = _engine.Plan(whole, grid=sl)
+        for c in range(nch):
+            assert np.array_equal(part.member_index(c), np.clip(ref.member_index(c) - lo, 0, hi - lo))
         q.put((rank, 'ok'))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
@@ -68,3 +87,30 @@ def test_two_rank_sharding_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_grid_slices_are_the_same_samples():
+    """wfk_grid.i0: a slice of a linspace / arange grid has the whole grid's times bit for bit (the overridden
+    last sample of np.linspace(endpoint=True) included), the library's piece indices and the oracle's samples
+    are those of the whole grid."""
+    import waveforms_amd as wf
+    from oracle import c_oracle
+    from waveforms_amd import _engine, _flatten, workloads as wl
+    w = wl.sum_channel(wf, 9, 3)
+    prog = _flatten.flatten([w])
+    for desc in (('linspace', 0.0, 9 * wl.SPAN, 30011, True), ('linspace', -3e-8, 2.9e-7, 9973, False),
+                 ('arange', 1e-3, 1e-3 + 2.7e-7, 0.25e-9)):
+        g = _flatten.grid_from_desc(desc)
+        t = wl.make_grid(desc)
+        assert np.array_equal(_flatten.grid_values(g), t)
+        whole = c_oracle.eval_grid(prog, g)[0]
+        ref = _engine.Plan(prog, grid=g)
+        n = int(g.n)
+        for lo, hi in ((0, n), (0, n // 3), (n // 3, n // 3 + 1), (n // 3, 2 * n // 3 + 17), (n - 5, n), (7, 7)):
+            sl = _flatten.grid_slice(g, lo, hi)
+            assert np.array_equal(_flatten.grid_values(sl), t[lo:hi]) and np.array_equal(c_oracle.grid_values(sl), t[lo:hi])
+            assert np.array_equal(c_oracle.eval_grid(prog, sl)[0], whole[lo:hi])
+            assert np.array_equal(_engine.Plan(prog, grid=sl).member_index(0), np.clip(ref.member_index(0) - lo, 0, hi - lo))
+            assert np.array_equal(c_oracle.member_index(prog, 0, grid=sl), np.clip(ref.member_index(0) - lo, 0, hi - lo))
+    with pytest.raises(ValueError):
+        _flatten.grid_slice(g, 5, n + 1)

@@ -108,7 +108,7 @@ def lib():
         l.wfk_stream_sync.argtypes = [VP]
         l.wfk_device_count.argtypes = [P(C.c_int)]
         l.wfk_set_device.argtypes = [C.c_int]
-        if l.wfk_abi_version() != 1:
+        if l.wfk_abi_version() != 2:
             raise EngineError('libwfk_hip.so ABI version mismatch')
         _lib = l
     return _lib

@@ -41,7 +41,7 @@ class wfk_program(C.Structure):
 
 class wfk_grid(C.Structure):
     _fields_ = [('t0', C.c_double), ('step', C.c_double), ('n', C.c_int64),
-                ('has_last', C.c_int32), ('last', C.c_double)]
+                ('has_last', C.c_int32), ('last', C.c_double), ('i0', C.c_int64)]
 
 
 class Program:
@@ -122,7 +122,7 @@ def channel_members(w):
 def grid_values(grid: 'wfk_grid') -> np.ndarray:
     """The NumPy array a `wfk_grid` stands for: t[i] = fl(fl(i*step) + t0), last element
     overridden when has_last (the linspace / arange element formulas)."""
-    t = np.arange(int(grid.n), dtype=np.float64) * grid.step + grid.t0
+    t = np.arange(int(grid.i0), int(grid.i0) + int(grid.n), dtype=np.float64) * grid.step + grid.t0
     if grid.has_last and grid.n > 0:
         t[-1] = grid.last
     return t
@@ -385,6 +385,17 @@ def grid_arange(start, stop, step) -> wfk_grid:
     n = max(0, int(math.ceil((stop - start) / step)))
     delta = (start + step) - start
     return wfk_grid(start, delta, n, 0, 0.0)
+
+
+def grid_slice(grid: wfk_grid, a: int, b: int) -> wfk_grid:
+    """Samples [a, b) of `grid` as a grid of their own (wfk_grid.i0): times, piece indices and sample values are
+    those of the same samples of the whole grid -- what a rank of a time-sharded job, or one chunk of a chunked
+    job, samples."""
+    a, b = int(a), int(b)
+    if not 0 <= a <= b <= int(grid.n):
+        raise ValueError('slice outside the grid')
+    last_in = bool(grid.has_last) and b == int(grid.n) and b > a
+    return wfk_grid(grid.t0, grid.step, b - a, 1 if last_in else 0, grid.last if last_in else 0.0, int(grid.i0) + a)
 
 
 def grid_from_desc(desc) -> wfk_grid:

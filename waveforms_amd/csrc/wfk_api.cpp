@@ -404,6 +404,7 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
   a.tiles_per_chunk = p->h.tiles_per_chunk;
   a.accumulate = (flags & WFK_ACCUMULATE) ? 1 : 0;
   a.t0 = p->h.t0;
+  a.i0 = p->h.i0;
   a.step = p->h.step;
   a.last = p->h.last;
   a.has_last = p->h.has_last;

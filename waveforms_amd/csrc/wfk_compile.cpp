@@ -34,7 +34,7 @@ struct TimeAxis {
   double at(int64_t i) const {
     if (t) return t[i];
     if (g->has_last && i == g->n - 1) return g->last;
-    volatile double m = (double)i * g->step;
+    volatile double m = (double)(i + g->i0) * g->step;
     return m + g->t0;
   }
   // first i with fl(x[i] - tshift) >= b
@@ -181,7 +181,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   H.n_channels = P->n_channels;
   H.n = ax.n;
   if (grid) {
-    H.t0 = grid->t0; H.step = grid->step; H.last = grid->last; H.has_last = grid->has_last;
+    H.t0 = grid->t0; H.step = grid->step; H.last = grid->last; H.has_last = grid->has_last; H.i0 = grid->i0;
+    if (grid->i0 < 0) { err = "negative grid.i0"; return WFK_EINVAL; }
     if (ax.n > 1 && !(grid->step > 0)) { err = "grid step must be positive"; return WFK_EINVAL; }
   }
   H.ns = H.tlist ? (ax.n < WFK_TLIST_SMALL_N ? WFK_NS_TLIST_SMALL : WFK_NS_TLIST) : WFK_NS_GRID;
@@ -351,7 +352,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       return 2.4e-16 * m;
     }
     const double m = std::max(std::fabs(ax.at(s0)), std::fabs(ax.at(s1 - 1)));
-    return 1.2e-16 * (m + std::fabs((double)(s1 - 1) * grid->step));
+    return 1.2e-16 * (m + std::fabs((double)(grid->i0 + s1 - 1) * grid->step));
   };
   auto rate_safe = [&](double rate, int64_t s0, int64_t s1) -> bool {   // |d value / dt| <= rate
     return std::fabs(rate) * grid_jitter(s0, s1) <= WFK_JITTER_TOL;
@@ -1638,7 +1639,7 @@ extern "C" int wfk_grid_detect(const double* t, int64_t n, wfk_grid* out) {
   GridProbe P{t, n, t[0]};
   if (!(t[n - 1] > t[0]) || !std::isfinite(t[0]) || !std::isfinite(t[n - 1])) return 0;
   auto accept = [&](double step, int has_last) {
-    out->t0 = t[0]; out->step = step; out->n = n; out->has_last = has_last;
+    out->t0 = t[0]; out->step = step; out->n = n; out->has_last = has_last; out->i0 = 0;
     out->last = has_last ? t[n - 1] : 0.0;
     return 1;
   };

@@ -55,6 +55,7 @@ struct ChainArgs {
   double t0, step, last;
   int32_t has_last, hop, K, lead;
   int64_t hrow;                // per-row kernels: complex elements between the spectra of consecutive rows (else 0)
+  int64_t i0;                  // wfk_grid.i0: sample j is sample i0 + j of the caller's full grid
 };
 
 template <int... K, typename F>
@@ -74,7 +75,7 @@ __device__ __forceinline__ int cuni(int v) { return __builtin_amdgcn_readfirstla
 // the zero-padded samples j < 0 and j >= n of the first and last windows
 __device__ __forceinline__ double chain_time(const ChainArgs& a, int64_t j) {
 #pragma clang fp contract(off)
-  const double m = (double)j * a.step;
+  const double m = (double)(j + a.i0) * a.step;
   double t = m + a.t0;
   if (a.has_last && j == a.n - 1) t = a.last;
   return t;
@@ -668,6 +669,7 @@ struct wfk_chain_plan {
   int64_t table_bytes = 0;
   double t0 = 0, step = 0, last = 0;
   int32_t has_last = 0;
+  int64_t i0 = 0;
   // unfused path: the sampler's output
   void* workspace = nullptr;
 };
@@ -713,7 +715,7 @@ static int chain_plan_create(const wfk_program* prog, const wfk_grid* grid, cons
   rc = per_row ? wfk_fir_plan_create_rows(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir)
                : wfk_fir_plan_create(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir);
   if (rc) { wfk_chain_plan_destroy(p); return rc; }
-  p->t0 = grid->t0; p->step = grid->step; p->last = grid->last; p->has_last = grid->has_last;
+  p->t0 = grid->t0; p->step = grid->step; p->last = grid->last; p->has_last = grid->has_last; p->i0 = grid->i0;
   if (p->n == 0 || p->n_channels == 0) { *out = p; return WFK_OK; }
 
   // ---- can the sampler run inside the transform? ---------------------------------------
@@ -896,7 +898,7 @@ int wfk_chain_launch(wfk_chain_plan* p, void* out_dev, int64_t out_stride, void*
   a.channels = p->d_channels; a.pieces = p->d_pieces; a.params = p->d_params; a.pair_first = p->d_pair_first;
   a.out = out_dev; a.out_stride = out_stride; a.n = p->n; a.npairs = p->npairs;
   a.hspec = kspec; a.tw = tw; a.hrow = wfk_internal_fir_krow(p->fir);
-  a.t0 = p->t0; a.step = p->step; a.last = p->last; a.has_last = p->has_last;
+  a.t0 = p->t0; a.step = p->step; a.last = p->last; a.has_last = p->has_last; a.i0 = p->i0;
   a.hop = 256 * p->hopb; a.K = K; a.lead = lead;
   const dim3 grid((unsigned)((p->npairs + WFK_FIRS_PPW - 1) / WFK_FIRS_PPW), (unsigned)p->n_channels);
   if (p->kind == WFK_OUT_F32) {

@@ -232,6 +232,7 @@ struct KArgs {
   int32_t lean_fam;            // lean kernel family (HostPlan::lean_fam)
   int32_t mixed;               // mixed plan: the lean kernel skips the pieces without WFK_PF_LEAN, the general
                                // kernel skips the lean and the zero pieces (two launches, one output)
+  int64_t i0;                  // wfk_grid.i0: sample j of the plan is sample i0 + j of the caller's full grid
 };
 
 #ifdef __cplusplus
@@ -246,6 +247,7 @@ struct HostPlan {
   int64_t n = 0;
   double t0 = 0, step = 0, last = 0;
   int32_t has_last = 0;
+  int64_t i0 = 0;              // wfk_grid.i0: index of the plan's first sample in the caller's full grid
   int32_t ns = 0, tile = 0, tiles_per_chunk = 1;
   int64_t chunks_per_ch = 0;
   std::vector<DevChannel> channels;

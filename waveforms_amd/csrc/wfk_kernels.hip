@@ -88,7 +88,7 @@ __device__ __forceinline__ double grid_time(const KArgs& a, int64_t j) {
 #pragma clang fp contract(off)
   // (int64 -> double is a multi-instruction sequence on this ISA, uint32 -> double is one: the
   //  per-sample callers of the direct tier feel it; both conversions are exact)
-  const double dj = a.n <= 0xffffffffLL ? (double)(uint32_t)j : (double)j;
+  const double dj = (a.i0 == 0 && a.n <= 0xffffffffLL) ? (double)(uint32_t)j : (double)(j + a.i0);   // (i0: wave-uniform)
   double m = dj * a.step;
   double t = m + a.t0;
   if (a.has_last && j == a.n - 1) t = a.last;
@@ -1291,10 +1291,10 @@ wfk_sample_lean(const KArgs a) {
           const int64_t js = j0 - (int64_t)since_seed * WT;
           double xs = grid_time(a, js);
           if (C.tshift != 0.0) xs = xs - C.tshift;
-          cc.dj0 = (double)j0;
+          cc.dj0 = (double)(j0 + a.i0);    // index in the caller's FULL grid (wfk_grid.i0): the times are formed from it
           cc.xref = xs;
           cc.step = a.step; cc.t0 = a.t0; cc.tshift = C.tshift; cc.last = a.last;
-          cc.dlast = a.has_last ? (double)(a.n - 1) : -1.0;
+          cc.dlast = a.has_last ? (double)(a.i0 + a.n - 1) : -1.0;
           cc.kbase = since_seed * NS;
         }
         for (int op = 0; op < nops; ++op) {
