@@ -70,6 +70,10 @@ def parse_args(argv=None):
                          '"gather", never part of `value`: results stay sharded by default)')
     ap.add_argument('--dtype', choices=['f64', 'f32'], default=None,
                     help='override the output dtype of the workload')
+    ap.add_argument('--shard', choices=['channels', 'time'], default='channels',
+                    help='N > 1: channel-block-per-rank (default: every rank owns --channels channels, weak scaling) or '
+                         'time-slice-per-rank (the SAME --channels rows of --points samples cut along time: strong scaling; '
+                         'a job of a few very long rows, SURVEY 8(e))')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--share-gpu', action='store_true')
     ap.add_argument('--plan-only', action='store_true')
@@ -490,7 +494,13 @@ def run_rank(args):
     tile = TILE.get(name, 1)
     if channels % tile:
         raise SystemExit(f'--channels must be a multiple of {tile} for workload {name}')
-    if name == 'tlist':
+    time_sharded = args.shard == 'time' and name not in ('tlist', 'c4', 'awg_c4')
+    if time_sharded:
+        from waveforms_amd._dist import TimeShardedSampler
+        if channels % tile:
+            raise SystemExit(f'--channels must be a multiple of {tile} for workload {name}')
+        sh = TimeShardedSampler([make_channel(c) for c in range(channels // tile)] * tile, grid, rank, world)
+    elif name == 'tlist':
         sh = TlistBlock(channels * world, make_channel, wl.jittered_times(points), rank, world)
     else:
         sh = ShardedSampler(channels * world, make_channel, grid, rank, world, tile=tile)
@@ -567,6 +577,8 @@ def run_rank(args):
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     samples_per_step = bs.n_channels * bs.n * world
+    if time_sharded:          # the ranks' slices differ by at most one sample: the job is channels x points
+        samples_per_step = bs.n_channels * points
     elem = np.dtype(dtype).itemsize
     algo_bytes = bs.n_channels * bs.n * (elem + (8 if name == 'tlist' else 0))   # per launch, per GPU (a time list is read: + 8 B/sample)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
@@ -623,12 +635,13 @@ def run_rank(args):
         'value': samples_per_step * args.steps / elapsed / 1e6,
         'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'higher_is_better': True, 'scaling': 'strong' if time_sharded else 'weak', 'vs_baseline': None,
         'dtype': 'f64' if dtype == np.float64 else 'f32', 'data': 'synthetic',
         'config': {'workload': f'{name}: {desc}', 'channels_per_gpu': bs.n_channels,
-                   'channels_total': bs.n_channels * world,
+                   'channels_total': bs.n_channels * (1 if time_sharded else world),
                    'points_per_channel': bs.n, 'output': 'device (HBM) buffer',
-                   'parallelism': f'channel-block-per-rank x{world}, no data-path collective',
+                   'parallelism': (f'time-slice-per-rank x{world} (wfk_grid.i0), no data-path collective' if time_sharded
+                                   else f'channel-block-per-rank x{world}, no data-path collective'),
                    'backend': None if dist is None else
                    ('nccl (RCCL) world_size=%d' % dist.get_world_size() if args.backend == 'nccl'
                     else 'gloo world_size=%d' % dist.get_world_size())},
@@ -812,6 +825,9 @@ def run_rank(args):
         line['cpu_baseline'] = base        # (timed after the last barrier of the timed region: rank 0's host only)
         line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
         got = out[:len(outs)].cpu().numpy().astype(np.float64)
+        if time_sharded:      # rank 0 holds the first time slice of every row
+            outs = [o[sh.start:sh.stop] for o in outs]
+            got = got[:, sh.own]
         line['max_abs_err_vs_numpy_ref'] = float(
             max(np.max(np.abs(got[i] - outs[i])) for i in range(len(outs))))
     if dist is not None and args.gather_rows > 0:
