@@ -163,6 +163,13 @@ int wfk_plan_create_tlist(const wfk_program* prog, const double* t_host,
  * grid (np.linspace with or without endpoint, np.arange: every element is compared), else 0.
  * Lets Waveform.__call__(x) (waveform.py:529-563) compile grid mode for the usual x.     */
 int wfk_grid_detect(const double* t_host, int64_t n, wfk_grid* grid);
+/* The same for an x that is SEVERAL such grids back to back (np.concatenate of the chunks of a chunked job,
+ * waveforms/waveform.py:232; a sequence sampled at two rates): number of runs found -- starts[k] = index of
+ * run k's first sample, grids[k] its grid, every element verified -- or 0 (a run shorter than min_len,
+ * more than max_runs runs, anything that is not exactly a grid).  The caller then samples run by run in grid
+ * mode instead of handing the whole x over as a time list.                                                */
+int wfk_grid_detect_runs(const double* t_host, int64_t n, int64_t min_len, int32_t max_runs,
+                         int64_t* starts, wfk_grid* grids);
 int wfk_plan_destroy(wfk_plan* plan);
 int wfk_plan_get_info(const wfk_plan* plan, wfk_plan_info* info);
 /* np.searchsorted(x - tshift, bounds) of one member (integer parity probe);

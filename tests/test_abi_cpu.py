@@ -191,3 +191,26 @@ def test_grid_detection_is_exact():
     for bad in (np.sort(rng.uniform(0, 1, 1000)), np.concatenate([t[:500], t[500:] + 0.5]),
                 np.where(np.arange(1000) == 7, np.nan, t), t[::-1].copy(), t[:8], np.zeros(100)):
         assert _engine.detect_grid(np.ascontiguousarray(bad)) is None
+
+
+def test_grid_run_detection_is_exact():
+    """wfk_grid_detect_runs: an x that is several NumPy grids back to back splits into runs, every run verified
+    element by element; one ulp off anywhere, a run too short, contiguous chunks without a spacing break
+    (np.concatenate of _sample_iter's chunks: not told apart from one grid by spacing, and not one grid bit for
+    bit) or random times -> None (the call then takes the time-list tier)."""
+    a = np.linspace(0, 1e-6, 50000, endpoint=False)
+    b = np.arange(2e-6, 3e-6, 0.5e-10)
+    c = np.linspace(3.5e-6, 4e-6, 9000)
+    t = np.concatenate([a, b, c])
+    runs = _engine.detect_grid_runs(t)
+    assert [s for s, _ in runs] == [0, len(a), len(a) + len(b)]
+    for (s, g), n in zip(runs, (len(a), len(b), len(c))):
+        assert g.n == n and np.array_equal(_flatten.grid_values(g), t[s:s + n])
+    bad = t.copy()
+    bad[60000] = np.nextafter(bad[60000], 1.0)
+    assert _engine.detect_grid_runs(bad) is None
+    assert _engine.detect_grid_runs(np.concatenate([a, b[:100], c])) is None           # a run below min_len
+    chunks = np.concatenate([np.linspace(k * 1e-6, (k + 1) * 1e-6, 10000, endpoint=False) for k in range(3)])
+    assert _engine.detect_grid(chunks) is None and _engine.detect_grid_runs(chunks) is None
+    assert _engine.detect_grid_runs(np.sort(np.random.default_rng(0).uniform(0, 1, 100000))) is None
+    assert _engine.detect_grid_runs(a) is not None and len(_engine.detect_grid_runs(a)) == 1

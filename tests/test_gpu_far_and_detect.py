@@ -107,3 +107,28 @@ def test_detection_is_exact_and_falls_back():
     assert np.max(np.abs(w(t2) - np_oracle.call(w, t2))) <= 1e-9
     assert _engine.detect_grid(np.sort(np.random.default_rng(1).uniform(0, 1e-6, 5000))) is None
     assert _engine.detect_grid(t[:10]) is None                        # tiny arrays: not worth it
+
+
+def test_x_of_several_grids_is_sampled_run_by_run():
+    """wav(x) with x = np.concatenate of grids (windows of one sequence, two sample rates): every run in grid
+    mode; the result equals the calls on the runs one by one, bit for bit, and the oracle on the whole x."""
+    x_wav = cases.CASES['readme_x'][0](wf)
+    parts = [np.linspace(-0.2e-6, 0.4e-6, 60000, endpoint=False), np.arange(0.9e-6, 1.3e-6, 0.25e-10),
+             np.linspace(1.95e-6, 2.2e-6, 20001)]
+    t = np.concatenate(parts)
+    assert _engine.detect_grid(t) is None and len(_engine.detect_grid_runs(t)) == 3
+    got = x_wav(t)
+    piecewise = np.concatenate([x_wav(p) for p in parts])
+    assert np.array_equal(got, piecewise)
+    ora = np_oracle.call(x_wav, t)
+    pk = np.abs(ora).max()
+    assert np.max(np.abs(got - ora)) <= 1e-9 * pk
+    # out= / accumulate on that path, a complex waveform, a WaveVStack
+    buf = np.full(len(t) + 5, 2.0)
+    r = x_wav(t, out=buf, accumulate=True)
+    assert r is buf and np.max(np.abs(buf[:len(t)] - 2.0 - ora)) <= 1e-9 * pk and np.all(buf[len(t):] == 2.0)
+    wc = (1 + 2j) * (wf.gaussian(200e-9) >> 1.1e-6) * wf.cos(2 * np.pi * 50e6) + wf.gaussian(100e-9)
+    gc = wc(t)
+    assert gc.dtype == np.complex128 and np.max(np.abs(gc - np_oracle.call(wc, t))) <= 1e-9
+    vs = wf.WaveVStack([wf.gaussian(300e-9) >> 1e-6, wf.cos(2 * np.pi * 10e6) * 0.1]) + 0.5
+    assert np.max(np.abs(vs(t) - np.real(np_oracle.call(vs, t)))) <= 1e-9

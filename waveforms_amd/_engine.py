@@ -64,6 +64,7 @@ def lib():
         l.wfk_plan_create_grid.argtypes = [P(wfk_program), P(wfk_grid), P(VP)]
         l.wfk_plan_create_tlist.argtypes = [P(wfk_program), VP, I64, P(VP)]
         l.wfk_grid_detect.argtypes = [VP, I64, P(wfk_grid)]
+        l.wfk_grid_detect_runs.argtypes = [VP, I64, I64, I32, VP, P(wfk_grid)]
         l.wfk_plan_destroy.argtypes = [VP]
         l.wfk_plan_get_info.argtypes = [VP, P(wfk_plan_info)]
         l.wfk_plan_member_index.argtypes = [VP, I32, VP, I32]
@@ -140,6 +141,24 @@ def detect_grid(t: np.ndarray):
         return None
     g = wfk_grid()
     return g if lib().wfk_grid_detect(t.ctypes.data, len(t), C.byref(g)) == 1 else None
+
+
+def detect_grid_runs(t: np.ndarray, min_len: int = 4096, max_runs: int = 256):
+    """-> [(start, wfk_grid), ...] if the float64 array `t` is several NumPy grids back to back (each run
+    verified element by element, at least `min_len` samples long), else None."""
+    if os.environ.get('WFK_NO_GRID_DETECT') == '1' or t.dtype != np.float64 or not t.flags.c_contiguous:
+        return None
+    starts = np.zeros(max_runs, dtype=np.int64)
+    grids = (wfk_grid * max_runs)()
+    k = lib().wfk_grid_detect_runs(t.ctypes.data, len(t), min_len, max_runs, starts.ctypes.data, grids)
+    if k <= 0:
+        return None
+    out = []
+    for i in range(k):
+        g = wfk_grid()
+        C.memmove(C.byref(g), C.byref(grids[i]), C.sizeof(wfk_grid))
+        out.append((int(starts[i]), g))
+    return out
 
 
 class Plan:

@@ -101,11 +101,42 @@ def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=Non
     if isinstance(x, (int, float, complex)):
         return call_waveform(w, np.array([x]), function_lib=function_lib)[0]
     t = _as_time_array(x)
+    if not frag and len(t) >= 2 * _RUN_MIN and _engine.detect_grid(t) is None:
+        runs = _engine.detect_grid_runs(t, _RUN_MIN)
+        if runs is not None:
+            return _call_runs(w, t, runs, out, accumulate, function_lib)
     plan = _plan_for_axis(w, t, function_lib)
     try:
         return _finish(w, plan, frag, out, accumulate)
     finally:
         plan.close()
+
+
+_RUN_MIN = 4096      # shortest run worth a plan of its own
+
+
+def _call_runs(w, t, runs, out, accumulate, function_lib):
+    """x = several NumPy grids back to back (windows of one sequence, chunks at two rates; every run verified
+    element by element by the library): each run is sampled in grid mode -- fused ops, no upload of x -- into
+    its part of one result.  Same values as one call per run (reference waveform.py:529-563)."""
+    from .waveform import WaveVStack
+    ends = [a for a, _ in runs[1:]] + [len(t)]
+    plans = [_engine.Plan(_flatten.flatten([w], g, function_lib), grid=g) for _, g in runs]
+    try:
+        cplx = (not isinstance(w, WaveVStack)) and any(_is_complex(w, p) for p in plans)
+        dtype = np.complex128 if cplx else np.float64
+        res = _engine.pinned_empty((len(t), ), dtype)
+        for (a, _), b, p in zip(runs, ends, plans):
+            p.run_host_into(res[a:b])
+    finally:
+        for p in plans:
+            p.close()
+    if out is None or isinstance(w, WaveVStack):
+        return res
+    if not accumulate:
+        out *= 0
+    out[:len(res)] += res
+    return out
 
 
 def call_vstack(w, x, function_lib=None):
@@ -114,6 +145,10 @@ def call_vstack(w, x, function_lib=None):
     if isinstance(x, (int, float, complex)):
         return call_vstack(w, np.array([x]), function_lib)[0]
     t = _as_time_array(x)
+    if len(t) >= 2 * _RUN_MIN and _engine.detect_grid(t) is None:
+        runs = _engine.detect_grid_runs(t, _RUN_MIN)
+        if runs is not None:
+            return _call_runs(w, t, runs, None, False, function_lib)
     plan = _plan_for_axis(w, t, function_lib)
     try:
         return plan.run_host(np.float64)[0]

@@ -1689,6 +1689,45 @@ extern "C" int wfk_grid_detect(const double* t, int64_t n, wfk_grid* out) {
   return 0;
 }
 
+// A sorted x that is several NumPy grids back to back -- np.concatenate of the chunks of a chunked job
+// (waveforms/waveform.py:232: one np.linspace(..., endpoint=False) per chunk), a sequence sampled at two
+// rates -- splits into runs that each pass wfk_grid_detect.  Run boundaries are where the spacing changes by
+// more than the rounding of the grid formula can explain; every run is then verified element by element.
+// -> number of runs (starts[k], grids[k]; the last run ends at n), 0 if x is not such a concatenation
+//    (a run shorter than `min_len`, more than `max_runs` runs, one element off anywhere).
+extern "C" int wfk_grid_detect_runs(const double* t, int64_t n, int64_t min_len, int32_t max_runs,
+                                    int64_t* starts, wfk_grid* grids) {
+  if (!t || !starts || !grids || n < 32 || max_runs < 1) return 0;
+  if (min_len < 16) min_len = 16;
+  std::vector<int64_t> cuts = {0};
+  double prev = t[1] - t[0];
+  int64_t run0 = 0;
+  for (int64_t i = 1; i + 1 < n; ++i) {
+    const double d = t[i + 1] - t[i];
+    // within a grid the spacing wobbles by a few ulp of |t| (two roundings per element); a new grid starts
+    // with a jump or with another step
+    const double tol = 8.0 * 2.3e-16 * (std::fabs(t[i]) + std::fabs(t[i + 1])) + 1e-12 * std::fabs(prev);
+    if (!(std::fabs(d - prev) <= tol)) {
+      // t[i + 1] opens a new run (the odd spacing is the gap between the runs) -- unless the run so far is
+      // a single gap itself, i.e. two breaks in a row
+      if (i + 1 - run0 < min_len) return 0;
+      cuts.push_back(i + 1);
+      if ((int64_t)cuts.size() > max_runs) return 0;
+      run0 = i + 1;
+      if (i + 2 < n) { prev = t[i + 2] - t[i + 1]; ++i; } else break;
+    } else {
+      prev = d;
+    }
+  }
+  if (n - run0 < min_len) return 0;
+  for (size_t k = 0; k < cuts.size(); ++k) {
+    const int64_t a = cuts[k], b = k + 1 < cuts.size() ? cuts[k + 1] : n;
+    if (!wfk_grid_detect(t + a, b - a, &grids[k])) return 0;
+    starts[k] = a;
+  }
+  return (int)cuts.size();
+}
+
 // ---- sampler fused into the FIR transform at AWG rates: half-window entry lists ----------------------
 // (reference chain: waveform.py:190-192 -> distortion.py:329-337; consumer: fir_short, wfk_fir_sampled.hip)
 int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half_len, int64_t npairs,
