@@ -214,3 +214,7 @@ def test_grid_run_detection_is_exact():
     assert _engine.detect_grid(chunks) is None and _engine.detect_grid_runs(chunks) is None
     assert _engine.detect_grid_runs(np.sort(np.random.default_rng(0).uniform(0, 1, 100000))) is None
     assert _engine.detect_grid_runs(a) is not None and len(_engine.detect_grid_runs(a)) == 1
+    # a run that crosses t = 0 (its spacing wobbles by ulps of i * step there, not of the tiny t)
+    z = np.linspace(-0.2e-6, 0.4e-6, 60000, endpoint=False)
+    runs = _engine.detect_grid_runs(np.concatenate([z, b]))
+    assert [(s, int(g.n)) for s, g in runs] == [(0, len(z)), (len(z), len(b))]

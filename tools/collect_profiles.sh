@@ -25,10 +25,11 @@ case "$WL" in
 esac
 echo "== stats pass ($WL)"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/stats.log" 2>&1
-for grp in WRITE_SIZE FETCH_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
+for grp in WRITE_SIZE FETCH_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT"; do
     name=$(echo $grp | cut -d' ' -f1)
     echo "== pmc pass $name"
-    rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o run -- python3 $ARGS > "$OUT/pmc_$name.log" 2>&1
+    # (a counter this part does not have fails its own pass only: the stall breakdown of round 4 is best effort)
+    rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o run -- python3 $ARGS > "$OUT/pmc_$name.log" 2>&1 || echo "   pass $name failed (see $OUT/pmc_$name.log)"
 done
 python3 tools/summarize_profiles.py "$OUT" "gpurun_out/profiles/${TAG}_${WL}"
 grep "^{" "$OUT/stats.log" | tail -1 > "gpurun_out/profiles/${TAG}_${WL}_bench.json" || rm -f "gpurun_out/profiles/${TAG}_${WL}_bench.json"

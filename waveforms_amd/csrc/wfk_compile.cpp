@@ -1700,13 +1700,16 @@ extern "C" int wfk_grid_detect_runs(const double* t, int64_t n, int64_t min_len,
   if (!t || !starts || !grids || n < 32 || max_runs < 1) return 0;
   if (min_len < 16) min_len = 16;
   std::vector<int64_t> cuts = {0};
+  const double scale = 8.0 * 2.3e-16 * (std::max(std::fabs(t[0]), std::fabs(t[n - 1])) + std::fabs(t[n - 1] - t[0]));
   double prev = t[1] - t[0];
   int64_t run0 = 0;
   for (int64_t i = 1; i + 1 < n; ++i) {
     const double d = t[i + 1] - t[i];
     // within a grid the spacing wobbles by a few ulp of |t| (two roundings per element); a new grid starts
     // with a jump or with another step
-    const double tol = 8.0 * 2.3e-16 * (std::fabs(t[i]) + std::fabs(t[i + 1])) + 1e-12 * std::fabs(prev);
+    // (a few ulp of the largest |t| or |i * step| of ANY run: near t = 0 a grid's own wobble is that of
+    //  its fl(i * step), not of the tiny t)
+    const double tol = scale + 1e-12 * std::fabs(prev);
     if (!(std::fabs(d - prev) <= tol)) {
       // t[i + 1] opens a new run (the odd spacing is the gap between the runs) -- unless the run so far is
       // a single gap itself, i.e. two breaks in a row

@@ -70,6 +70,9 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define CH_END });
 
 __device__ __forceinline__ int cuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t cuni64(int64_t v) {     // a block-uniform 64-bit value, pinned to an SGPR pair
+  return (int64_t)(((uint64_t)(uint32_t)cuni((int)(v >> 32)) << 32) | (uint32_t)cuni((int)v));
+}
 
 // t[j] = fl(fl(j*step) + t0) (NumPy's linspace / arange element formula), continued linearly for
 // the zero-padded samples j < 0 and j >= n of the first and last windows
@@ -202,7 +205,7 @@ __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, 
   T u = (T)u0;
   const T Dt = (T)r[WFK_FCE_D];
 #ifndef WFK_FIRS_SB
-#define WFK_FIRS_SB 4
+#define WFK_FIRS_SB 1      // table entries fetched per sub-batch.  Same box, C4: 4 -> 9.70 ms (8 VGPRs spilled: +13 % HBM writes), 2 -> 9.66, 1 -> 9.58 (none)
 #endif
   constexpr int SB = CL % WFK_FIRS_SB == 0 ? WFK_FIRS_SB : 2;   // sub-batch: bounds the live table entries / temporaries
   static_assert(CL % SB == 0, "chain length must be even");
@@ -474,12 +477,21 @@ __device__ __attribute__((noinline)) void chain_copy_runs(T* lds, const T* wrow,
   }
 }
 
+#ifndef WFK_FSH_PARK
+#define WFK_FSH_PARK 7     // same box, 2048 x 1e5 at 2 GS/s: 0 -> 1.017 ms (8 VGPRs in scratch), 5 -> 0.985 (2), 6 -> 0.978 (2), 7 -> 0.965 (none; 45 KB of LDS per workgroup, three still fit a CU)
+#endif
 template <typename T, int HOPB>
 __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShortArgs a) {
   constexpr int CL = 16 + HOPB, HR = CL / 2, HALF = 256 * HR, R = WFK_SH_R;
   static_assert(CL % 2 == 0 && HALF + HALF / 16 <= LDS_ELEMS, "a half window must fit the transform's array");
   static_assert(HALF <= 4096, "entry offsets are 12 bit");
-  __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
+  // The first half's HR samples per thread wait in registers while the second half is sampled -- on top of that
+  // phase's own 16 accumulators and op record.  The double kernel had 4 of them in scratch (8 VGPRs spilled:
+  // WRITE_SIZE 1.30x the output).  They are parked in the array instead: the second half's image ends at
+  // HALF + HALF / 16, the PARK rows behind it belong to nobody until the transform (one more row of LDS).
+  constexpr int PARK = sizeof(T) == 8 ? WFK_FSH_PARK : 0, PARK_BASE = HALF + HALF / 16;
+  constexpr int LDS_ALL = PARK_BASE + 256 * PARK > LDS_ELEMS ? PARK_BASE + 256 * PARK : LDS_ELEMS;
+  __shared__ __attribute__((aligned(16))) T lds[LDS_ALL];
   const int tid = threadIdx.x;
   const int ch = blockIdx.y;
   const DevChannel C = a.channels[ch];
@@ -500,8 +512,8 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
   int w_cnt[2], w_pad[2], w_ccnt[2];
   uint32_t w_first[2];
   CH_EACH(2, half)
-    w_rec0[half] = wp0[half].rec0;
-    w_e0[half] = wp0[half].e0;
+    w_rec0[half] = cuni64(wp0[half].rec0);               // (block-uniform: SGPRs; as VGPR pairs they were 8 of the
+    w_e0[half] = cuni64(wp0[half].e0);                   //  registers this kernel spilled)
     w_cnt[half] = cuni(wp0[half].cnt);
     w_pad[half] = cuni(wp0[half].pad);
     w_ccnt[half] = cuni(wp0[half].ccnt);
@@ -593,12 +605,19 @@ __global__ void __launch_bounds__(256, WFK_FIRS_WAVES) fir_short(const ChainShor
       chain_copy_runs<T>(lds, static_cast<const T*>(a.ws) + (int64_t)ch * a.ws_stride + h0, a.entries + e0 + cnt,
                          w_ccnt[half], sw, tid);
     __syncthreads();
-    if (sw) {
-      CH_EACH(HR, k) x[half * HR + k] = mine[272 * k]; CH_END
-    } else {
-      CH_EACH(HR, k) x[half * HR + k] = mine[256 * k]; CH_END
-    }
+    // pick up the thread's stride-256 samples; the last PARK rows of the FIRST half go to the parking rows
+    // (written and read back by the same thread: no barrier of their own)
+    auto pickup = [&](auto rs_) __attribute__((always_inline)) {
+      constexpr int rs = decltype(rs_)::value;
+      CH_EACH(HR, k)
+        if constexpr (half == 0 && k >= HR - PARK) lds[PARK_BASE + 256 * (k - (HR - PARK)) + tid] = mine[rs * k];
+        else x[half * HR + k] = mine[rs * k];
+      CH_END
+    };
+    if (sw) pickup(std::integral_constant<int, 272>{});
+    else pickup(std::integral_constant<int, 256>{});
   CH_END
+  CH_EACH(PARK, k) x[HR - PARK + k] = lds[PARK_BASE + 256 * k + tid]; CH_END
   __syncthreads();                                         // the array becomes the FFT exchange buffer
 
   cx<T> v[16];
