@@ -338,9 +338,6 @@ __global__ void __launch_bounds__(64) iir_scan(double* __restrict__ state, const
 #ifndef OP_WAVES
 #define OP_WAVES 2
 #endif
-#ifndef OP_REREAD
-#define OP_REREAD 1
-#endif
 #define OP_SPIN (1 << 22)
 #define OP_WINDOWS 4            // look-back reach: 256 chunks of the row in flight
 
@@ -437,18 +434,10 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
     }
   }
   __syncthreads();
-  // The lane's block stays in ITS row of the tile from here to the output transpose: sweep 1 reads it, sweep 2
-  // reads it again and overwrites it in place.  (Held in 32 registers across the look-back instead, it kept the
-  // kernel at the 256-VGPR limit of two waves per SIMD; a row is touched by its own lane only between the barriers.)
-#if OP_REREAD
-#define XR(i) ((double)tile[lane][i] - pre_sub)
-#else
   double xr[OP_LB];
 #pragma unroll
   for (int i = 0; i < OP_LB; ++i) xr[i] = (double)tile[lane][i] - pre_sub;
   __syncthreads();
-#define XR(i) xr[i]
-#endif
 
   // ---- sweep 1: zero state -> local final state; scan over the 64 blocks
   double z[IIR_MAXD];
@@ -456,11 +445,11 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
   if (whole) {
 #pragma unroll
-    for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, ORD>(c, XR(i), z);
+    for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, ORD>(c, xr[i], z);
   } else {
 #pragma unroll
     for (int i = 0; i < OP_LB; ++i)
-      if (i < cnt) (void)iir_step_t<NSEC, ORD>(c, XR(i), z);
+      if (i < cnt) (void)iir_step_t<NSEC, ORD>(c, xr[i], z);
   }
   // (a block past the end of the row leaves its state alone: T1^0; the scan below still multiplies
   //  by T1 per block, which only matters AFTER the last sample -- nothing there is used)
@@ -599,13 +588,12 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   const double bad = poisoned ? __builtin_nan("") : 0.0;
   if (whole) {
 #pragma unroll
-    for (int i = 0; i < OP_LB; ++i) tile[lane][i] = (T)(iir_step_t<NSEC, ORD>(c, XR(i), z) + post_add + bad);
+    for (int i = 0; i < OP_LB; ++i) tile[lane][i] = (T)(iir_step_t<NSEC, ORD>(c, xr[i], z) + post_add + bad);
   } else {
 #pragma unroll
     for (int i = 0; i < OP_LB; ++i)
-      if (i < cnt) tile[lane][i] = (T)(iir_step_t<NSEC, ORD>(c, XR(i), z) + post_add + bad);
+      if (i < cnt) tile[lane][i] = (T)(iir_step_t<NSEC, ORD>(c, xr[i], z) + post_add + bad);
   }
-#undef XR
   // final state of the row: the block that holds its last sample
   if (zf && chunk == nchunks - 1) {
     const int64_t lastblk = (left - 1) / OP_LB;
