@@ -47,7 +47,8 @@ def test_time_slices_reproduce_the_whole_plan(kind, world):
     for rank in range(world):
         ts = TimeShardedSampler(chans, grid, rank, world)
         assert ts.lo == ts.start and ts.hi == ts.stop and ts.n == ts.stop - ts.start
-        assert ts.local.plan.kernel_name().split('<')[0] == whole.plan.kernel_name().split('<')[0]     # same tier
+        if kind != 'endpoint':      # (README x has its pulses in the first fifth of the window: a slice of zeros is a fill)
+            assert ts.local.plan.kernel_name().split('<')[0] == whole.plan.kernel_name().split('<')[0]     # same tier
         out = torch.full((ts.n_channels, ts.n + 3), 9.0, dtype=torch.float64, device='cuda')
         ts.launch_torch(out)
         torch.cuda.synchronize()

@@ -428,6 +428,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         const double dphase = 3.141592653589793 * a[0] * dstride;
         rec[0] = WFK_M_SINC_TAB; rec[3] = a[0]; rec[4] = dphase; fast = true;
         table = table_for(B, dphase);
+      } else if (type == WFK_MOLLIFIER && a[1] == 0.0 && std::isfinite(a[0]) && a[0] > 0.0 && rate_safe(4.0 / a[0], s0, s1) &&
+                 !std::getenv("WFK_NO_MOLL_REC")) {
+        // exp(1 / (x^2 - 1) + 1), x = u / r (reference _waveform.pyx:359-363): the exponent is <= 0 inside the
+        // support; Newton reciprocal + inline exponential instead of an IEEE division and libm's exp
+        rec[0] = WFK_M_MOLL_REC; rec[3] = a[0]; rec[4] = dstride; fast = true;
       } else if (type == WFK_EXP && std::isfinite(a[0]) && rate_safe(a[0], s0, s1)) {
         double ext = std::fabs(a[0]) * (umax + dstride * NS);
         if (ext <= 600.0) {

@@ -85,6 +85,7 @@
 #define WFK_M_SAMPLED 20      // caller-evaluated factor (WFK_SAMPLED): a0 = pool offset of the values, a1 = i0, a2 = m
 #define WFK_M_REUSE 1000      // added to a direct factor's type: same record as the previous direct factor of
                               // the block -> its values are still in the LDS value buffer
+#define WFK_M_MOLL_REC 111    // mollifier(width) (d = 0): exp(1 / ((u/r)^2 - 1) + 1) inside |u| < r, inline reciprocal and exponential   a0 = r
 #define WFK_M_SINC_TAB 110    // sinc(b u) = sin(pi b u) / (pi b u): sin by the phasor table (as COS_TAB), the argument advanced by the
                               // SAME per-stride phase, one reciprocal per sample   a0 = b, a1 = pi b D (the table's phase step), aux = table
 #define WFK_M_INTERP_LIN 109  // the same table (finite values) read as a continuous piecewise-linear function: knot index from

@@ -133,6 +133,32 @@ __device__ __forceinline__ double rcp_nr(double y) {
   return r;
 }
 
+// exp(x) inline: x = n ln2 + r, |r| <= 0.347, exp(r) by its Taylor polynomial of degree 13 (next term 4e-18),
+// scaled by v_ldexp_f64 (which also does the gradual underflow).  ~20 VALU instructions, no table, no call;
+// <= 2 ulp against libm's <= 1 (the Gaussian and exponential envelopes of the pointwise ops).
+__device__ __forceinline__ double exp_inline(double x) {
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = fma(r, 1.6059043836821613e-10, 2.08767569878681e-09);      // 1/13!, 1/12!
+  p = fma(r, p, 2.505210838544172e-08);
+  p = fma(r, p, 2.755731922398589e-07);
+  p = fma(r, p, 2.7557319223985893e-06);
+  p = fma(r, p, 2.48015873015873e-05);
+  p = fma(r, p, 1.984126984126984e-04);
+  p = fma(r, p, 1.3888888888888889e-03);
+  p = fma(r, p, 8.333333333333333e-03);
+  p = fma(r, p, 4.1666666666666664e-02);
+  p = fma(r, p, 1.6666666666666666e-01);
+  p = fma(r, p, 0.5);
+  p = fma(r, p, 1.0);
+  p = fma(r, p, 1.0);
+  double e = ldexp(p, (int)n);
+  e = x < -746.0 ? 0.0 : e;                       // (also x = -inf, where r is NaN)
+  e = x > 710.0 ? __builtin_inf() : e;
+  return e;
+}
+
 template <bool TLIST>
 __device__ __forceinline__ double time_at(const KArgs& a, int64_t j) {
   if (TLIST) {
@@ -439,6 +465,16 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
         v = y2 < 1e-6 ? ser : v;
         prod[k] *= (T)v;
       }
+    } else if (mode == WFK_M_MOLL_REC) {
+      const double ir = 1.0 / r[3], D = r[4];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const double xx = fma((double)k, D, u0) * ir;
+        const double q = fma(xx, xx, -1.0);
+        const double qq = q < -1e-300 ? q : -1.0;                     // (outside the support: any harmless argument)
+        const double v = exp_inline(rcp_nr(qq) + 1.0);
+        prod[k] *= (T)(q < 0.0 ? v : 0.0);
+      }
     } else if (mode == WFK_M_INTERP_LIN) {
       // np.interp on linspace knots with a finite table (reference _waveform.pyx:309-311), as a continuous
       // piecewise-linear function: segment from the O(1) guess, x clamped into [start, stop] (the constant
@@ -447,11 +483,10 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
       const int last = (int)r[5] - 2;                // last segment
       const double* fp = a.pool + (int64_t)r[6];
       const double* sl = a.pool + (int64_t)r[7];
+      const double D = 64.0 * a.step;                 // (the general kernel's lane stride; x to an ulp or two: continuity again)
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        double x = grid_time(a, j0 + 64 * (int64_t)k);
-        if (tshift != 0.0) x = x - tshift;
-        x = x - shift;
+        const double x = fma((double)k, D, u0);         // (same box: 2.37 ms against 2.46 with the exact per-sample grid time)
         const double xc = fmin(fmax(x, start), stop);
         int j = (int)((xc - start) * inv_step);
         j = j > last ? last : j;
@@ -967,32 +1002,6 @@ __device__ __forceinline__ void sincos_small(double th, double& c, double& s) {
   s = (q & 2) ? -b : b;
 }
 
-// exp(x) inline: x = n ln2 + r, |r| <= 0.347, exp(r) by its Taylor polynomial of degree 13 (next term 4e-18),
-// scaled by v_ldexp_f64 (which also does the gradual underflow).  ~20 VALU instructions, no table, no call;
-// <= 2 ulp against libm's <= 1 (the Gaussian and exponential envelopes of the pointwise ops).
-__device__ __forceinline__ double exp_inline(double x) {
-  const double n = rint(x * 1.4426950408889634);
-  double r = fma(-n, 6.93147180369123816490e-01, x);
-  r = fma(-n, 1.90821492927058770002e-10, r);
-  double p = fma(r, 1.6059043836821613e-10, 2.08767569878681e-09);      // 1/13!, 1/12!
-  p = fma(r, p, 2.505210838544172e-08);
-  p = fma(r, p, 2.755731922398589e-07);
-  p = fma(r, p, 2.7557319223985893e-06);
-  p = fma(r, p, 2.48015873015873e-05);
-  p = fma(r, p, 1.984126984126984e-04);
-  p = fma(r, p, 1.3888888888888889e-03);
-  p = fma(r, p, 8.333333333333333e-03);
-  p = fma(r, p, 4.1666666666666664e-02);
-  p = fma(r, p, 1.6666666666666666e-01);
-  p = fma(r, p, 0.5);
-  p = fma(r, p, 1.0);
-  p = fma(r, p, 1.0);
-  double e = ldexp(p, (int)n);
-  e = x < -746.0 ? 0.0 : e;                       // (also x = -inf, where r is NaN)
-  e = x > 710.0 ? __builtin_inf() : e;
-  return e;
-}
-
 // value of one group at time x (on the channel's own axis); everything wave-uniform comes in by value
 struct FcePoint {
   double W, sref, slin, sigma, sg;
@@ -1370,10 +1379,12 @@ wfk_sample_lean(const KArgs a) {
 #define WFK_TL_WGS 3
 #endif
 template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
+// (the build with generic terms but no direct tier is capped at 256 VGPRs as well: left alone it took 261 + 5 AGPRs = one
+//  wave per SIMD; same box, sinc / INTERP / mollifier pulses 4.79 / 3.04 / 2.18 ms uncapped, 3.25 / 2.34 / 1.37 capped)
 // (the build with direct primitives inlines all of device libm's shapes: left alone it takes 280 VGPRs = ONE
 // workgroup per CU, one wave per SIMD walking serial libm chains; capped at 256 it runs two: direct tier 1.8x.
 // The tlist builds (no fused code, 8 samples per lane) fit three at 168: 4.80 -> 3.45 ms on 64 x 2e6 times.)
-__global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || (GENERIC && CPLX)) ? 2 : 1)) wfk_sample(const KArgs a) {
+__global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENERIC) ? 2 : 1)) wfk_sample(const KArgs a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
   __shared__ double s_val[DIRECT ? NS * WFK_WG : 1];   // direct-factor values (apply_factor)
   constexpr int WT = 64 * NS;
