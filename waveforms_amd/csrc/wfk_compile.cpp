@@ -974,6 +974,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     }
     rec[WFK_FCE_D] = dstride;
     if (H.tlist) {
+      // (pointwise evaluation: no lane stride; the H slot carries 1 / sigma -- the Gaussian's argument is formed
+      //  by a multiplication, one rounding off the reference's division: 2 v^2 ulp <= 1.5e-13 relative at |v| = 26)
+      if (G.has_env && !G.has_exp) rec[WFK_FCE_H] = 1.0 / G.sigma;
       double lim = 1.6e6;       // (tests: WFK_TLSMALL_LIMIT=0 sends every carrier through the two-term 1/pi reduction)
       if (const char* e = std::getenv("WFK_TLSMALL_LIMIT")) lim = std::atof(e);
       if (G.tl_thmax <= lim) rec[WFK_FCE_DEG] += (double)WFK_FCE_TLSMALL;

@@ -721,6 +721,14 @@ __device__ __forceinline__ void fce_loop(const double2* tab, const double* r, Fc
     WFK_EACH(SB, kk)
       constexpr int k = kb * SB + kk;
       T val;
+      if constexpr (DEG == 0 && CARRIER && !CORR && ENV == 0) {
+        // a bare carrier (the tones of a multiplexed pulse under a shared envelope): two fused multiply-adds
+        // straight into the accumulator instead of product, fma and add
+        const double2 cs = tb[kb & 1][kk];
+        acc[k] = __builtin_fma(ac, (T)cs.x, acc[k]);
+        acc[k] = __builtin_fma(-as, (T)cs.y, acc[k]);
+        return;
+      }
       if (DEG == 0) {
         if (CARRIER) {
           const double2 cs = tb[kb & 1][kk];
@@ -1014,7 +1022,7 @@ __device__ __forceinline__ void sincos_small(double th, double& c, double& s) {
 
 // value of one group at time x (on the channel's own axis); everything wave-uniform comes in by value
 struct FcePoint {
-  double W, sref, slin, sigma, sg;
+  double W, sref, slin, sigma, sg, isig;
   int deg, env;
   bool carrier, expenv, small;
 };
@@ -1040,7 +1048,7 @@ __device__ __forceinline__ double fce_point_value(const double* r, const FcePoin
   if (g.env == 1) {
     const double d = x - g.sg;
     double q = g.sigma * d;                                                // exp(alpha (t' - ref))
-    if (!g.expenv) { q = d / g.sigma; q = -(q * q); }                      // exp(-((t' - s_g)/sigma)^2), as the reference forms it
+    if (!g.expenv) { q = d * g.isig; q = -(q * q); }                       // exp(-((t' - s_g)/sigma)^2); 1 / sigma from the host
     v *= exp_inline(q);
   }
   return v;
@@ -1059,9 +1067,10 @@ __device__ __forceinline__ void fce_point(const double* r, const double (&x)[NS]
   const double sigma = r[WFK_FCE_SIGMA], sg = r[WFK_FCE_SG];
   if (env == 3) {
     // closing op of a piece whose carriers share one Gaussian: multiply what they accumulated by it
+    const double isig = r[WFK_FCE_H];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      const double v = (x[k] - sg) / sigma;
+      const double v = (x[k] - sg) * isig;
       const T e = (T)exp_inline(-(v * v));
       acc[k] *= e;
       if constexpr (CPLX) acci[k] *= e;
@@ -1070,6 +1079,7 @@ __device__ __forceinline__ void fce_point(const double* r, const double (&x)[NS]
   }
   FcePoint g;
   g.W = r[WFK_FCE_W]; g.sref = r[WFK_FCE_SREF]; g.slin = r[WFK_FCE_SLIN]; g.sigma = sigma; g.sg = sg;
+  g.isig = r[WFK_FCE_H];
   g.deg = deg; g.env = env; g.carrier = carrier; g.expenv = (fl & WFK_FCE_EXPENV) != 0;
   g.small = (fl & WFK_FCE_TLSMALL) != 0;
 #pragma unroll
