@@ -109,9 +109,11 @@ def test_detection_is_exact_and_falls_back():
     assert _engine.detect_grid(t[:10]) is None                        # tiny arrays: not worth it
 
 
-def test_x_of_several_grids_is_sampled_run_by_run():
-    """wav(x) with x = np.concatenate of grids (windows of one sequence, two sample rates): every run in grid
-    mode; the result equals the calls on the runs one by one, bit for bit, and the oracle on the whole x."""
+def test_x_of_several_grids_is_sampled_run_by_run(monkeypatch):
+    """wav(x) with x = np.concatenate of grids (windows of one sequence, two sample rates), WFK_GRID_RUNS=1: every
+    run in grid mode; the result equals the calls on the runs one by one, bit for bit, and the oracle on the
+    whole x.  (Default: the whole x as one time list -- faster since round 4 -- checked at the end.)"""
+    monkeypatch.setattr(_sampling, '_RUNS_ON', True)
     x_wav = cases.CASES['readme_x'][0](wf)
     parts = [np.linspace(-0.2e-6, 0.4e-6, 60000, endpoint=False), np.arange(0.9e-6, 1.3e-6, 0.25e-10),
              np.linspace(1.95e-6, 2.2e-6, 20001)]
@@ -132,3 +134,6 @@ def test_x_of_several_grids_is_sampled_run_by_run():
     assert gc.dtype == np.complex128 and np.max(np.abs(gc - np_oracle.call(wc, t))) <= 1e-9
     vs = wf.WaveVStack([wf.gaussian(300e-9) >> 1e-6, wf.cos(2 * np.pi * 10e6) * 0.1]) + 0.5
     assert np.max(np.abs(vs(t) - np.real(np_oracle.call(vs, t)))) <= 1e-9
+    monkeypatch.setattr(_sampling, '_RUNS_ON', False)
+    one_list = x_wav(t)
+    assert np.max(np.abs(one_list - ora)) <= 1e-9 * pk

@@ -49,3 +49,13 @@ for m in (10001, 100000):
     for _ in range(50):
         w(tt)
     print('w(t) on %d points: %.1f us' % (m, (c() - t0) / 50 * 1e6))
+# round 4: a NON-grid x of 1e7 points (jittered) through the drop-in call: upload of x + the time-list tier + copy back;
+# the finite scan that out= costs; an x of four grids back to back (sampled run by run)
+tj = wl.jittered_times(n)
+for rep in range(3):
+    t0 = c(); y = w(tj); print('w(jittered x) %.2f ms' % ((c() - t0) * 1e3)); del y
+t0 = c(); ok = _engine.all_finite(out); print('all_finite(1e7 doubles) %.2f ms' % ((c() - t0) * 1e3))
+tr = np.concatenate([np.linspace(k * 0.8e-6, (k * 0.8 + 0.7) * 1e-6, n // 4, endpoint=False) for k in range(4)])
+t0 = c(); runs = _engine.detect_grid_runs(tr); print('detect_grid_runs %.2f ms -> %d runs' % ((c() - t0) * 1e3, len(runs)))
+for rep in range(3):
+    t0 = c(); y = w(tr); print('w(4 grids back to back) %.2f ms' % ((c() - t0) * 1e3)); del y

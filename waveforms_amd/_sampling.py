@@ -86,12 +86,13 @@ def _finish(w, plan, frag, out, accumulate):
     return out
 
 
-def _plan_for_axis(w, t, function_lib):
+def _plan_for_axis(w, t, function_lib, grid=False):
     """x is almost always np.linspace / np.arange output: when it is bit-identical to the grid
     formula (checked element by element in the library) the plan is compiled in grid mode --
     fused ops, no upload of x -- and the device regenerates exactly the caller's times.  Any
     other sorted x stays in tlist mode."""
-    grid = _engine.detect_grid(t)
+    if grid is False:                      # (not looked at yet by the caller)
+        grid = _engine.detect_grid(t)
     if grid is not None:
         return _engine.Plan(_flatten.flatten([w], grid, function_lib), grid=grid)
     return _engine.Plan(_flatten.flatten([w], t, function_lib), t=t)
@@ -101,11 +102,12 @@ def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=Non
     if isinstance(x, (int, float, complex)):
         return call_waveform(w, np.array([x]), function_lib=function_lib)[0]
     t = _as_time_array(x)
-    if not frag and len(t) >= 2 * _RUN_MIN and _engine.detect_grid(t) is None:
+    grid = _engine.detect_grid(t)
+    if _RUNS_ON and grid is None and not frag and len(t) >= 2 * _RUN_MIN:
         runs = _engine.detect_grid_runs(t, _RUN_MIN)
         if runs is not None:
             return _call_runs(w, t, runs, out, accumulate, function_lib)
-    plan = _plan_for_axis(w, t, function_lib)
+    plan = _plan_for_axis(w, t, function_lib, grid)
     try:
         return _finish(w, plan, frag, out, accumulate)
     finally:
@@ -113,6 +115,11 @@ def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=Non
 
 
 _RUN_MIN = 4096      # shortest run worth a plan of its own
+# Run-by-run grid sampling of an x made of several grids is OFF unless WFK_GRID_RUNS=1: since the time-list tier
+# evaluates fused groups pointwise it is the faster way (1e7 points in four runs: 11.7 ms run by run -- 8 ms of
+# it the host's run detection -- against 4.2 ms as ONE time list, tools/big_call_latency.py); the run path is
+# kept for callers who want the grid tiers' values (and as the place the library's run detector is exercised).
+_RUNS_ON = __import__('os').environ.get('WFK_GRID_RUNS') == '1'
 
 
 def _call_runs(w, t, runs, out, accumulate, function_lib):
@@ -145,11 +152,12 @@ def call_vstack(w, x, function_lib=None):
     if isinstance(x, (int, float, complex)):
         return call_vstack(w, np.array([x]), function_lib)[0]
     t = _as_time_array(x)
-    if len(t) >= 2 * _RUN_MIN and _engine.detect_grid(t) is None:
+    grid = _engine.detect_grid(t)
+    if _RUNS_ON and grid is None and len(t) >= 2 * _RUN_MIN:
         runs = _engine.detect_grid_runs(t, _RUN_MIN)
         if runs is not None:
             return _call_runs(w, t, runs, None, False, function_lib)
-    plan = _plan_for_axis(w, t, function_lib)
+    plan = _plan_for_axis(w, t, function_lib, grid)
     try:
         return plan.run_host(np.float64)[0]
     finally:
