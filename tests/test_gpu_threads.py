@@ -54,3 +54,38 @@ def test_four_threads_share_the_library():
     for th in threads:
         th.join(timeout=300)
     assert not errs, errs
+
+
+def test_repeated_small_calls_reuse_their_plan():
+    """the per-thread plan cache of the drop-in calls (_sampling._cached_grid_plan): same values call after call,
+    a changed tree or grid is a new plan, trees with Python callables are never cached, other threads have their own"""
+    import threading
+    import numpy as np
+    import waveforms_amd as wf
+    from oracle import np_oracle
+    from waveforms_amd import _sampling, workloads as wl
+    w = wl.sum_channel(wf, 12, 5)
+    t = np.linspace(0, 12 * wl.SPAN, 5001)
+    ref = np_oracle.call(w, t)
+    _sampling._tls.__dict__.pop('plans', None)
+    a = w(t)
+    n0 = len(_sampling._tls.plans)
+    b = w(t)
+    assert len(_sampling._tls.plans) == n0 == 1 and np.array_equal(a, b) and np.max(np.abs(a - ref)) <= 1e-9
+    w2 = w * 0.5                                   # a new tree: a new plan, the old values stay right
+    assert np.max(np.abs(w2(t) - 0.5 * ref)) <= 1e-9 and len(_sampling._tls.plans) == 2
+    assert np.max(np.abs(w(t[:-1].copy()) - ref[:-1])) <= 1e-9 and len(_sampling._tls.plans) == 3    # another grid
+    w.max = 0.25                                   # clip changed on the same object
+    assert np.max(np.abs(w(t) - np.clip(ref, -np.inf, 0.25))) <= 1e-9
+    w.max = np.inf
+    f = wf.function(np.tanh, start=-1, stop=1) * wf.cos(3.0)
+    n1 = len(_sampling._tls.plans)
+    f(np.linspace(-2, 2, 2001))
+    assert len(_sampling._tls.plans) == n1         # Python callable: not cached
+    for _ in range(40):                            # LRU bound
+        (w * np.random.rand())(t)
+    assert len(_sampling._tls.plans) <= _sampling._PLAN_CACHE_SIZE
+    out = []
+    th = threading.Thread(target=lambda: out.append((w(t), len(_sampling._tls.plans))))
+    th.start(); th.join()
+    assert np.array_equal(out[0][0], a) and out[0][1] == 1

@@ -17,7 +17,7 @@ print(grid, plan.kernel_name(), plan.info.n_direct, plan.info.n_generic, plan.in
 for c, w in enumerate(chans):
     want = FUZZ[f'far{seed}.{c}']
     pk = max(1.0, np.abs(want).max())
-    p2 = _sampling._plan_for_axis(w, t, None)
+    p2, _ = _sampling._plan_for_axis(w, t, None)
     dr = np.real(w(t))
     print(c, 'batch err %.2e  drop-in err %.2e  pk %.2e  drop-in kernel %s' % (np.abs(got[c]-want).max()/pk, np.abs(dr-want).max()/pk, pk, p2.kernel_name()))
     k = int(np.argmax(np.abs(dr - want)))

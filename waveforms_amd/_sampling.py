@@ -86,6 +86,58 @@ def _finish(w, plan, frag, out, accumulate):
     return out
 
 
+# ---- plans of recent grid calls, per thread ---------------------------------------------------------------------
+# A drop-in call on a small grid is host work: flatten 300 us + plan creation 160 us + 45 us of launch and copy for a
+# 100-pulse channel on 1e4 points.  Scripts call the SAME waveform on the SAME grid again and again (a shot loop, a
+# scan that changes another channel): the plan of such a call is kept -- keyed by the identity of the waveform's
+# immutable (bounds, seq) tuples, which the entry keeps alive, and by the grid's numbers -- and the repeat costs the
+# launch alone.  Per thread (a plan owns scratch for its launches), 16 entries, never for trees with Python callables
+# (their values are the callable's business at every call).
+import collections
+import threading
+
+_PLAN_CACHE_SIZE = 16
+_PLAN_CACHE_MAX_N = 1 << 20
+_tls = threading.local()
+
+
+def _tree_key(w):
+    from .waveform import WaveVStack
+    if getattr(w, 'function_lib', None) is not None:
+        return None, None
+    if isinstance(w, WaveVStack):
+        members = tuple(w.wlist)
+        return (('v', w.offset, w.shift) + tuple((id(b), id(s)) for b, s in members)), members
+    return ('w', id(w.bounds), id(w.seq), w.min, w.max), (w.bounds, w.seq)
+
+
+def _cached_grid_plan(w, grid, function_lib):
+    """-> (plan, owned): owned plans are the caller's to close, cached ones stay open"""
+    key, keep = (None, None) if function_lib is not None else _tree_key(w)
+    if int(grid.n) > _PLAN_CACHE_MAX_N:
+        key = None                              # (a cached plan keeps its result buffer on the device: small calls only)
+    if key is None:
+        return _engine.Plan(_flatten.flatten([w], grid, function_lib), grid=grid), True
+    cache = getattr(_tls, 'plans', None)
+    if cache is None:
+        cache = _tls.plans = collections.OrderedDict()
+    from .waveform import _baseFunc
+    key = key + (grid.t0, grid.step, int(grid.n), int(grid.has_last), grid.last, int(grid.i0), len(_baseFunc))
+    hit = cache.get(key)
+    if hit is not None and hit[0]._h:          # (a plan someone closed behind the cache's back is rebuilt)
+        cache.move_to_end(key)
+        return hit[0], False
+    prog = _flatten.flatten([w], grid, None)
+    plan = _engine.Plan(prog, grid=grid)
+    if _flatten.SAMPLED in prog.arrays['fc_type'][:prog.struct.n_factors]:
+        return plan, True                      # a registered Python callable: evaluated afresh at every call
+    cache[key] = (plan, keep)
+    while len(cache) > _PLAN_CACHE_SIZE:
+        _, (old, _keep) = cache.popitem(last=False)
+        old.close()
+    return plan, False
+
+
 def _plan_for_axis(w, t, function_lib, grid=False):
     """x is almost always np.linspace / np.arange output: when it is bit-identical to the grid
     formula (checked element by element in the library) the plan is compiled in grid mode --
@@ -94,8 +146,8 @@ def _plan_for_axis(w, t, function_lib, grid=False):
     if grid is False:                      # (not looked at yet by the caller)
         grid = _engine.detect_grid(t)
     if grid is not None:
-        return _engine.Plan(_flatten.flatten([w], grid, function_lib), grid=grid)
-    return _engine.Plan(_flatten.flatten([w], t, function_lib), t=t)
+        return _cached_grid_plan(w, grid, function_lib)
+    return _engine.Plan(_flatten.flatten([w], t, function_lib), t=t), True
 
 
 def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=None):
@@ -107,11 +159,12 @@ def call_waveform(w, x, frag=False, out=None, accumulate=False, function_lib=Non
         runs = _engine.detect_grid_runs(t, _RUN_MIN)
         if runs is not None:
             return _call_runs(w, t, runs, out, accumulate, function_lib)
-    plan = _plan_for_axis(w, t, function_lib, grid)
+    plan, owned = _plan_for_axis(w, t, function_lib, grid)
     try:
         return _finish(w, plan, frag, out, accumulate)
     finally:
-        plan.close()
+        if owned:
+            plan.close()
 
 
 _RUN_MIN = 4096      # shortest run worth a plan of its own
@@ -157,11 +210,12 @@ def call_vstack(w, x, function_lib=None):
         runs = _engine.detect_grid_runs(t, _RUN_MIN)
         if runs is not None:
             return _call_runs(w, t, runs, None, False, function_lib)
-    plan = _plan_for_axis(w, t, function_lib, grid)
+    plan, owned = _plan_for_axis(w, t, function_lib, grid)
     try:
         return plan.run_host(np.float64)[0]
     finally:
-        plan.close()
+        if owned:
+            plan.close()
 
 
 def _sos_sections(sos):
@@ -238,7 +292,7 @@ def _sample_filtered(w, plan, sos, initial, zi):
 
 def _sample_on_grid(w, grid, out, function_lib, filters=None, zi=None):
     from .waveform import WaveVStack
-    plan = _engine.Plan(_flatten.flatten([w], grid, function_lib), grid=grid)
+    plan, owned = _cached_grid_plan(w, grid, function_lib)
     try:
         if filters is not None:
             sos, initial = filters
@@ -247,7 +301,8 @@ def _sample_on_grid(w, grid, out, function_lib, filters=None, zi=None):
             return plan.run_host(np.float64)[0]
         return _finish(w, plan, False, out, False)
     finally:
-        plan.close()
+        if owned:
+            plan.close()
 
 
 def sample_waveform(w, sample_rate=None, out=None, chunk_size=None, function_lib=None,
