@@ -171,3 +171,33 @@ def test_two_processes_hand_the_iir_state_on():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_more_ranks_than_samples_and_tiny_slices():
+    """edge cases of the time cut: slices of 0 / 1 / 2 samples (world > n), a FIR whose halo is longer than the
+    slice, a grid of one sample; every rank emulated in turn against the whole plan"""
+    import torch
+    w = (wf.gaussian(20e-9) >> 15e-9) * wf.cos(2 * np.pi * 100e6) + 0.25
+    ker = wl.c4_kernel(33)
+    for n, world in ((5, 8), (1, 3), (40, 7), (300, 4)):
+        grid = ('linspace', 0.0, 30e-9, n, False)
+        ref = BatchSampler([w], grid).to_host(np.float64)
+        fref = SampledFir([w], grid, ker).to_host()
+        got, fgot = np.full_like(ref, np.nan), np.full_like(ref, np.nan)
+        for rank in range(world):
+            ts = TimeShardedSampler([w], grid, rank, world)
+            assert ts.n == ts.stop - ts.start
+            out = torch.zeros((1, max(ts.n, 1)), dtype=torch.float64, device='cuda')
+            ts.launch_torch(out)
+            torch.cuda.synchronize()
+            got[:, ts.start:ts.stop] = out.cpu().numpy()[:, :ts.n][:, ts.own]
+            ts.close()
+            tf = TimeShardedFir([w], grid, ker, rank, world)
+            if tf.stop > tf.start:
+                fo = torch.zeros((1, tf.n), dtype=torch.float64, device='cuda')
+                tf.launch_torch(fo)
+                torch.cuda.synchronize()
+                fgot[:, tf.start:tf.stop] = fo.cpu().numpy()[:, tf.own]
+            tf.close()
+        assert np.max(np.abs(got - ref)) <= 1e-12, (n, world)
+        assert np.max(np.abs(fgot - fref)) <= 1e-12, (n, world)

@@ -148,3 +148,17 @@ def test_far_from_the_origin_is_fused_only_where_the_phase_noise_allows():
         assert (info.n_generic == 0) == fused, (t0, info.n_generic, info.n_fused)
         ref = oracle([I], t)
         assert np.max(np.abs(got - ref)) <= 1e-9
+
+
+def test_time_lists_of_zero_one_and_repeated_times():
+    I, _ = wf.mixing(wf.gaussian(20e-9) >> 15e-9, freq=150e6, phase=0.3, DRAGScaling=1e-10)
+    for t in (np.zeros(0), np.array([15e-9]), np.array([15e-9, 15e-9, 15e-9, 16e-9]),
+              np.sort(np.concatenate([np.full(70, 14e-9), np.linspace(0, 30e-9, 130)]))):
+        got, name, info = run([I], t)
+        assert got.shape == (1, len(t))
+        if len(t):
+            ref = oracle([I], t)
+            assert np.max(np.abs(got - ref)) <= 1e-11
+            assert np.max(np.abs(I(t) - ref[0])) <= 1e-11
+        else:
+            assert I(t).shape == (0, )
