@@ -1021,42 +1021,68 @@ __device__ __forceinline__ void sincos_small(double th, double& c, double& s) {
 }
 
 // value of one group at time x (on the channel's own axis); everything wave-uniform comes in by value
-struct FcePoint {
-  double W, sref, slin, sigma, sg, isig;
-  int deg, env;
-  bool carrier, expenv, small;
-};
-__device__ __forceinline__ double fce_point_value(const double* r, const FcePoint& g, double x) {
-  double A = r[WFK_FCE_A], Bq = r[WFK_FCE_B];
-  if (g.deg > 0) {
-    const double u = x - g.slin;
-    A = r[WFK_FCE_A + g.deg];
-    Bq = r[WFK_FCE_B + g.deg];
-    for (int i = g.deg - 1; i >= 0; --i) {
-      A = fma(A, u, r[WFK_FCE_A + i]);
-      Bq = fma(Bq, u, r[WFK_FCE_B + i]);
+// One group over the lane's NS samples, specialised by SHAPE -- polynomial degree <= 1 or cubic, carrier or not,
+// no envelope / Gaussian / exponential -- so that the per-sample code is straight line: the eight samples'
+// dependent chains (range reduction -> polynomials, exponent -> polynomial -> ldexp) are interleaved by the
+// scheduler instead of sitting in eight separate basic blocks behind wave-uniform branches, and the group's
+// coefficients are read from LDS once per group, not per sample.  ENV: 0 none, 1 Gaussian, 2 exponential.
+template <typename T, int NS, bool CPLX, bool CUBIC, bool CARRIER, int ENV>
+__device__ __forceinline__ void fce_point_shape(const double* r, const double (&x)[NS], T (&acc)[NS],
+                                                T (&acci)[CPLX ? NS : 1], bool imag) {
+  // (wave-uniform values read from LDS land in VGPRs: pinned to SGPR pairs, they leave the registers to the samples)
+  auto ud = [](double v) __attribute__((always_inline)) {
+    return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v)));
+  };
+  const double A0 = ud(r[WFK_FCE_A]), A1 = ud(r[WFK_FCE_A + 1]), B0 = ud(r[WFK_FCE_B]), B1 = ud(r[WFK_FCE_B + 1]);
+  const double A2 = CUBIC ? ud(r[WFK_FCE_A + 2]) : 0.0, A3 = CUBIC ? ud(r[WFK_FCE_A + 3]) : 0.0;
+  const double B2 = CUBIC ? ud(r[WFK_FCE_B + 2]) : 0.0, B3 = CUBIC ? ud(r[WFK_FCE_B + 3]) : 0.0;
+  const double W = ud(r[WFK_FCE_W]), sref = ud(r[WFK_FCE_SREF]), slin = ud(r[WFK_FCE_SLIN]);
+  const double sg = ud(r[WFK_FCE_SG]), ea = ud(ENV == 1 ? r[WFK_FCE_H] : r[WFK_FCE_SIGMA]);   // 1 / sigma | alpha
+  constexpr int PB = NS % 4 == 0 ? 4 : 1;    // samples interleaved at a time (2 / 4 / 8: the same 0.58 ms on 64 x 2e6; bounds the live values)
+#pragma unroll
+  for (int k0 = 0; k0 < NS; k0 += PB) {
+  double val[PB];
+#pragma unroll
+  for (int kk = 0; kk < PB; ++kk) {
+    const int k = k0 + kk;
+    const double u = x[k] - slin;
+    double A, Bq;
+    if constexpr (CUBIC) {
+      A = fma(fma(fma(A3, u, A2), u, A1), u, A0);
+      Bq = fma(fma(fma(B3, u, B2), u, B1), u, B0);
+    } else {
+      A = fma(A1, u, A0);                        // (degree 0: A1 = B1 = 0 in the record)
+      Bq = fma(B1, u, B0);
+    }
+    double v = A;
+    if constexpr (CARRIER) {
+      double c, sn;
+      sincos_small(W * (x[k] - sref), c, sn);
+      v = fma(Bq, sn, A * c);
+    }
+    if constexpr (ENV != 0) {
+      double q = (x[k] - sg) * ea;               // Gaussian: (t' - s_g) / sigma; exponential: alpha (t' - ref)
+      if constexpr (ENV == 1) q = -(q * q);
+      v *= exp_inline(q);
+    }
+    val[kk] = v;
+  }
+#pragma unroll
+  for (int kk = 0; kk < PB; ++kk) {
+    const int k = k0 + kk;
+    if constexpr (CPLX) {
+      if (imag) acci[k] += (T)val[kk];
+      else acc[k] += (T)val[kk];
+    } else {
+      acc[k] += (T)val[kk];
     }
   }
-  double v = A;
-  if (g.carrier) {
-    const double th = g.W * (x - g.sref);
-    double c, s;
-    if (g.small) sincos_small(th, c, s);
-    else { const double2 cs = sincos_phase(th); c = cs.x; s = cs.y; }      // (out of line: two-term 1/pi reduction)
-    v = fma(Bq, s, A * c);
+  __builtin_amdgcn_sched_barrier(0);
   }
-  if (g.env == 1) {
-    const double d = x - g.sg;
-    double q = g.sigma * d;                                                // exp(alpha (t' - ref))
-    if (!g.expenv) { q = d * g.isig; q = -(q * q); }                       // exp(-((t' - s_g)/sigma)^2); 1 / sigma from the host
-    v *= exp_inline(q);
-  }
-  return v;
 }
 
-// One group over the lane's NS samples (the pointwise-ops-only build of the general kernel; a time-list plan
-// that also holds generic terms runs as two launches: this build takes the fully fused pieces, the build
-// with the direct tier the others).
+// (the pointwise-ops-only build of the general kernel; a time-list plan that also holds generic terms runs as two
+// launches: this build takes the fully fused pieces, the build with the direct tier the others)
 template <typename T, int NS, bool CPLX>
 __device__ __forceinline__ void fce_point(const double* r, const double (&x)[NS], T (&acc)[NS],
                                           T (&acci)[CPLX ? NS : 1]) {
@@ -1064,10 +1090,9 @@ __device__ __forceinline__ void fce_point(const double* r, const double (&x)[NS]
   const int deg = fl & 3, env = (fl >> 4) & 3;
   const bool carrier = (fl & 4) != 0, imag = (fl & 8) != 0;
   if (imag && !CPLX) return;                       // a real-output launch drops the imaginary groups
-  const double sigma = r[WFK_FCE_SIGMA], sg = r[WFK_FCE_SG];
   if (env == 3) {
     // closing op of a piece whose carriers share one Gaussian: multiply what they accumulated by it
-    const double isig = r[WFK_FCE_H];
+    const double sg = r[WFK_FCE_SG], isig = r[WFK_FCE_H];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const double v = (x[k] - sg) * isig;
@@ -1077,21 +1102,40 @@ __device__ __forceinline__ void fce_point(const double* r, const double (&x)[NS]
     }
     return;
   }
-  FcePoint g;
-  g.W = r[WFK_FCE_W]; g.sref = r[WFK_FCE_SREF]; g.slin = r[WFK_FCE_SLIN]; g.sigma = sigma; g.sg = sg;
-  g.isig = r[WFK_FCE_H];
-  g.deg = deg; g.env = env; g.carrier = carrier; g.expenv = (fl & WFK_FCE_EXPENV) != 0;
-  g.small = (fl & WFK_FCE_TLSMALL) != 0;
-#pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    const T v = (T)fce_point_value(r, g, x[k]);
-    if constexpr (CPLX) {
-      if (imag) acci[k] += v;
-      else acc[k] += v;
-    } else {
-      acc[k] += v;
+  const int ev = env == 0 ? 0 : ((fl & WFK_FCE_EXPENV) ? 2 : 1);
+  if (carrier && !(fl & WFK_FCE_TLSMALL)) {
+    // a phase beyond 1.6e6 rad (never with the rounding budget of a time list unless s_ref lies far outside the
+    // piece): the two-term 1/pi reduction, out of line, sample by sample
+    const double W = r[WFK_FCE_W], sref = r[WFK_FCE_SREF], slin = r[WFK_FCE_SLIN], sg = r[WFK_FCE_SG];
+    const double ea = ev == 1 ? r[WFK_FCE_H] : r[WFK_FCE_SIGMA];
+#pragma unroll 1
+    for (int k = 0; k < NS; ++k) {
+      const double u = x[k] - slin;
+      double A = r[WFK_FCE_A + 3], Bq = r[WFK_FCE_B + 3];
+      for (int i = 2; i >= 0; --i) { A = fma(A, u, r[WFK_FCE_A + i]); Bq = fma(Bq, u, r[WFK_FCE_B + i]); }
+      const double2 cs = sincos_phase(W * (x[k] - sref));
+      double v = fma(Bq, cs.y, A * cs.x);
+      if (ev) { double q = (x[k] - sg) * ea; if (ev == 1) q = -(q * q); v *= exp_inline(q); }
+      // (NS is 1 or 8: a rolled loop over a register array needs compile-time indices)
+      static_for<NS>([&](auto kk) __attribute__((always_inline)) {
+        if (decltype(kk)::value == k) {
+          if constexpr (CPLX) { if (imag) acci[decltype(kk)::value] += (T)v; else acc[decltype(kk)::value] += (T)v; }
+          else acc[decltype(kk)::value] += (T)v;
+        }
+      });
     }
+    return;
   }
+  const bool cubic = deg > 1;
+#define WFK_PT(CU, CA, EN) fce_point_shape<T, NS, CPLX, CU, CA, EN>(r, x, acc, acci, imag)
+  if (!cubic) {
+    if (carrier) { if (ev == 1) WFK_PT(false, true, 1); else if (ev == 2) WFK_PT(false, true, 2); else WFK_PT(false, true, 0); }
+    else { if (ev == 1) WFK_PT(false, false, 1); else if (ev == 2) WFK_PT(false, false, 2); else WFK_PT(false, false, 0); }
+  } else {
+    if (carrier) { if (ev == 1) WFK_PT(true, true, 1); else if (ev == 2) WFK_PT(true, true, 2); else WFK_PT(true, true, 0); }
+    else { if (ev == 1) WFK_PT(true, false, 1); else if (ev == 2) WFK_PT(true, false, 2); else WFK_PT(true, false, 0); }
+  }
+#undef WFK_PT
 }
 
 template <typename T> struct OutOps;
