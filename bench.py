@@ -243,11 +243,6 @@ def _c_oracle_worker(job):
     return float(y.sum())
 
 
-def wf_mod():
-    import waveforms_amd
-    return waveforms_amd
-
-
 def host_cpu_share():
     """-> (cores this process may use, cores of the host).  A GPU box hands each GPU a share of the host
     (cgroup quota and / or affinity mask): os.cpu_count() is the host, not the share."""
@@ -778,10 +773,11 @@ def run_rank(args):
         # ---- tiers beside the BASELINE configs: explicit non-uniform sample times (the tlist tier: what any `x`
         # that is not np.linspace / np.arange output takes; 16 B/sample, t is read), primitives without a
         # recurrence form (direct tier) and 10-tone multiplexed pulses; kernel time by HIP events
+        import waveforms_amd as wfm
         from waveforms_amd import _flatten
         stream = torch.cuda.current_stream().cuda_stream
         tt = wl.jittered_times()
-        tch = [wl.sum_channel(wf_mod(), 100, 1000 + c) for c in range(64)]
+        tch = [wl.sum_channel(wfm, 100, 1000 + c) for c in range(64)]
         tplan = _engine.Plan(_flatten.flatten(tch), t=tt)
         o2 = torch.empty((64, len(tt)), device='cuda', dtype=torch.float64)
         ms = timed(lambda: tplan.launch(o2.data_ptr(), len(tt), _engine.OUT_F64, stream=stream), 20, 3)
@@ -796,7 +792,7 @@ def run_rank(args):
         del o2
         direct = {}
         for shape in ('sinc', 'mollifier', 'interp'):
-            b2 = BatchSampler([wl.direct_channel(wf_mod(), shape, c) for c in range(8)], ('linspace', 0.0, wl.DIRECT_T, 10**7, False), tile=8)
+            b2 = BatchSampler([wl.direct_channel(wfm, shape, c) for c in range(8)], ('linspace', 0.0, wl.DIRECT_T, 10**7, False), tile=8)
             o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)
             ms = timed(lambda: b2.launch_torch(o2), 5, 2)
             nb = b2.n_channels * b2.n * 8
@@ -808,7 +804,7 @@ def run_rank(args):
         direct['workload'] = ('64 rows (8 distinct x 8) x 1e7 pts over 3 us: 25 overlapping sinc pulses / 100 mollifier pulses / '
                               '100 samplingPoints envelopes of 1000 knots under carriers')
         also['direct'] = direct
-        b2 = BatchSampler([wl.multitone_channel(wf_mod(), c) for c in range(8)], wl.c2_grid(), tile=8)
+        b2 = BatchSampler([wl.multitone_channel(wfm, c) for c in range(8)], wl.c2_grid(), tile=8)
         o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)
         ms = timed(lambda: b2.launch_torch(o2), 10, 3)
         nb = b2.n_channels * b2.n * 8

@@ -9,6 +9,10 @@ API (no reference counterpart): many channels, one launch, output left in HBM.
 """
 from __future__ import annotations
 
+import collections
+import os
+import threading
+
 import numpy as np
 
 from . import _engine, _flatten
@@ -93,9 +97,6 @@ def _finish(w, plan, frag, out, accumulate):
 # immutable (bounds, seq) tuples, which the entry keeps alive, and by the grid's numbers -- and the repeat costs the
 # launch alone.  Per thread (a plan owns scratch for its launches), 16 entries, never for trees with Python callables
 # (their values are the callable's business at every call).
-import collections
-import threading
-
 _PLAN_CACHE_SIZE = 16
 _PLAN_CACHE_MAX_N = 1 << 20
 _tls = threading.local()
@@ -172,7 +173,7 @@ _RUN_MIN = 4096      # shortest run worth a plan of its own
 # evaluates fused groups pointwise it is the faster way (1e7 points in four runs: 11.7 ms run by run -- 8 ms of
 # it the host's run detection -- against 4.2 ms as ONE time list, tools/big_call_latency.py); the run path is
 # kept for callers who want the grid tiers' values (and as the place the library's run detector is exercised).
-_RUNS_ON = __import__('os').environ.get('WFK_GRID_RUNS') == '1'
+_RUNS_ON = os.environ.get('WFK_GRID_RUNS') == '1'
 
 
 def _call_runs(w, t, runs, out, accumulate, function_lib):
