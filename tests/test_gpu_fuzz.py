@@ -107,9 +107,9 @@ def test_far_from_origin_vs_reference_golden(seed):
 
 def test_float_cancellation_case_stays_inside_the_contract():
     """tools/fuzz_soak.py awg, seed 306405 (the one float-output exception of 54 000 round-4 soak scripts): a piece whose
-    terms cancel to ~1e-3 of their size, evaluated by the general kernel's float build -- float accumulators lose the
-    cancellation factor x 6e-8.  fp64 must hold 1e-9; the float launch must stay inside BASELINE's 1e-3 (measured 9.2e-5:
-    above cases.FP32_TOL, which every other test and soak script holds)."""
+    terms cancel to ~1e-3 of their size.  Evaluated by the general kernel's float build it measured 9.2e-5 of the peak
+    (float accumulators lose the cancellation factor x 6e-8); float outputs of that tier now run under double arithmetic
+    (wfk_sample_wide) and round once at the store."""
     rng = np.random.default_rng(10_000 + 306405)
     ch, grid = cases.random_awg_channel(wf, rng)
     prog = _flatten.flatten([ch])
@@ -118,6 +118,6 @@ def test_float_cancellation_case_stays_inside_the_contract():
     pk = max(1.0, float(np.abs(ora).max()))
     plan = _engine.Plan(prog, grid=g)
     assert np.max(np.abs(plan.run_host(np.float64)[0] - ora)) <= 1e-9 * pk
+    assert 'wfk_sample_wide<' in plan.kernel_name(np.float32)
     e32 = float(np.max(np.abs(plan.run_host(np.float32)[0] - ora)))
-    assert e32 <= 1e-3 * pk
-    assert e32 <= 2e-4 * pk, e32          # what it measures today (9.2e-5); a jump beyond this is a regression
+    assert e32 <= 2e-7 * pk, e32          # one rounding to float

@@ -319,11 +319,18 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
   const char* T = (out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64) ? "float" : "double";
   const char* cplx = (out_kind == WFK_OUT_C128 || out_kind == WFK_OUT_C64) ? "true" : "false";
   const HostPlan& h = p->h;
+  const bool f32 = out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64;
+  // the general kernel's symbol: float outputs of plans with generic terms and of time lists run the builds with
+  // double arithmetic (wfk_sample_wide)
+  auto general = [&](bool tl, bool g, bool d, int ns) {
+    const std::string tail = std::string(cplx) + "," + (tl ? "true" : "false") + "," + (g ? "true" : "false") + "," +
+                             (d ? "true" : "false") + "," + std::to_string(ns) + ">";
+    return f32 && (tl || g || d) ? "wfk_sample_wide<" + tail : std::string("wfk_sample<") + T + "," + tail;
+  };
   if (h.shortp) {
     name = std::string("wfk_sample_short<") + T + "," + cplx + ",false," + std::to_string(WFK_SH_R) + ">";
     if (h.mixed)      // pieces the short tier cannot take: a second launch of the general kernel
-      name += std::string(" + wfk_sample<") + T + "," + cplx + ",false," + (h.n_direct > 0 || h.n_generic > 0 ? "true" : "false") +
-              "," + (h.n_direct > 0 ? "true" : "false") + "," + std::to_string(h.ns) + ">";
+      name += " + " + general(false, h.n_direct > 0 || h.n_generic > 0, h.n_direct > 0, h.ns);
     return name.c_str();
   }
   const std::string lean_name = std::string("wfk_sample_lean<") + T + "," + cplx + "," + std::to_string(h.ns) +
@@ -337,11 +344,8 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
     //  the build with the direct tier, as before)
     const bool tl_full = h.tlist && (h.n_direct > 0 || h.n_generic > 0);
     const bool direct = tl_full || (!h.tlist && h.n_direct > 0), generic = direct || (!h.tlist && h.n_generic > 0);
-    name = std::string("wfk_sample<") + T + "," + cplx + "," + (h.tlist ? "true" : "false") + "," +
-           (generic ? "true" : "false") + "," + (direct ? "true" : "false") + "," +
-           std::to_string(h.ns) + ">";
-    if (h.mixed && h.tlist)
-      name = std::string("wfk_sample<") + T + "," + cplx + ",true,false,false," + std::to_string(h.ns) + "> + " + name;
+    name = general(h.tlist, generic, direct, h.ns);
+    if (h.mixed && h.tlist) name = general(true, false, false, h.ns) + " + " + name;
     else if (h.mixed) name = lean_name + " + " + name;   // two launches over disjoint pieces
   }
   return name.c_str();

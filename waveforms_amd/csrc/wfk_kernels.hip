@@ -83,12 +83,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define WFK_EACH(N, k) static_for<N>([&](auto k##_) __attribute__((always_inline)) { constexpr int k = decltype(k##_)::value;
 #define WFK_END });
 
-// t[j] = fl(fl(j*step) + t0): NumPy's linspace/arange element formula, two roundings.
+// t[j] = fl(fl(j*step) + t0): NumPy's linspace / arange element formula, two roundings.
+// SLICE (wfk_grid.i0 != 0: the plan is a time slice of a longer grid): the index is that of the caller's FULL grid.
+// The general kernel is instantiated for both; whole grids run the code they always ran -- one more operation in
+// here (a 64-bit add, a double add, anything) moves the register allocation of the complex double build of the direct
+// tier, which sits at its 256 registers, from 37 to 700-840 spilled ones (0.80 -> 1.48 ms on tools/cplx_direct_bench.py).
+template <bool SLICE = true>
 __device__ __forceinline__ double grid_time(const KArgs& a, int64_t j) {
 #pragma clang fp contract(off)
   // (int64 -> double is a multi-instruction sequence on this ISA, uint32 -> double is one: the
   //  per-sample callers of the direct tier feel it; both conversions are exact)
-  const double dj = (a.i0 == 0 && a.n <= 0xffffffffLL) ? (double)(uint32_t)j : (double)(j + a.i0);   // (i0: wave-uniform)
+  double dj;
+  if constexpr (SLICE) dj = (double)(j + a.i0);
+  else dj = a.n <= 0xffffffffLL ? (double)(uint32_t)j : (double)j;
   double m = dj * a.step;
   double t = m + a.t0;
   if (a.has_last && j == a.n - 1) t = a.last;
@@ -159,13 +166,13 @@ __device__ __forceinline__ double exp_inline(double x) {
   return e;
 }
 
-template <bool TLIST>
+template <bool TLIST, bool SLICE = true>
 __device__ __forceinline__ double time_at(const KArgs& a, int64_t j) {
   if (TLIST) {
     int64_t jj = j < a.n ? j : a.n - 1;
     return a.tlist[jj];
   }
-  return grid_time(a, j);
+  return grid_time<SLICE>(a, j);
 }
 
 // ---- direct primitives (device libm), evaluated at u = t - shift ----------------
@@ -375,7 +382,7 @@ __device__ double np_power(double v, double n) {
 
 // ---- one factor over the wave tile: prod[k] *= f(t_k - shift)^power -------------
 // blk: LDS parameter block, r: this factor's record inside it, j0: lane's first sample.
-template <typename T, bool TLIST, bool DIRECT, int NS>
+template <typename T, bool TLIST, bool DIRECT, int NS, bool SLICE>
 __device__ __forceinline__ void apply_factor(const double* blk, const double* r, const KArgs& a,
                                              double tshift, int64_t j0, T (&prod)[NS],
                                              double* s_val) {
@@ -390,7 +397,7 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
   }
   if (!TLIST && mode >= 100) {
     // seed at the lane's first sample, evaluated exactly as the reference does
-    double x = grid_time(a, j0);
+    double x = grid_time<SLICE>(a, j0);
     if (tshift != 0.0) x = x - tshift;
     const double u0 = x - shift;
     if (mode == WFK_M_COS_TAB) {
@@ -474,6 +481,9 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
         const double qq = q < -1e-300 ? q : -1.0;                     // (outside the support: any harmless argument)
         const double v = exp_inline(rcp_nr(qq) + 1.0);
         prod[k] *= (T)(q < 0.0 ? v : 0.0);
+        // (four samples interleaved at most: with all 16 exponentials in flight the complex double build of the
+        //  direct tier, already at its 256 registers, spilled 700)
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     } else if (mode == WFK_M_INTERP_LIN) {
       // np.interp on linspace knots with a finite table (reference _waveform.pyx:309-311), as a continuous
@@ -522,7 +532,7 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           if (k0 + kk < NS) {
-            double x = grid_time(a, j0 + 64 * (int64_t)(k0 + kk));
+            double x = grid_time<SLICE>(a, j0 + 64 * (int64_t)(k0 + kk));
             if (tshift != 0.0) x = x - tshift;
             x = x - shift;
             int j;
@@ -588,7 +598,7 @@ __device__ __forceinline__ void apply_factor(const double* blk, const double* r,
   } else {
 #pragma unroll 1
     for (int k = 0; k < NS; ++k) {
-      double x = time_at<TLIST>(a, j0 + 64 * (int64_t)k);
+      double x = time_at<TLIST, SLICE>(a, j0 + 64 * (int64_t)k);
       if (tshift != 0.0) x = x - tshift;
       double v = prim_direct(mode, x - shift, r, a.pool);
       if (has_pw) v = np_power(v, pw);
@@ -978,10 +988,10 @@ __device__ __forceinline__ void chirp_loop(const double* r, ChirpSeeds& sd, doub
   sd.c = c; sd.s = s; sd.wc = wc; sd.ws = ws; sd.g = g; sd.r = rr;
 }
 
-template <typename T, int NS>
+template <typename T, int NS, bool SLICE>
 __device__ __forceinline__ void apply_fce(const double* blk, const double* r, const KArgs& a,
                                           double tshift, int64_t j0, T (&acc)[NS]) {
-  double x = grid_time(a, j0);
+  double x = grid_time<SLICE>(a, j0);
   if (tshift != 0.0) x = x - tshift;
   const int fl = uni(WFK_FCE_WORD(r));
   FceSeeds sd = fce_make_seeds(r, x, fl);
@@ -1173,13 +1183,14 @@ __device__ __forceinline__ void clip_np_cplx(T& re, T& im, T lo, T hi) {
 // NT: non-temporal stores.  A loss for the plain lean kernel (headline 3.45 -> 3.52 ms, C3 0.199 -> 0.207 on one
 // box) but a gain for its CORR variant, which runs fewer waves per SIMD and keeps re-reading nothing the stream
 // could evict (dense far-from-origin workload 0.93 -> 0.84 ms, same box): used there only.
-template <typename T, bool CPLX, int NS, bool PLAIN, bool NT = false>
+// E: element type of the output (T, or float under double arithmetic: the "wide" builds of the general kernel)
+template <typename T, bool CPLX, int NS, bool PLAIN, bool NT = false, typename E = T>
 __device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel& C,
-                                                const DevPiece& P, typename OutOps<T>::Real* tr,
-                                                typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
+                                                const DevPiece& P, typename OutOps<E>::Real* tr,
+                                                typename OutOps<E>::Cplx* tc, int64_t w0, int lane,
                                                 const T (&acc)[NS],
                                                 const T (&acci)[CPLX ? NS : 1]) {
-  using OutC = typename OutOps<T>::Cplx;
+  using OutC = typename OutOps<E>::Cplx;
   constexpr int WT = 64 * NS;
   const T base = (T)C.offset;
   const bool clip = !PLAIN && C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
@@ -1199,14 +1210,14 @@ __device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel
       }
       v += base;
       if constexpr (CPLX) {
-        OutC w;
-        w.x = v;
-        w.y = vi;
         if (accum) {
           const OutC old = tc[o];
-          w.x += old.x;
-          w.y += old.y;
+          v += (T)old.x;
+          vi += (T)old.y;
         }
+        OutC w;
+        w.x = (E)v;
+        w.y = (E)vi;
         if constexpr (NT) {
           __builtin_nontemporal_store(w.x, &tc[o].x);
           __builtin_nontemporal_store(w.y, &tc[o].y);
@@ -1214,25 +1225,25 @@ __device__ __forceinline__ void store_tile_impl(const KArgs& a, const DevChannel
           tc[o] = w;
         }
       } else {
-        if (accum) v += tr[o];
-        if constexpr (NT) __builtin_nontemporal_store(v, &tr[o]);
-        else tr[o] = v;
+        if (accum) v += (T)tr[o];
+        if constexpr (NT) __builtin_nontemporal_store((E)v, &tr[o]);
+        else tr[o] = (E)v;
       }
     }
   WFK_END
 }
 
-template <typename T, bool CPLX, int NS, bool NT = false>
+template <typename T, bool CPLX, int NS, bool NT = false, typename E = T>
 __device__ __forceinline__ void store_tile(const KArgs& a, const DevChannel& C, const DevPiece& P,
-                                           typename OutOps<T>::Real* tr,
-                                           typename OutOps<T>::Cplx* tc, int64_t w0, int lane,
+                                           typename OutOps<E>::Real* tr,
+                                           typename OutOps<E>::Cplx* tc, int64_t w0, int lane,
                                            const T (&acc)[NS], const T (&acci)[CPLX ? NS : 1]) {
   const bool full = P.start <= w0 && P.stop >= w0 + 64 * NS;
   const bool clip = C.do_clip && (P.flags & WFK_PF_HAS_TERMS);
   if (full && !clip && !a.accumulate)
-    store_tile_impl<T, CPLX, NS, true, NT>(a, C, P, tr, tc, w0, lane, acc, acci);
+    store_tile_impl<T, CPLX, NS, true, NT, E>(a, C, P, tr, tc, w0, lane, acc, acci);
   else
-    store_tile_impl<T, CPLX, NS, false, NT>(a, C, P, tr, tc, w0, lane, acc, acci);
+    store_tile_impl<T, CPLX, NS, false, NT, E>(a, C, P, tr, tc, w0, lane, acc, acci);
 }
 
 // XCD-aware workgroup -> chunk map.  Workgroups are dealt round-robin to the 8 XCDs
@@ -1448,13 +1459,16 @@ template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
 // (the build with direct primitives inlines all of device libm's shapes: left alone it takes 280 VGPRs = ONE
 // workgroup per CU, one wave per SIMD walking serial libm chains; capped at 256 it runs two: direct tier 1.8x.
 // The tlist builds (no fused code, 8 samples per lane) fit three at 168: 4.80 -> 3.45 ms on 64 x 2e6 times.)
-__global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENERIC) ? 2 : 1)) wfk_sample(const KArgs a) {
+__global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENERIC) ? 2 : 1)) wfk_sample(const KArgs a);
+// the body, shared with wfk_sample_wide: T arithmetic / accumulators, E elements of the output
+template <typename T, typename E, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS, bool SLICE>
+__device__ __forceinline__ void wfk_sample_body(const KArgs& a) {
   __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
   __shared__ double s_val[DIRECT ? NS * WFK_WG : 1];   // direct-factor values (apply_factor)
   constexpr int WT = 64 * NS;
   constexpr int TILE = WFK_WG * NS;
-  using OutR = typename OutOps<T>::Real;
-  using OutC = typename OutOps<T>::Cplx;
+  using OutR = typename OutOps<E>::Real;
+  using OutC = typename OutOps<E>::Cplx;
 
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
@@ -1536,15 +1550,15 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENER
             if (!TLIST && kind == WFK_OP_FCE) {
               const int fl = uni(WFK_FCE_WORD(s_par + pos));
               if (((fl >> 4) & 3) == 3) {
-                double x = grid_time(a, j0);
+                double x = grid_time<SLICE>(a, j0);
                 if (C.tshift != 0.0) x = x - C.tshift;
                 FceSeeds sd = fce_make_seeds(s_par + pos, x, fl);
                 if (fl & 3) fce_erfmul<T, NS, CPLX>(s_par + pos, sd, x, acc, acci);
                 else fce_envmul<T, NS, CPLX>(s_par + pos, sd, acc, acci);
               } else if (fl & 8) {
-                if constexpr (CPLX) apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acci);
+                if constexpr (CPLX) apply_fce<T, NS, SLICE>(s_par, s_par + pos, a, C.tshift, j0, acci);
               } else {
-                apply_fce<T, NS>(s_par, s_par + pos, a, C.tshift, j0, acc);
+                apply_fce<T, NS, SLICE>(s_par, s_par + pos, a, C.tshift, j0, acc);
               }
               pos += WFK_FCE_REC;
               continue;
@@ -1557,7 +1571,7 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENER
 #pragma unroll
             for (int i = 0; i < NS; ++i) prod[i] = (T)1;
             for (int f = 0; f < nf; ++f) {
-              apply_factor<T, TLIST, DIRECT, NS>(s_par, s_par + pos, a, C.tshift, j0, prod, s_val);
+              apply_factor<T, TLIST, DIRECT, NS, SLICE>(s_par, s_par + pos, a, C.tshift, j0, prod, s_val);
               pos += WFK_FREC;
             }
 #pragma unroll
@@ -1573,9 +1587,32 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENER
       }
 
       if (active)
-        store_tile<T, CPLX, NS>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
+        store_tile<T, CPLX, NS, false, E>(a, C, P, uniptr(outr + w0), uniptr(outc + w0), w0, lane, acc, acci);
     }
   }
+}
+
+template <typename T, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
+__global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENERIC) ? 2 : 1)) wfk_sample(const KArgs a) {
+  wfk_sample_body<T, T, CPLX, TLIST, GENERIC, DIRECT, NS, false>(a);
+}
+// the same for a plan that is a time slice of a longer grid (wfk_grid.i0 != 0; grid plans only: a time list carries its times)
+template <typename T, bool CPLX, bool GENERIC, bool DIRECT, int NS>
+__global__ void __launch_bounds__(WFK_WG, (DIRECT || GENERIC) ? 2 : 1) wfk_sample_slice(const KArgs a) {
+  wfk_sample_body<T, T, CPLX, false, GENERIC, DIRECT, NS, true>(a);
+}
+
+// Float (complex64) output under DOUBLE arithmetic: what a float launch of a plan with generic terms, or of a time list,
+// runs.  These tiers are bound by instruction issue, where unpacked fp32 costs what fp64 costs, so float accumulators
+// bought nothing -- and they lose the cancellation factor x 6e-8 where a piece's terms cancel (tools/fuzz_soak.py awg,
+// seed 306405: terms 1e3 x the result, 9.2e-5 of the peak in float; 6e-8 here).  The fused tiers keep their float forms.
+template <bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS>
+__global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENERIC) ? 2 : 1)) wfk_sample_wide(const KArgs a) {
+  wfk_sample_body<double, float, CPLX, TLIST, GENERIC, DIRECT, NS, false>(a);
+}
+template <bool CPLX, bool GENERIC, bool DIRECT, int NS>
+__global__ void __launch_bounds__(WFK_WG, (DIRECT || GENERIC) ? 2 : 1) wfk_sample_wide_slice(const KArgs a) {
+  wfk_sample_body<double, float, CPLX, false, GENERIC, DIRECT, NS, true>(a);
 }
 
 template <typename T, bool CPLX, bool TLIST, int NS>
@@ -1596,6 +1633,23 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
       else hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 0>), g, dim3(64), lds, s, a);
       return hipGetLastError() == hipSuccess ? 0 : -1;
     }
+  }
+  if constexpr (!TLIST) {
+    if (a.i0 != 0) {                     // a time slice of a longer grid: the builds that offset the sample index
+      if constexpr (sizeof(T) == 4) {
+        if (direct) { hipLaunchKernelGGL((wfk_sample_wide_slice<CPLX, true, true, NS>), g, b, 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -1; }
+        if (generic) { hipLaunchKernelGGL((wfk_sample_wide_slice<CPLX, true, false, NS>), g, b, 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -1; }
+      }
+      if (direct) hipLaunchKernelGGL((wfk_sample_slice<T, CPLX, true, true, NS>), g, b, 0, s, a);
+      else if (generic) hipLaunchKernelGGL((wfk_sample_slice<T, CPLX, true, false, NS>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((wfk_sample_slice<T, CPLX, false, false, NS>), g, b, 0, s, a);
+      return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+  }
+  if constexpr (sizeof(T) == 4) {        // float / complex64 outputs of these tiers: double arithmetic (wfk_sample_wide)
+    if (TLIST && !generic && !direct) { hipLaunchKernelGGL((wfk_sample_wide<CPLX, TLIST, false, false, NS>), g, b, 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -1; }
+    if (TLIST || direct) { hipLaunchKernelGGL((wfk_sample_wide<CPLX, TLIST, true, true, NS>), g, b, 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -1; }
+    if (generic) { hipLaunchKernelGGL((wfk_sample_wide<CPLX, false, true, false, NS>), g, b, 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -1; }
   }
   if (TLIST && !generic && !direct)      // every term of the plan fused: pointwise ops only, no libm shapes of the direct tier
     hipLaunchKernelGGL((wfk_sample<T, CPLX, TLIST, false, false, NS>), g, b, 0, s, a);
