@@ -1,0 +1,143 @@
+"""Stateless closing multipliers of the lean kernel (family 3): a piece whose terms share ONE
+`samplingPoints` table (INTERP, reference _waveform.pyx:309-311: np.interp on linspace knots) or ONE mollifier
+(_waveform.pyx:359-363) runs its carriers as fused ops and multiplies what they accumulated by that envelope --
+one 16-byte gather or one inline exponential per sample instead of a term-by-term pass of the general kernel.
+Checked against the C oracle and against the same plan with the multipliers off (WFK_DISABLE_FMUL=1)."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import FP32_TOL
+import waveforms_amd as wf
+from oracle import c_oracle
+from waveforms_amd import _engine, _flatten, workloads as wl
+from waveforms_amd.waveform import _window, primitive, INTERP
+
+pytestmark = pytest.mark.gpu
+SPAN = wl.SPAN
+
+
+def run(chans, grid, dtype=np.float64, env=None):
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        plan = _engine.Plan(_flatten.flatten(chans), grid=_flatten.grid_from_desc(grid))
+        return plan.run_host(dtype), plan.kernel_name(dtype), plan.info
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def oracle(chans, grid, cplx=False):
+    return c_oracle.eval_grid(_flatten.flatten(chans), _flatten.grid_from_desc(grid), cplx)
+
+
+def hann(m=1000, a=1.0):
+    return wf.samplingPoints(-SPAN / 2, SPAN / 2, np.hanning(m) * a)
+
+
+GRID = ('linspace', 0.0, 3e-6, 1_500_000, False)
+
+
+def both_ways(chans, grid=GRID, tol=1e-12, cplx=False, fam3=True):
+    dt = np.complex128 if cplx else np.float64
+    got, name, info = run(chans, grid, dt)
+    if fam3:
+        assert name.startswith('wfk_sample_lean<') and name.endswith(',3>'), name
+        assert info.n_generic == 0 and info.n_direct == 0
+    ref = oracle(chans, grid, cplx)
+    pk = max(1.0, np.abs(ref).max())
+    err = np.max(np.abs(got - ref))
+    assert err <= tol * pk, (err, pk)
+    off, name_off, info_off = run(chans, grid, dt, env={'WFK_DISABLE_FMUL': '1'})
+    assert ',3>' not in name_off and info_off.n_generic > 0
+    assert np.max(np.abs(off - ref)) <= 1e-12 * pk
+    return got, ref
+
+
+def test_bench_shapes():
+    """bench.py's `direct_interp` and `direct_mollifier` rows (workloads.direct_channel)."""
+    for shape in ('interp', 'mollifier'):
+        chans = [wl.direct_channel(wf, shape, c) for c in range(2)]
+        both_ways(chans)
+
+
+def test_table_under_several_carriers_and_next_to_other_terms():
+    env = hann()
+    chans = [
+        (env * (wf.cos(2e9) + 0.3 * wf.cos(3e9, 0.3))) >> 1e-6,                       # two carriers, one multiplier
+        ((env * wf.cos(2e9)) >> 1e-6) + (wf.gaussian(20e-9) >> 1.005e-6),             # unmodulated terms behind it
+        (hann(17, 0.7) >> 0.5e-6) + (hann(4096) * wf.cos(1e9, 1.0) >> 2e-6),          # coarse and fine tables
+        0.25 * env >> 2.5e-6,                                                         # the table alone
+    ]
+    both_ways(chans)
+
+
+def test_clamped_continuation_and_offsets():
+    """np.interp holds the end values outside [start, stop]; a window wider than the table samples that."""
+    pts = tuple(np.linspace(0.2, 1.0, 33) ** 2)
+    w = _window(-40e-9, 50e-9, primitive(INTERP, -10e-9, 20e-9, pts)) >> 1e-6
+    chans = [w, (w * wf.cos(5e8)) + 0.1, (w >> 1e-6) * 2 - 0.5]
+    got, ref = both_ways(chans)
+    g = np.linspace(0.0, 3e-6, 1_500_000, endpoint=False)
+    left = (g > 1e-6 - 39e-9) & (g < 1e-6 - 11e-9)
+    assert np.all(got[0][left] == pts[0]) and np.all(ref[0][left] == pts[0])
+
+
+def test_mollifier_with_plateau_and_carrier():
+    chans = [
+        wf.mollifier(20e-9, plateau=30e-9) >> 1e-6,
+        (wf.mollifier(40e-9) * wf.cos(2e9, 0.4)) >> 2e-6,
+        (0.5 * wf.mollifier(40e-9) * (wf.cos(2e9) + wf.cos(2.5e9))) >> 0.5e-6,
+    ]
+    both_ways(chans)
+
+
+def test_complex_amplitudes_and_float_outputs():
+    env = hann()
+    chans = [((0.5 + 0.3j) * env * wf.cos(2e9)) >> 1e-6, ((0.2 - 0.1j) * wf.mollifier(30e-9) * wf.cos(1e9)) >> 2e-6]
+    got, ref = both_ways(chans, cplx=True)
+    re, name, _ = run(chans, GRID, np.float64)                                  # real launch of complex channels
+    assert name.endswith(',3>') and np.max(np.abs(re - ref.real)) <= 1e-12
+    c64, name64, _ = run(chans, GRID, np.complex64)
+    assert name64.startswith('wfk_sample_lean<float,true') and name64.endswith(',3>')
+    assert np.max(np.abs(c64 - ref)) <= FP32_TOL
+    chans = [wl.direct_channel(wf, 'interp'), wl.direct_channel(wf, 'mollifier')]
+    f32, name32, _ = run(chans, GRID, np.float32)
+    assert name32.startswith('wfk_sample_lean<float,false') and name32.endswith(',3>')
+    ref = oracle(chans, GRID)
+    assert np.max(np.abs(f32 - ref)) <= FP32_TOL * np.abs(ref).max()
+
+
+def test_what_the_multiplier_does_not_take():
+    """Two different tables in one piece, a table to a power, non-finite table values, derivative orders of the
+    mollifier: the general kernel's per-factor paths, as before."""
+    env = hann()
+    for w in ((env * hann(100)) >> 1e-6,
+              (env ** 2) >> 1e-6,
+              wf.samplingPoints(-SPAN / 2, SPAN / 2, np.r_[np.hanning(50), np.inf, np.hanning(50)]) >> 1e-6,
+              wf.mollifier(20e-9, d=1) >> 1e-6,
+              ((env >> 1e-6) * wf.cos(2e9)) + (hann(100) >> 1.004e-6)):      # (two tables where the pulses overlap only)
+        got, name, info = run([w], GRID)
+        if info.n_fused:
+            assert name.startswith('wfk_sample_lean<double,false,16,false,3> + wfk_sample<'), name   # a mixed plan
+        else:
+            assert ',3>' not in name, name
+        ref = oracle([w], GRID)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert np.max(np.abs(got[fin] - ref[fin])) <= 1e-9 * max(1.0, np.abs(ref[fin]).max())
+
+
+def test_far_from_the_origin_and_endpoint_grids():
+    env = hann()
+    w = (env * wf.cos(2e8, 0.3)) >> 1e-6
+    for t0 in (1e-3, -2e-2):
+        grid = ('linspace', t0, t0 + 3e-6, 1_000_001, True)
+        got, name, info = run([w >> t0], grid)
+        ref = oracle([w >> t0], grid)
+        assert np.max(np.abs(got - ref)) <= 1e-9

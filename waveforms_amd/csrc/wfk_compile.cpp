@@ -100,6 +100,9 @@ struct FceGroup {
   bool envmul = false;          // pseudo-op: multiply the accumulators by the shared Gaussian envelope
   bool erfmul = false;          // pseudo-op: multiply them by m0 + m1 erf((t - sg) / sigma) (flat-top edge)
   double m0 = 0, m1 = 1;
+  int fmul = 0;                 // pseudo-op: multiply them by a stateless function of t - slin: 2 = a finite INTERP table read as a
+                                // continuous piecewise-linear function, 3 = mollifier(r) (lean kernel family 3 only)
+  int32_t fmul_f = -1;          // ... the program factor it stands for
   long double K = 0;            // chirp: the phase is K t'^2 + W t' - psi_ref (W, psi_ref as for a plain carrier)
   bool chirp = false;
   double tref = 0;              // chirp: reference time inside the piece (the device works in t' - tref)
@@ -581,6 +584,14 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool expfuse = !(noexp_env && noexp_env[0] == '1');
   const char* noerf_env = std::getenv("WFK_DISABLE_ERFMUL");
   const bool erfmod_base = can_fuse && !H.tlist && ns_override == 0 && !(noerf_env && noerf_env[0] == '1');
+  // stateless closing multipliers (INTERP tables, mollifiers): ops of the lean kernel's family 3 ONLY, so they
+  // exist where every piece flagged lean is certain to run on that kernel (lean or mixed plans in the standard
+  // geometry, no corrected carriers: that instantiation has families 0 / 1 only)
+  const char* nofmul_env = std::getenv("WFK_DISABLE_FMUL");
+  const char* nomix_env0 = std::getenv("WFK_DISABLE_MIXED");
+  const bool fmul_base = erfmod_base && !nolean && !shortm && !g_no_chirp && !(nofmul_env && nofmul_env[0] == '1') &&
+                         !(nomix_env0 && nomix_env0[0] == '1');
+  bool piece_fmul_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
 
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
                        int64_t s1, int32_t skip = -1) -> bool {   // skip: a factor handled by the caller
@@ -947,6 +958,38 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       B.fce_ats.push_back(at);
       return;
     }
+    if (G.fmul) {
+      // stateless closing multiplier (wfk_kernels.hip: fce_tabmul / fce_mollmul): no per-lane state, no seed
+      const int32_t f = G.fmul_f;
+      const double* fa = P->pool + P->fc_arg_off[f];
+      rec[0] = WFK_OP_FCE;
+      rec[WFK_FCE_DEG] = (double)WFK_FCE_PACK(G.fmul, 0, 0, 3, 0);
+      rec[WFK_FCE_SLIN] = P->fc_shift[f];
+      rec[WFK_FCE_D] = dstride;
+      if (G.fmul == 2) {
+        // np.interp on linspace knots (reference _waveform.pyx:309-311) as value + fraction * difference: the
+        // table travels as (f_j, f_{j+1} - f_j) pairs -- ONE 16-byte gather per sample -- with a closing
+        // (f_{m-1}, 0) entry for x == stop (and one more, should the index guess round up there)
+        const int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 2;
+        const double start = fa[0], stop = fa[1];
+        const double* fp = fa + 2;
+        if (H.pool.size() & 1) H.pool.push_back(0.0);
+        rec[WFK_FCE_A] = start; rec[WFK_FCE_A + 1] = stop;
+        rec[WFK_FCE_A + 2] = (double)(m - 1) / (stop - start);
+        rec[WFK_FCE_A + 3] = (double)(H.pool.size() / 2);          // in 16-byte entries
+        for (int64_t j = 0; j < m; ++j) {
+          H.pool.push_back(fp[j]);
+          H.pool.push_back(j + 1 < m ? fp[j + 1] - fp[j] : 0.0);
+        }
+        H.pool.push_back(fp[m - 1]); H.pool.push_back(0.0);
+      } else {
+        rec[WFK_FCE_A] = 1.0 / fa[0];
+      }
+      const size_t at = B.body.size();
+      B.body.insert(B.body.end(), rec, rec + WFK_FCE_REC);
+      B.fce_ats.push_back(at);
+      return;
+    }
     rec[0] = WFK_OP_FCE;
     rec[WFK_FCE_W] = G.W;
     rec[WFK_FCE_SREF] = sref;
@@ -1179,8 +1222,55 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         std::vector<FceGroup> mgroups;
         bool mod_on = false;
         double mod_sigma = 0, mod_shift = 0;
+        int mod_kind = 0;             // 1: erf edge, 2: INTERP table, 3: mollifier (the closing multiplier of this piece)
+        int32_t mod_f = -1;           // the first term's factor of that kind (later terms must carry an equal one)
+        const bool fmul_now = fmul_base && piece_fmul_ok && !cur_short && std::isfinite(ax.at(s0)) && std::isfinite(ax.at(s1 - 1));
+        // a term's ONE factor of a kind the closing multipliers take (power 1); -1: none, or not admissible here
+        auto fmul_factor_of = [&](int32_t k, int& kind_out) -> int32_t {
+          if (!fmul_now || mod_kind == 1) return -1;
+          int32_t at = -1;
+          for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
+            if (P->fc_type[f] == WFK_INTERP || P->fc_type[f] == WFK_MOLLIFIER) {
+              if (at >= 0 || P->fc_power[f] != 1.0) return -1;
+              at = f;
+            } else if (P->fc_type[f] == WFK_ERF) return -1;
+          if (at < 0) return -1;
+          const double* fa = P->pool + P->fc_arg_off[at];
+          const int64_t na = P->fc_arg_off[at + 1] - P->fc_arg_off[at];
+          const double sh = P->fc_shift[at];
+          if (!std::isfinite(sh)) return -1;
+          const int kind = P->fc_type[at] == WFK_INTERP ? 2 : 3;
+          if (mod_f >= 0) {
+            // one multiplier per piece: the same primitive, arguments and shift as the first term's
+            if (kind != mod_kind || sh != P->fc_shift[mod_f] || na != P->fc_arg_off[mod_f + 1] - P->fc_arg_off[mod_f]) return -1;
+            if (P->fc_arg_off[at] != P->fc_arg_off[mod_f] &&
+                std::memcmp(fa, P->pool + P->fc_arg_off[mod_f], (size_t)na * sizeof(double)) != 0) return -1;
+            kind_out = kind;
+            return at;
+          }
+          if (kind == 2) {
+            // a finite table on increasing linspace knots, slopes inside the grid-rounding budget (as WFK_M_INTERP_LIN)
+            const int64_t m = na - 2;
+            const double start = fa[0], stop = fa[1];
+            if (m < 2 || m > (int64_t(1) << 24) || !(stop > start) || !std::isfinite(start) || !std::isfinite(stop)) return -1;
+            const double inv = (double)(m - 1) / (stop - start);
+            if (!std::isfinite(inv)) return -1;
+            double dmax = 0.0;
+            for (int64_t j = 0; j < m; ++j) {
+              if (!std::isfinite(fa[2 + j])) return -1;
+              if (j + 1 < m) dmax = std::max(dmax, std::fabs(fa[3 + j] - fa[2 + j]));
+            }
+            if (!std::isfinite(dmax) || !rate_safe(4.0 * dmax * inv, s0, s1)) return -1;
+            // the knot index comes from (x - start) * inv: its rounding (2^-52 of the index) times the largest step
+            if (dmax * (double)m * 4.5e-16 > WFK_JITTER_TOL) return -1;
+          } else {
+            if (!(fa[1] == 0.0) || !std::isfinite(fa[0]) || !(fa[0] > 0.0) || !rate_safe(4.0 / fa[0], s0, s1)) return -1;
+          }
+          kind_out = kind;
+          return at;
+        };
         auto erf_factor_of = [&](int32_t k, double& sg_out, double& sh_out) -> int32_t {
-          if (!erfmod_base) return -1;
+          if (!erfmod_base || mod_kind >= 2) return -1;
           int32_t at = -1;
           for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
             if (P->fc_type[f] == WFK_ERF) {
@@ -1208,8 +1298,14 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           double esg = 0, esh = 0;
           const bool fuse_now = can_fuse && piece_fuse_ok;
           const int32_t fe = fuse_now ? erf_factor_of(k, esg, esh) : -1;
+          int fkind = 0;
+          const int32_t ff = fuse_now && fe < 0 ? fmul_factor_of(k, fkind) : -1;
           if (fe >= 0 && fuse_term(mgroups, k, C.tshift, s0, s1, fe)) {
-            mod_on = true; mod_sigma = esg; mod_shift = esh;
+            mod_on = true; mod_sigma = esg; mod_shift = esh; mod_kind = 1;
+            ++H.n_fused;
+          } else if (ff >= 0 && fuse_term(mgroups, k, C.tshift, s0, s1, ff)) {
+            mod_on = true; mod_kind = fkind;
+            if (mod_f < 0) mod_f = ff;
             ++H.n_fused;
           } else if (fuse_now && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
           else generic.push_back(k);
@@ -1226,7 +1322,14 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           piece_fuse_ok = false;
           continue;
         }
-        if (mod_on) {
+        if (mod_on && mod_kind >= 2) {
+          // out = F S1 + S0: the groups of the modulated terms, the closing multiplier, then the rest
+          FceGroup E;
+          E.fmul = mod_kind; E.fmul_f = mod_f;
+          mgroups.push_back(E);
+          mgroups.insert(mgroups.end(), groups.begin(), groups.end());
+          groups.swap(mgroups);
+        } else if (mod_on) {
           // out = S0 + erf S1.  Where every group of S1 has a twin in S0 with the same coefficients
           // times ONE ratio rho (0.5 cos + 0.5 erf cos), the twins go: out = (rho + erf) S1 + rest.
           FceGroup E;
@@ -1298,7 +1401,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
           // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
           bool ok = generic.empty() && !groups.empty() && groups.size() <= 255;
-          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul);
+          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul || G.fmul);
           if (!ok) {
             H.params.resize(snap.params); H.pool.resize(snap.pool);
             H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
@@ -1317,11 +1420,12 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           break;
         }
         piece_lean = generic.empty() && !groups.empty() && groups.size() <= WFK_LEAN_OPS;
-        bool piece_has_chirp = false;
-        int piece_fam = 0;          // lean kernel family the piece needs: 0 plain ops, 1 closing ops, 2 chirps
+        bool piece_has_chirp = false, piece_has_fmul = false;
+        int piece_fam = 0;          // lean kernel family the piece needs: 0 plain ops, 1 closing ops, 2 chirps, 3 stateless multipliers
         for (const FceGroup& G : groups) {
           piece_has_chirp = piece_has_chirp || G.chirp;
-          piece_fam = std::max(piece_fam, G.chirp ? 2 : ((G.erfmul || G.envmul) ? 1 : 0));
+          piece_has_fmul = piece_has_fmul || G.fmul != 0;
+          piece_fam = std::max(piece_fam, G.fmul ? 3 : (G.chirp ? 2 : ((G.erfmul || G.envmul) ? 1 : 0)));
         }
         const int32_t piece_ops = (int32_t)groups.size();
         int32_t piece_units = 0;
@@ -1357,7 +1461,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         ++D.n_blk;
         piece_lean = piece_lean && D.n_blk == 1 && len <= lean_par_cap && piece_units <= 63;
         (void)piece_ops;
-        if (!piece_lean && (H.n_corr > corr_before || piece_has_chirp) && attempt == 0) {
+        if ((!piece_lean && (H.n_corr > corr_before || piece_has_chirp || piece_has_fmul) && attempt == 0) ||
+            (piece_has_fmul && H.n_corr > corr_before && attempt == 0)) {
           // roll back and build the piece again without corrected carriers / fused chirps (lean kernel only)
           H.params.resize(snap.params); H.pool.resize(snap.pool);
           H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
@@ -1365,6 +1470,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           D = D0;
           piece_corr_ok = false;
           piece_chirp_ok = false;
+          piece_fmul_ok = false;
           continue;
         }
         if (H.tlist) {
@@ -1384,6 +1490,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       }
       piece_corr_ok = true;
       piece_chirp_ok = true;
+      piece_fmul_ok = true;
       piece_fuse_ok = true;
       if (shortm) set_geom(true);
       // fuse adjacent zero pieces

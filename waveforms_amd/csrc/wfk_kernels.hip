@@ -929,6 +929,69 @@ __device__ __forceinline__ void fce_erfmul(const double* r, FceSeeds& sd, double
   sd.r = rr;
 }
 
+// closing pseudo-ops WITHOUT state (env == 3, deg == 2 | 3; lean kernel family 3): everything accumulated so far is
+// multiplied by F(u_k), u_k = x - s + k D -- the envelope the piece's carriers share, where F has no recurrence form.
+__device__ __forceinline__ double udbl(double v) {   // a wave-uniform double read from LDS: pinned to an SGPR pair
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// deg == 2: np.interp over linspace knots with a finite table (reference _waveform.pyx:309-311), read as the
+// continuous piecewise-linear function it is: x clamped into [start, stop] (np.interp's constant continuation),
+// q = (x - start) * (m - 1) / (stop - start), value = f[floor q] + frac(q) * (f[floor q + 1] - f[floor q]).  The
+// host packs (f_j, f_{j+1} - f_j) pairs: one 16-byte gather per sample, eight samples' gathers in flight; 9 VALU
+// instructions per sample next to it.  (Admission, wfk_compile.cpp: the rounding of q times the largest step and
+// the grid rounding times the largest slope both stay inside the jitter budget.)
+template <typename T, int NS, bool CPLX>
+__device__ __forceinline__ void fce_tabmul(const double* r, const KArgs& a, double x, T (&acc)[NS],
+                                           T (&acci)[CPLX ? NS : 1]) {
+  const double u0 = x - r[WFK_FCE_SLIN];
+  const double D = udbl(r[WFK_FCE_D]), start = udbl(r[WFK_FCE_A]), stop = udbl(r[WFK_FCE_A + 1]);
+  const double inv = udbl(r[WFK_FCE_A + 2]);
+  const double2* tab = uniptr(reinterpret_cast<const double2*>(a.pool) + uni64((int64_t)r[WFK_FCE_A + 3]));
+  constexpr int IB = NS % 8 == 0 ? 8 : 1;
+#pragma unroll
+  for (int k0 = 0; k0 < NS; k0 += IB) {
+    double fr[IB];
+    double2 e[IB];
+#pragma unroll
+    for (int kk = 0; kk < IB; ++kk) {
+      const double xk = fma((double)(k0 + kk), D, u0);
+      const double xc = fmin(fmax(xk, start), stop);
+      const double q = (xc - start) * inv;
+      fr[kk] = __builtin_amdgcn_fract(q);
+      e[kk] = tab[(uint32_t)(int)q];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // gathers above, uses below
+#pragma unroll
+    for (int kk = 0; kk < IB; ++kk) {
+      const T m = (T)fma(fr[kk], e[kk].y, e[kk].x);
+      acc[k0 + kk] *= m;
+      if constexpr (CPLX) acci[k0 + kk] *= m;
+    }
+  }
+}
+
+// deg == 3: mollifier(r) (d = 0): exp(1 / (x^2 - 1) + 1), x = u / r, inside |x| < 1, else 0 (reference
+// _waveform.pyx:359-363); Newton reciprocal and the inline exponential, as WFK_M_MOLL_REC
+template <typename T, int NS, bool CPLX>
+__device__ __forceinline__ void fce_mollmul(const double* r, double x, T (&acc)[NS], T (&acci)[CPLX ? NS : 1]) {
+  const double u0 = x - r[WFK_FCE_SLIN];
+  const double D = udbl(r[WFK_FCE_D]), ir = udbl(r[WFK_FCE_A]);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double xx = fma((double)k, D, u0) * ir;
+    const double q = fma(xx, xx, -1.0);
+    const double qq = q < -1e-300 ? q : -1.0;                     // (outside the support: any harmless argument)
+    const double v = exp_inline(rcp_nr(qq) + 1.0);
+    const T m = (T)(q < 0.0 ? v : 0.0);
+    acc[k] *= m;
+    if constexpr (CPLX) acci[k] *= m;
+    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- fused chirp op (lean kernel, family 2): E_k (A(u_k) cos th_k + B(u_k) sin th_k) with a QUADRATIC
 // phase, th(tau) = K tau^2 + W' tau + phi0 about tau = t' - tref (reference LINEARCHIRP,
 // _waveform.pyx:323-324, times whatever carriers the term multiplies it with).  Along a lane (stride D)
@@ -1267,7 +1330,8 @@ __device__ __forceinline__ int64_t xcd_chunk(const KArgs& a) {
 // every WFK_LEAN_RESEED tiles, in a phase where no accumulator is live (so the libm call
 // does not inflate the kernel's register allocation).  No barriers between waves at all.
 // FAM: op families compiled into this instantiation -- 0: carrier / envelope ops only (every BASELINE
-// config), 1: + the closing ops (erf edges, shared envelopes), 2: + chirps.  The host picks the smallest
+// config), 1: + the closing ops (erf edges, shared envelopes), 2: + chirps, 3: + the stateless closing multipliers
+// (INTERP tables, mollifiers).  The host picks the smallest
 // family a plan needs, so a shape added to one family cannot move the register allocation and code
 // layout of the others (round 2 took the chirp op out again for exactly that: inlined into the one
 // kernel it cost the multi-tone workloads 4-9 %).
@@ -1355,6 +1419,9 @@ wfk_sample_lean(const KArgs a) {
                 continue;
               }
             }
+            if constexpr (FAM >= 3) {
+              if ((sfl & 0x32) == 0x32) continue;      // stateless closing multiplier: nothing to seed
+            }
             const FceSeeds sd = fce_make_seeds<CORR>(srec, x, sfl);
             double* st = s_st + WFK_FCE_STOFF(sfl) + lane;
             if (sfl & WFK_FCE_HAS_CS) {
@@ -1406,6 +1473,13 @@ wfk_sample_lean(const KArgs a) {
               }
               st[0] = cd.c; st[64] = cd.s; st[128] = cd.wc; st[192] = cd.ws;
               if (cenv) { st[256] = cd.g; st[320] = cd.r; }
+              continue;
+            }
+          }
+          if constexpr (FAM >= 3) {
+            if ((fl & 0x32) == 0x32) {      // env == 3, deg >= 2: stateless closing multiplier
+              if (fl & 1) fce_mollmul<T, NS, CPLX>(rec, x, acc, acci);
+              else fce_tabmul<T, NS, CPLX>(rec, a, x, acc, acci);
               continue;
             }
           }
@@ -1628,7 +1702,8 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
           return hipGetLastError() == hipSuccess ? 0 : -1;
         }
       }
-      if (a.lean_fam >= 2) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 2>), g, dim3(64), lds, s, a);
+      if (a.lean_fam >= 3) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 3>), g, dim3(64), lds, s, a);
+      else if (a.lean_fam == 2) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 2>), g, dim3(64), lds, s, a);
       else if (a.lean_fam == 1) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 1>), g, dim3(64), lds, s, a);
       else hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 0>), g, dim3(64), lds, s, a);
       return hipGetLastError() == hipSuccess ? 0 : -1;
