@@ -206,6 +206,10 @@ def workload(name, channels, points):
             f'mixing(gaussian(20 ns), DRAGScaling) pulses ' + ('100 ns apart (30 % duty)' if d30 else 'back to back') +
             f', 60 samples per pulse; {channels // TILE[name]} distinct channels x {TILE[name]} copies, every row with '
             f'its own device tables')
+    if name == 'awg_interp':
+        return (lambda c: wl.awg_interp_channel(wf, c, points, 2e9)), wl.awg_grid(points, 2e9), np.float64, (
+            f'{channels} rows/GPU x {points:.0e} pts at 2 GS/s: samplingPoints envelopes (301 knots, 8 shapes per channel) under '
+            f'carriers, back to back, 60 samples per pulse; {channels // TILE[name]} distinct channels x {TILE[name]} copies')
     if name == 'multitone':
         return (lambda c: wl.multitone_channel(wf, c)), wl.c2_grid(points), np.float64, (
             f'{channels} rows/GPU ({channels // TILE[name]} distinct x {TILE[name]}) x {points:.0e} pts, 100 gaussian pulses per row, 10 tones under every pulse')
@@ -221,13 +225,13 @@ def workload(name, channels, points):
     raise SystemExit(f'unknown workload {name}')
 
 
-TILE = {'awg': 128, 'awg_duty30': 128, 'awg_c4': 128, 'multitone': 8, 'direct_sinc': 8, 'direct_mollifier': 8, 'direct_interp': 8}     # rows = TILE copies of rows / TILE distinct channels
+TILE = {'awg': 128, 'awg_duty30': 128, 'awg_c4': 128, 'awg_interp': 128, 'multitone': 8, 'direct_sinc': 8, 'direct_mollifier': 8, 'direct_interp': 8}     # rows = TILE copies of rows / TILE distinct channels
 
 
 def default_shape(name):
-    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512, 'awg': 2048, 'awg_duty30': 2048, 'awg_c4': 2048, 'tlist': 64,
+    channels = {'c2': 1, 'c2_duty30': 1, 'c2_drag': 1, 'c5': 512, 'awg': 2048, 'awg_duty30': 2048, 'awg_c4': 2048, 'awg_interp': 2048, 'tlist': 64,
                 'multitone': 64, 'direct_sinc': 64, 'direct_mollifier': 64, 'direct_interp': 64}.get(name, 256)
-    points = {'c3': 10**6, 'far': 2 * 10**6, 'far_sparse': 2 * 10**6, 'awg': 10**5, 'awg_duty30': 10**5, 'awg_c4': 10**5,
+    points = {'c3': 10**6, 'far': 2 * 10**6, 'far_sparse': 2 * 10**6, 'awg': 10**5, 'awg_duty30': 10**5, 'awg_c4': 10**5, 'awg_interp': 10**5,
               'tlist': 2 * 10**6}.get(name, 10**7)
     return channels, points
 

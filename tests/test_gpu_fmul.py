@@ -141,3 +141,68 @@ def test_far_from_the_origin_and_endpoint_grids():
         got, name, info = run([w >> t0], grid)
         ref = oracle([w >> t0], grid)
         assert np.max(np.abs(got - ref)) <= 1e-9
+
+
+# ---- the same multipliers in the short tier (AWG sample rates: a 30 ns pulse is 60 samples) -----------------
+AWG = wl.awg_grid(100_000, 2e9)
+AWG_TOL = 5e-11        # of peak, as tests/test_gpu_awg.py: grid jitter x carrier out to t = 50 us (measured <= 2e-11)
+
+
+def test_optimised_pulses_at_awg_rates_run_on_the_short_tier():
+    chans = [wl.awg_interp_channel(wf, c) for c in range(3)]
+    got, name, info = run(chans, AWG)
+    assert name == 'wfk_sample_short<double,false,false,16>' and info.n_generic == 0 and info.n_fused > 0, name
+    ref = oracle(chans, AWG)
+    assert np.max(np.abs(got - ref)) <= AWG_TOL * np.abs(ref).max()
+    # one copy per distinct table: 3 channels x 8 shapes x 302 entries of 16 B (+ the op records), not one per pulse
+    plan = _engine.Plan(_flatten.flatten(chans), grid=_flatten.grid_from_desc(AWG))
+    assert plan.table_bytes() < 2_000_000            # (records 3 x 1666 x 224 B, tables 3 x 8 x 302 x 16 B; 24 MB with one copy per pulse)
+    off, name_off, info_off = run(chans, AWG, env={'WFK_DISABLE_FMUL': '1'})
+    assert name_off.startswith('wfk_sample<') and info_off.n_generic > 0
+    assert np.max(np.abs(off - ref)) <= AWG_TOL * np.abs(ref).max()
+    f32, name32, _ = run(chans, AWG, np.float32)
+    assert name32 == 'wfk_sample_short<float,false,false,16>'
+    assert np.max(np.abs(f32 - ref)) <= FP32_TOL * np.abs(ref).max()
+
+
+def test_short_tier_mollifiers_complex_amplitudes_offsets_and_mixed_plans():
+    rng = np.random.default_rng(5)
+    moll = wl._tree_sum([rng.uniform(0.3, 1) * (wf.mollifier(30e-9) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6)))
+                         >> ((k + 0.5) * 30e-9) for k in range(1600)])
+    cplx = wl._tree_sum([complex(rng.uniform(-1, 1), rng.uniform(-1, 1)) * hann(64) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8))
+                         >> ((k + 0.5) * 30e-9) for k in range(1600)])
+    chans = [moll + 0.25, cplx, (wl.awg_interp_channel(wf, 7) >> 0.2e-9) - 0.5,
+             wl.awg_channel(wf, 3) + (hann(200) * wf.cos(1e9) >> 10e-6) + (hann(100) >> 10.004e-6)]   # two tables overlap: generic there
+    got, name, info = run(chans, AWG, np.complex128)
+    assert name.startswith('wfk_sample_short<double,true,') and ' + wfk_sample<' in name, name     # (a mixed short plan)
+    ref = oracle(chans, AWG, True)
+    assert np.max(np.abs(got - ref)) <= AWG_TOL * np.abs(ref).max()
+    re, _, _ = run(chans, AWG, np.float64)
+    assert np.max(np.abs(re - ref.real)) <= AWG_TOL * np.abs(ref).max()
+    # windows wider than the table (the clamped continuation), pulses cut by the end of the grid, a clip
+    pts = tuple(np.linspace(0.3, 1.0, 40) ** 2)
+    wide = wl._tree_sum([_window(-14e-9, 15e-9, primitive(INTERP, -5e-9, 9e-9, pts)) * wf.cos(3e8 * (k % 7), 0.1 * k)
+                         >> ((k + 0.5) * 30e-9) for k in range(1700)])
+    clipped = wide >> 7e-9
+    clipped.max, clipped.min = 0.6, -0.4
+    chans = [wide, wf.WaveVStack([wide, moll]), clipped]
+    got, name, _ = run(chans, AWG)
+    assert name.startswith('wfk_sample_short<'), name
+    ref = oracle(chans, AWG)
+    assert np.max(np.abs(got - ref)) <= AWG_TOL * max(1.0, np.abs(ref).max())
+
+
+def test_fir_chain_keeps_its_fused_form_next_to_table_envelopes():
+    """predistort(wav(t), ker) at AWG rates: fir_short samples the Gaussian pieces itself; the table / mollifier
+    pieces are written by the general kernel first (fir_short has no closing multipliers of this kind)."""
+    from waveforms_amd.distortion import SampledFir
+    ker = np.random.default_rng(1).normal(size=257)
+    ker /= np.abs(ker).sum()
+    chans = [wl.awg_channel(wf, 0) + (hann(300) * wf.cos(1e9) >> 20.015e-6), wl.awg_interp_channel(wf, 1, 20_000)]
+    grid = wl.awg_grid(20_000, 2e9)
+    sf = SampledFir(chans, grid, ker)
+    x = oracle(chans, grid)
+    want = np.stack([c_oracle.fir(r, ker) for r in x])
+    assert np.max(np.abs(sf.to_host() - want)) <= AWG_TOL * np.abs(want).max()
+    assert 'fir_short<' in sf.plan.kernel_name() or '+ FIR' in sf.plan.kernel_name()
+    sf.close()

@@ -381,6 +381,7 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
     sa.accumulate = (flags & WFK_ACCUMULATE) ? 1 : 0;
     sa.lds_samples = p->h.s_lds_samples;
     sa.step = p->h.step;
+    sa.pool = p->d_pool;
     if (s_lo && nparts > 1) {
       const int64_t u0 = sa.chunk_base * sa.units_per_chunk, u1 = (sa.chunk_base + sa.n_chunks) * sa.units_per_chunk;
       *s_lo = u0 < sa.n_units ? p->h.s_units[(size_t)u0].j0 : p->h.n;

@@ -124,6 +124,8 @@ struct BlockBuilder {
 
 }  // namespace
 
+static thread_local bool g_no_short_fmul = false;   // the FIR chain's sampler plan: fir_short has no table / mollifier multipliers, such pieces stay with the general kernel
+void wfk_internal_no_short_fmul(bool on) { g_no_short_fmul = on; }
 static thread_local bool g_no_chirp = false;   // second compile of a plan that mixes corrected carriers and chirps
 
 // want_short: -1 = decide from the mean live piece length (grid plans), 0 = never.  Returns
@@ -589,7 +591,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // geometry, no corrected carriers: that instantiation has families 0 / 1 only)
   const char* nofmul_env = std::getenv("WFK_DISABLE_FMUL");
   const char* nomix_env0 = std::getenv("WFK_DISABLE_MIXED");
-  const bool fmul_base = erfmod_base && !nolean && !shortm && !g_no_chirp && !(nofmul_env && nofmul_env[0] == '1') &&
+  const bool fmul_base = erfmod_base && !nolean && !g_no_chirp && !(nofmul_env && nofmul_env[0] == '1') &&
                          !(nomix_env0 && nomix_env0[0] == '1');
   bool piece_fmul_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
 
@@ -917,6 +919,39 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     return true;
   };
 
+  // (f_j, f_{j+1} - f_j) pairs of an INTERP factor's table in the pool, in 16-byte entries; one copy per distinct
+  // table of the plan (a gate set reuses a few pulse shapes many times), found again by content
+  std::multimap<uint64_t, int64_t> fmul_tables;
+  auto fmul_table = [&](int32_t f) -> int64_t {
+    const double* fa = P->pool + P->fc_arg_off[f];
+    const int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 2;
+    const double* fp = fa + 2;
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)m;
+    for (int64_t j = 0; j < m; ++j) {
+      uint64_t b;
+      std::memcpy(&b, &fp[j], 8);
+      h = (h ^ b) * 1099511628211ull;
+    }
+    auto range = fmul_tables.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+      const size_t at = (size_t)it->second * 2;
+      if (at + 2 * (size_t)(m + 1) > H.pool.size()) continue;          // (rolled back with its piece)
+      bool same = true;
+      for (int64_t j = 0; j < m && same; ++j) same = std::memcmp(&H.pool[at + 2 * (size_t)j], &fp[j], 8) == 0;
+      same = same && H.pool[at + 2 * (size_t)m + 1] == 0.0 && std::memcmp(&H.pool[at + 2 * (size_t)m], &fp[m - 1], 8) == 0;
+      if (same) return it->second;
+    }
+    if (H.pool.size() & 1) H.pool.push_back(0.0);
+    const int64_t at = (int64_t)(H.pool.size() / 2);
+    for (int64_t j = 0; j < m; ++j) {
+      H.pool.push_back(fp[j]);
+      H.pool.push_back(j + 1 < m ? fp[j + 1] - fp[j] : 0.0);
+    }
+    H.pool.push_back(fp[m - 1]); H.pool.push_back(0.0);
+    fmul_tables.emplace(h, at);
+    return at;
+  };
+
   auto emit_group = [&](BlockBuilder& B, FceGroup& G) {
     double rec[WFK_FCE_REC] = {0};
     long double A0 = G.A[0], B0 = G.B[0];
@@ -972,16 +1007,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // (f_{m-1}, 0) entry for x == stop (and one more, should the index guess round up there)
         const int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 2;
         const double start = fa[0], stop = fa[1];
-        const double* fp = fa + 2;
-        if (H.pool.size() & 1) H.pool.push_back(0.0);
-        rec[WFK_FCE_A] = start; rec[WFK_FCE_A + 1] = stop;
+        rec[WFK_FCE_A] = start; rec[WFK_FCE_A + 1] = (double)(m - 1);
         rec[WFK_FCE_A + 2] = (double)(m - 1) / (stop - start);
-        rec[WFK_FCE_A + 3] = (double)(H.pool.size() / 2);          // in 16-byte entries
-        for (int64_t j = 0; j < m; ++j) {
-          H.pool.push_back(fp[j]);
-          H.pool.push_back(j + 1 < m ? fp[j + 1] - fp[j] : 0.0);
-        }
-        H.pool.push_back(fp[m - 1]); H.pool.push_back(0.0);
+        rec[WFK_FCE_B] = dstride * rec[WFK_FCE_A + 2];             // the lane stride in knot units
+        rec[WFK_FCE_A + 3] = (double)fmul_table(f);                // in 16-byte entries
       } else {
         rec[WFK_FCE_A] = 1.0 / fa[0];
       }
@@ -1065,7 +1094,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
                               int32_t& n_rec) -> int32_t {
     const long double PIl = 3.141592653589793238462643383279502884L;
     int32_t rec_len = 0;
-    for (const FceGroup& G : groups) rec_len += G.deg > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
+    for (const FceGroup& G : groups) rec_len += (G.deg > 1 || G.fmul) ? WFK_SH_OP3 : WFK_SH_OP1;
     n_rec = 0;
     for (int64_t r0 = s0; r0 < s1; r0 += WFK_SH_SUB, ++n_rec) {
       double x = ax.at(r0);
@@ -1075,6 +1104,31 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       H.params.resize(at + (size_t)rec_len, 0.0);
       double* o = H.params.data() + at;
       for (const FceGroup& G : groups) {
+        if (G.fmul) {
+          // stateless closing multiplier (wfk_short_dev.h: short_tabmul / short_mollmul); the word's degree field
+          // (2 | 3) names the kind, so the record is stepped over as a 16-double one.  [5] position at the
+          // reference sample and [6] its step per sample, in knot units (table) or in units of r (mollifier);
+          // table: [8] m - 1, [9] the table's first entry in the pool (16-byte entries)
+          const int32_t f = G.fmul_f;
+          const double* fa = P->pool + P->fc_arg_off[f];
+          const uint64_t word = (uint64_t)(uint32_t)(G.fmul | (3 << 4) | (&G == &groups.back() ? WFK_SH_LAST : 0)) | ((uint64_t)(uint32_t)r0 << 32);
+          std::memcpy(&o[0], &word, sizeof word);
+          const long double u0 = x0 - (long double)P->fc_shift[f];
+          if (G.fmul == 2) {
+            const int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 2;
+            const long double inv = (long double)(m - 1) / ((long double)fa[1] - (long double)fa[0]);
+            o[5] = (double)((u0 - (long double)fa[0]) * inv);
+            o[6] = (double)((long double)grid->step * inv);
+            o[8] = (double)(m - 1);
+            o[9] = (double)fmul_table(f);
+          } else {
+            o[5] = (double)(u0 / (long double)fa[0]);
+            o[6] = (double)((long double)grid->step / (long double)fa[0]);
+          }
+          H.short_has_fmul = true;
+          o += WFK_SH_OP3;
+          continue;
+        }
         if (G.erfmul) {
           // closing op of a flat-top edge: everything accumulated so far *= m0 + m1 erf(v), v = v0 + koff H
           const uint64_t word = (uint64_t)(uint32_t)((3 << 4) | (&G == &groups.back() ? WFK_SH_LAST : 0)) | ((uint64_t)(uint32_t)r0 << 32);
@@ -1224,7 +1278,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         double mod_sigma = 0, mod_shift = 0;
         int mod_kind = 0;             // 1: erf edge, 2: INTERP table, 3: mollifier (the closing multiplier of this piece)
         int32_t mod_f = -1;           // the first term's factor of that kind (later terms must carry an equal one)
-        const bool fmul_now = fmul_base && piece_fmul_ok && !cur_short && std::isfinite(ax.at(s0)) && std::isfinite(ax.at(s1 - 1));
+        // (a short plan: in its short pieces only -- the pieces that tier hands on go to the general kernel)
+        const bool fmul_now = fmul_base && piece_fmul_ok && (!shortm || (cur_short && !g_no_short_fmul)) && std::isfinite(ax.at(s0)) && std::isfinite(ax.at(s1 - 1));
         // a term's ONE factor of a kind the closing multipliers take (power 1); -1: none, or not admissible here
         auto fmul_factor_of = [&](int32_t k, int& kind_out) -> int32_t {
           if (!fmul_now || mod_kind == 1) return -1;
@@ -1261,8 +1316,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
               if (j + 1 < m) dmax = std::max(dmax, std::fabs(fa[3 + j] - fa[2 + j]));
             }
             if (!std::isfinite(dmax) || !rate_safe(4.0 * dmax * inv, s0, s1)) return -1;
-            // the knot index comes from (x - start) * inv: its rounding (2^-52 of the index) times the largest step
-            if (dmax * (double)m * 4.5e-16 > WFK_JITTER_TOL) return -1;
+            // the position in knot units, q = (x - start) * inv advanced by a tile's worth of additions: its
+            // rounding (<= 2.5e-15 of the index range) times the largest step
+            if (dmax * (double)m * 2.5e-15 > WFK_JITTER_TOL) return -1;
           } else {
             if (!(fa[1] == 0.0) || !std::isfinite(fa[0]) || !(fa[0] > 0.0) || !rate_safe(4.0 / fa[0], s0, s1)) return -1;
           }
@@ -1401,7 +1457,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
           // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
           bool ok = generic.empty() && !groups.empty() && groups.size() <= 255;
-          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul || G.fmul);
+          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul);
           if (!ok) {
             H.params.resize(snap.params); H.pool.resize(snap.pool);
             H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
@@ -1852,6 +1908,7 @@ int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, i
                       std::vector<ShortWin>& wins, std::vector<uint32_t>& ents, std::string& bad) {
   bad.clear();
   if (!H.shortp) { bad = "not a short plan"; return WFK_EINVAL; }
+  if (H.short_has_fmul) { bad = "table / mollifier envelopes (closing multipliers the fused chain does not evaluate)"; return WFK_EINVAL; }
   if (half_len <= 0 || half_len > 4096 || hop <= 0 || npairs < 0) { bad = "window geometry"; return WFK_EINVAL; }
   const int32_t nch = (int32_t)H.channels.size();
   wins.assign((size_t)npairs * nch * 2, ShortWin{});

@@ -729,6 +729,21 @@ static int chain_plan_create(const wfk_program* prog, const wfk_grid* grid, cons
   p->kind = kind;
   int rc = wfk_plan_create_grid(prog, grid, &p->sampler);
   if (rc) { wfk_chain_plan_destroy(p); return rc; }
+  {
+    // pieces that close with a table / mollifier multiplier: fir_short does not evaluate those, the general kernel
+    // writes them to the chain's workspace like the other pieces the short tier hands on
+    const HostPlan* h0 = nullptr;
+    const double* r0 = nullptr;
+    wfk_internal_plan_tables(p->sampler, &h0, &r0);
+    if (h0 && h0->shortp && h0->short_has_fmul) {
+      wfk_plan_destroy(p->sampler);
+      p->sampler = nullptr;
+      wfk_internal_no_short_fmul(true);
+      rc = wfk_plan_create_grid(prog, grid, &p->sampler);
+      wfk_internal_no_short_fmul(false);
+      if (rc) { wfk_chain_plan_destroy(p); return rc; }
+    }
+  }
   p->n = grid->n;
   p->n_channels = prog->n_channels;
   rc = per_row ? wfk_fir_plan_create_rows(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir)

@@ -208,6 +208,7 @@ struct SArgs {                // short-tier launch (wfk_short.hip)
   int32_t lds_samples;        // largest n_samples of a unit with slots
   int32_t pad;
   double step;
+  const double* pool;         // INTERP tables of the closing multipliers ((value, difference) pairs)
 };
 
 struct KArgs {
@@ -276,6 +277,7 @@ struct HostPlan {
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most state units (128 doubles) of a piece
   // short tier (WFK_SH_*): `params` then holds the compact records
   bool shortp = false;
+  bool short_has_fmul = false;     // some short piece closes with a table / mollifier multiplier (wfk_sample_short evaluates them, fir_short does not)
   bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
   std::vector<ShortUnit> s_units;
   std::vector<uint32_t> s_slots;
@@ -306,6 +308,9 @@ struct ShortWin {        // one half of one pair of windows of one channel
 // -> wins[(c * npairs + pr) * 2 + h], entries; returns 0, or WFK_EINVAL with the reason in err
 int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half, int64_t npairs,
                       std::vector<ShortWin>& wins, std::vector<uint32_t>& entries, std::string& err);
+
+// this thread's next plan compiles keep table / mollifier multipliers out of short pieces (the FIR chain's sampler plan)
+void wfk_internal_no_short_fmul(bool on);
 
 // kernels (wfk_kernels.hip)
 int wfk_launch_sampler(const KArgs& a, int32_t n_channels, int out_kind, bool tlist, int ns,

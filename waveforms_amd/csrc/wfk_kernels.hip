@@ -938,17 +938,17 @@ __device__ __forceinline__ double udbl(double v) {   // a wave-uniform double re
 }
 
 // deg == 2: np.interp over linspace knots with a finite table (reference _waveform.pyx:309-311), read as the
-// continuous piecewise-linear function it is: x clamped into [start, stop] (np.interp's constant continuation),
-// q = (x - start) * (m - 1) / (stop - start), value = f[floor q] + frac(q) * (f[floor q + 1] - f[floor q]).  The
-// host packs (f_j, f_{j+1} - f_j) pairs: one 16-byte gather per sample, eight samples' gathers in flight; 9 VALU
-// instructions per sample next to it.  (Admission, wfk_compile.cpp: the rounding of q times the largest step and
-// the grid rounding times the largest slope both stay inside the jitter budget.)
+// continuous piecewise-linear function it is, in knot units: q = (x - start) * (m - 1) / (stop - start) clamped
+// into [0, m - 1] (np.interp's constant continuation), value = f[floor q] + frac(q) * (f[floor q + 1] - f[floor q]).
+// q advances along the lane by additions of D (m - 1) / (stop - start).  The host packs (f_j, f_{j+1} - f_j) pairs:
+// one 16-byte gather per sample, eight samples' gathers in flight; 8 VALU instructions per sample next to it.
+// (Admission, wfk_compile.cpp: the rounding of q -- seed, sixteen additions -- times the largest step, and the
+// grid rounding times the largest slope, both stay inside the jitter budget.)
 template <typename T, int NS, bool CPLX>
 __device__ __forceinline__ void fce_tabmul(const double* r, const KArgs& a, double x, T (&acc)[NS],
                                            T (&acci)[CPLX ? NS : 1]) {
-  const double u0 = x - r[WFK_FCE_SLIN];
-  const double D = udbl(r[WFK_FCE_D]), start = udbl(r[WFK_FCE_A]), stop = udbl(r[WFK_FCE_A + 1]);
-  const double inv = udbl(r[WFK_FCE_A + 2]);
+  const double qmax = udbl(r[WFK_FCE_A + 1]), Dq = udbl(r[WFK_FCE_B]);
+  double q = ((x - r[WFK_FCE_SLIN]) - r[WFK_FCE_A]) * r[WFK_FCE_A + 2];
   const double2* tab = uniptr(reinterpret_cast<const double2*>(a.pool) + uni64((int64_t)r[WFK_FCE_A + 3]));
   constexpr int IB = NS % 8 == 0 ? 8 : 1;
 #pragma unroll
@@ -957,11 +957,10 @@ __device__ __forceinline__ void fce_tabmul(const double* r, const KArgs& a, doub
     double2 e[IB];
 #pragma unroll
     for (int kk = 0; kk < IB; ++kk) {
-      const double xk = fma((double)(k0 + kk), D, u0);
-      const double xc = fmin(fmax(xk, start), stop);
-      const double q = (xc - start) * inv;
-      fr[kk] = __builtin_amdgcn_fract(q);
-      e[kk] = tab[(uint32_t)(int)q];
+      const double qc = fmin(fmax(q, 0.0), qmax);
+      fr[kk] = __builtin_amdgcn_fract(qc);
+      e[kk] = tab[(uint32_t)(int)qc];
+      q += Dq;
     }
     __builtin_amdgcn_sched_barrier(0);   // gathers above, uses below
 #pragma unroll

@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         //  waiting for it -- a vmcnt(3) right behind the prefetch)
         asm volatile("" : : "v"(rc.a.x));
         const int w = op_word(rc);
-        const bool closing = ((w >> 4) & 3) == 3;       // erf edge multiplier
+        const bool closing = ((w >> 4) & 3) == 3;       // closing multiplier (erf edge, table, mollifier)
         const bool mine = lv && !closing && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
         const bool cubic = __any(mine && (w & 3) > 1);
         if (mine) {
@@ -221,7 +221,16 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
           else short_op<R, false, CPLX>(rc, opp, w, kf, a.step, acc, acci);
         }
         if (__any(lv && closing)) {
-          if (lv && closing) short_erfmul<R, CPLX>(rc, kf, acc, acci);
+          const int kind = w & 3;      // 0: erf edge; 2: INTERP table, 3: mollifier (stateless multipliers)
+          if (__any(lv && closing && kind == 0)) {
+            if (lv && closing && kind == 0) short_erfmul<R, CPLX>(rc, kf, acc, acci);
+          }
+          if (__any(lv && closing && kind == 2)) {
+            if (lv && closing && kind == 2) short_tabmul<R, CPLX>(rc, a.pool, kf, acc, acci);
+          }
+          if (__any(lv && closing && kind == 3)) {
+            if (lv && closing && kind == 3) short_mollmul<R, CPLX>(rc, kf, acc, acci);
+          }
         }
         return lv && !(w & WFK_SH_LAST);
       };

@@ -182,5 +182,56 @@ __device__ __forceinline__ void short_erfmul(const OpRec& o, double kf, double (
   SH_END
 }
 
+// Stateless closing multipliers (the op word's degree field: 2 | 3; records of 16 doubles): what the piece's ops
+// accumulated is multiplied by the envelope they share.
+//   2: a finite INTERP table on linspace knots (np.interp, reference _waveform.pyx:309-311) read as the continuous
+//      piecewise-linear function it is: position in knot units q = q0 + (koff + k) dq clamped into [0, m - 1], value
+//      f[floor q] + frac(q) (f[floor q + 1] - f[floor q]) from (value, difference) pairs -- one 16-byte gather per sample
+//   3: mollifier(r): exp(1 / (x^2 - 1) + 1) inside |x| < 1, x = x0 + (koff + k) dx (reference _waveform.pyx:359-363)
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_tabmul(const OpRec& o, const double* pool, double kf, double (&acc)[R],
+                                             double (&acci)[CPLX ? R : 1]) {
+  const double dq = o.d.x, qmax = o.e.x;
+  const double2* tab = reinterpret_cast<const double2*>(pool) + (int64_t)o.e.y;
+  double q = fma(kf, dq, o.c.y);
+  // four samples' gathers in flight at a time (all sixteen would cost the kernel 48 more live registers: it sits
+  // at its 168 for three waves per SIMD)
+  constexpr int IB = R % 4 == 0 ? 4 : 1;
+  SH_EACH(R / IB, kb)
+    double fr[IB];
+    double2 e[IB];
+    SH_EACH(IB, kk)
+      const double qc = fmin(fmax(q, 0.0), qmax);
+      fr[kk] = __builtin_amdgcn_fract(qc);
+      e[kk] = tab[(uint32_t)(int)qc];
+      q += dq;
+    SH_END
+    __builtin_amdgcn_sched_barrier(0);
+    SH_EACH(IB, kk)
+      const double m = fma(fr[kk], e[kk].y, e[kk].x);
+      acc[kb * IB + kk] *= m;
+      if constexpr (CPLX) acci[kb * IB + kk] *= m;
+    SH_END
+    __builtin_amdgcn_sched_barrier(0);
+  SH_END
+}
+
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_mollmul(const OpRec& o, double kf, double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+  const double dx = o.d.x;
+  double x = fma(kf, dx, o.c.y);
+  SH_EACH(R, k)
+    const double qv = fma(x, x, -1.0);
+    const double qq = qv < -1e-300 ? qv : -1.0;                   // (outside the support: any harmless argument)
+    double rc = __builtin_amdgcn_rcp(qq);
+    rc = fma(fma(-qq, rc, 1.0), rc, rc);
+    rc = fma(fma(-qq, rc, 1.0), rc, rc);
+    const double v = exp_small(fmax(rc + 1.0, -740.0));            // (below: < 1e-321, the value is 0 to every bound)
+    const double m = qv < 0.0 ? (rc + 1.0 < -740.0 ? 0.0 : v) : 0.0;
+    acc[k] *= m;
+    if constexpr (CPLX) acci[k] *= m;
+    x += dx;
+  SH_END
+}
 
 }  // namespace shdev

@@ -125,6 +125,29 @@ def awg_channel(ns, c, n_pts=100000, rate=2e9, duty30=False, seed0=7000):
     return sum_channel(ns, nseg, seed0 + c, spacing)
 
 
+def awg_interp_channel(ns, c, n_pts=100000, rate=2e9, nshapes=8, knots=301):
+    """One channel of numerically optimised pulses at an AWG sample rate: every pulse is a `samplingPoints`
+    envelope (301 knots over 30 ns, one of `nshapes` shapes of the channel's gate set) under its own carrier
+    (`mixing(A * env, freq, phase)`), back to back -- what an optimal-control pulse library looks like to
+    `Waveform.sample()` (reference waveform.py:173-207, INTERP: _waveform.pyx:309-311)."""
+    rng = np.random.default_rng(8000 + c)
+    x = np.linspace(0.0, 1.0, knots)
+    shapes = []
+    for _ in range(nshapes):
+        y = np.hanning(knots).copy()
+        for h in (2, 3, 5):
+            y *= 1.0 + 0.15 * rng.normal() * np.sin(2 * np.pi * h * x + rng.uniform(0, 6))
+        shapes.append(tuple(y))
+    nseg = int(n_pts / rate / SPAN)
+    ws = []
+    for k in range(nseg):
+        env = ns.samplingPoints(-SPAN / 2, SPAN / 2, shapes[int(rng.integers(nshapes))])
+        I, _ = ns.mixing(rng.uniform(0.1, 1) * env >> ((k + 0.5) * SPAN), freq=rng.uniform(-200e6, 200e6),
+                         phase=rng.uniform(0, 2 * np.pi))
+        ws.append(I)
+    return _tree_sum(ws)
+
+
 def awg_grid(n_pts=100000, rate=2e9):
     """np.arange(0, n_pts / rate, 1 / rate): the grid of Waveform.sample (waveform.py:190)."""
     return ('arange', 0.0, n_pts / rate, 1.0 / rate)
