@@ -806,7 +806,20 @@ def run_rank(args):
             b2.close()
             del o2
         direct['workload'] = ('64 rows (8 distinct x 8) x 1e7 pts over 3 us: 25 overlapping sinc pulses / 100 mollifier pulses / '
-                              '100 samplingPoints envelopes of 1000 knots under carriers')
+                              '100 samplingPoints envelopes of 1000 knots under carriers; awg_interp: 2048 rows (16 distinct x 128) '
+                              'x 1e5 pts at 2 GS/s, samplingPoints envelopes (301 knots, 8 shapes per channel) under carriers, '
+                              '60 samples per pulse')
+        b2 = BatchSampler([wl.awg_interp_channel(wfm, c) for c in range(16)], wl.awg_grid(), tile=128)
+        o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)
+        ms = timed(lambda: b2.launch_torch(o2), 5, 2)
+        nb = b2.n_channels * b2.n * 8
+        direct['awg_interp'] = {'kernel': b2.plan.kernel_name(), 'kernel_ms': ms, 'msamples_per_s': b2.n_channels * b2.n / (ms * 1e-3) / 1e6,
+                                'algorithmic_bytes_per_launch': nb, 'table_bytes_per_launch': int(b2.plan.table_bytes()),
+                                'frac': nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'frac_incl_tables': (nb + b2.plan.table_bytes()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'fused_ops': int(b2.plan.info.n_fused), 'generic_terms': int(b2.plan.info.n_generic)}
+        b2.close()
+        del o2
         also['direct'] = direct
         b2 = BatchSampler([wl.multitone_channel(wfm, c) for c in range(8)], wl.c2_grid(), tile=8)
         o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)

@@ -1093,8 +1093,16 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   auto emit_short_piece = [&](const std::vector<FceGroup>& groups, double tshift, int64_t s0, int64_t s1,
                               int32_t& n_rec) -> int32_t {
     const long double PIl = 3.141592653589793238462643383279502884L;
+    // ONE carrier (or none) under a table / mollifier envelope -- a pulse as mixing() makes it -- is a single
+    // 12-double record: the op adds envelope x carrier itself (word bit 7; bit 8: mollifier) instead of a carrier
+    // op followed by the closing multiplier in a record of its own (a dependent load per piece)
+    const bool one = groups.size() >= 2 && groups[1].fmul && groups[0].deg == 0 && !groups[0].has_env && !groups[0].has_exp &&
+                     !groups[0].erfmul && !groups[0].envmul && !groups[0].chirp && !groups[0].fmul && !std::getenv("WFK_NO_SHORT_CMUL");
     int32_t rec_len = 0;
-    for (const FceGroup& G : groups) rec_len += (G.deg > 1 || G.fmul) ? WFK_SH_OP3 : WFK_SH_OP1;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      if (one && gi == 1) continue;
+      rec_len += (groups[gi].deg > 1 || groups[gi].fmul) ? WFK_SH_OP3 : WFK_SH_OP1;
+    }
     n_rec = 0;
     for (int64_t r0 = s0; r0 < s1; r0 += WFK_SH_SUB, ++n_rec) {
       double x = ax.at(r0);
@@ -1103,7 +1111,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       const size_t at = H.params.size();
       H.params.resize(at + (size_t)rec_len, 0.0);
       double* o = H.params.data() + at;
-      for (const FceGroup& G : groups) {
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const FceGroup& G = groups[gi];
+        if (one && gi == 1) continue;           // (folded into the record of group 0, below)
         if (G.fmul) {
           // stateless closing multiplier (wfk_short_dev.h: short_tabmul / short_mollmul); the word's degree field
           // (2 | 3) names the kind, so the record is stepped over as a 16-double one.  [5] position at the
@@ -1175,6 +1185,33 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             Br[i] += G.B[m] * f;
           }
         o[8] = (double)Ar[0]; o[9] = (double)Ar[1]; o[10] = (double)Br[0]; o[11] = (double)Br[1];
+        if (one && gi == 0) {
+          // envelope x carrier in one op (wfk_short_dev.h: short_cmul): the carrier fields as above, [5] / [6] the
+          // envelope's position at the reference sample and its step per sample (knot units | units of r),
+          // table: [7] m - 1, [9] first entry in the pool (16-byte entries)
+          const FceGroup& E = groups[1];
+          const int32_t f = E.fmul_f;
+          const double* fa = P->pool + P->fc_arg_off[f];
+          const uint64_t w2 = (uint64_t)(uint32_t)(((G.W != 0.0 ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (3 << 4) |
+                                                   (groups.size() == 2 ? WFK_SH_LAST : 0) | 128 | (E.fmul == 3 ? 256 : 0)) |
+                              ((uint64_t)(uint32_t)r0 << 32);
+          std::memcpy(&o[0], &w2, sizeof w2);
+          const long double ue = x0 - (long double)P->fc_shift[f];
+          if (E.fmul == 2) {
+            const int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 2;
+            const long double inv = (long double)(m - 1) / ((long double)fa[1] - (long double)fa[0]);
+            o[5] = (double)((ue - (long double)fa[0]) * inv);
+            o[6] = (double)((long double)grid->step * inv);
+            o[7] = (double)(m - 1);
+            o[9] = (double)fmul_table(f);
+          } else {
+            o[5] = (double)(ue / (long double)fa[0]);
+            o[6] = (double)((long double)grid->step / (long double)fa[0]);
+          }
+          H.short_has_fmul = true;
+          o += WFK_SH_OP1;
+          continue;
+        }
         if (G.deg > 1) {
           o[12] = (double)Ar[2]; o[13] = (double)Ar[3]; o[14] = (double)Br[2]; o[15] = (double)Br[3];
           o += WFK_SH_OP3;

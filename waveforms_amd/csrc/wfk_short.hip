@@ -221,7 +221,11 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
           else short_op<R, false, CPLX>(rc, opp, w, kf, a.step, acc, acci);
         }
         if (__any(lv && closing)) {
-          const int kind = w & 3;      // 0: erf edge; 2: INTERP table, 3: mollifier (stateless multipliers)
+          const bool own = (w & 128) != 0;      // envelope x carrier in one op: adds its own term
+          if (__any(lv && closing && own)) {
+            if (lv && closing && own && (CPLX || !(w & 8))) short_cmul<R, CPLX>(rc, a.pool, w, kf, acc, acci);
+          }
+          const int kind = own ? -1 : (w & 3);      // 0: erf edge; 2: INTERP table, 3: mollifier (stateless multipliers)
           if (__any(lv && closing && kind == 0)) {
             if (lv && closing && kind == 0) short_erfmul<R, CPLX>(rc, kf, acc, acci);
           }

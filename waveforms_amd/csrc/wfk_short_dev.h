@@ -234,4 +234,83 @@ __device__ __forceinline__ void short_mollmul(const OpRec& o, double kf, double 
   SH_END
 }
 
+// Envelope x carrier in ONE op (word bit 7; bit 8: the envelope is a mollifier, else a table): acc[k] += F_k (A0 c_k + B0 s_k)
+// -- a pulse as mixing(A * samplingPoints(...), freq, phase) makes it, in a record of 12 doubles like a Gaussian pulse's.
+// The carrier's rotation of each batch runs while the batch's table gathers are in flight.
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_cmul(const OpRec& o, const double* pool, int w, double kf, double (&acc)[R],
+                                           double (&acci)[CPLX ? R : 1]) {
+  const double C1 = o.b.y, S1 = o.c.x, A0 = o.e.x, B0 = o.f.x;
+  double c = 1.0, s = 0.0;
+  if (w & 4) {
+    const double x = fma(kf, o.b.x, o.a.y);       // phase / pi
+    const double n = rint(x);
+    sincospi_small(x - n, &s, &c);
+    if (((int)n) & 1) { c = -c; s = -s; }
+  }
+  double mr = 1.0, mi = 0.0;
+  if constexpr (CPLX) {
+    if (w & 8) { mr = 0.0; mi = 1.0; }
+  }
+  const double dq = o.d.x;
+  double q = fma(kf, dq, o.c.y);
+  if (w & 256) {
+    SH_EACH(R, k)
+      const double qv = fma(q, q, -1.0);
+      const double qq = qv < -1e-300 ? qv : -1.0;                   // (outside the support: any harmless argument)
+      double rc = __builtin_amdgcn_rcp(qq);
+      rc = fma(fma(-qq, rc, 1.0), rc, rc);
+      rc = fma(fma(-qq, rc, 1.0), rc, rc);
+      const double v = exp_small(fmax(rc + 1.0, -740.0));
+      const double m = qv < 0.0 ? (rc + 1.0 < -740.0 ? 0.0 : v) : 0.0;
+      const double t = fma(A0, c, B0 * s) * m;
+      if constexpr (CPLX) {
+        acc[k] = fma(mr, t, acc[k]);
+        acci[k] = fma(mi, t, acci[k]);
+      } else {
+        acc[k] += t;
+      }
+      if constexpr (k + 1 < R) {
+        const double cn = fma(c, C1, -(s * S1));
+        s = fma(s, C1, c * S1);
+        c = cn;
+        q += dq;
+      }
+    SH_END
+    return;
+  }
+  const double qmax = o.d.y;
+  const double2* tab = reinterpret_cast<const double2*>(pool) + (int64_t)o.e.y;
+#ifndef WFK_SH_CMUL_IB
+#define WFK_SH_CMUL_IB 4   // (8: 166 VGPRs + 2 spills, awg_interp 0.80 ms either way and the Gaussian pulses 0.39 -> 0.45 ms: the gathers are bound by the cache's tag rate, one line per lane, not by their latency)
+#endif
+  constexpr int IB = R % WFK_SH_CMUL_IB == 0 ? WFK_SH_CMUL_IB : 1;    // samples whose gathers are in flight together
+  SH_EACH(R / IB, kb)
+    double fr[IB];
+    double2 e[IB];
+    SH_EACH(IB, kk)
+      const double qc = fmin(fmax(q, 0.0), qmax);
+      fr[kk] = __builtin_amdgcn_fract(qc);
+      e[kk] = tab[(uint32_t)(int)qc];
+      q += dq;
+    SH_END
+    __builtin_amdgcn_sched_barrier(0);
+    SH_EACH(IB, kk)
+      const double t = fma(A0, c, B0 * s) * fma(fr[kk], e[kk].y, e[kk].x);
+      {
+        const double cn = fma(c, C1, -(s * S1));
+        s = fma(s, C1, c * S1);
+        c = cn;
+      }
+      if constexpr (CPLX) {
+        acc[kb * IB + kk] = fma(mr, t, acc[kb * IB + kk]);
+        acci[kb * IB + kk] = fma(mi, t, acci[kb * IB + kk]);
+      } else {
+        acc[kb * IB + kk] += t;
+      }
+    SH_END
+    __builtin_amdgcn_sched_barrier(0);
+  SH_END
+}
+
 }  // namespace shdev
