@@ -100,6 +100,7 @@ struct FceGroup {
   bool envmul = false;          // pseudo-op: multiply the accumulators by the shared Gaussian envelope
   bool erfmul = false;          // pseudo-op: multiply them by m0 + m1 erf((t - sg) / sigma) (flat-top edge)
   double m0 = 0, m1 = 1;
+  int bank = 0;                 // first of a run of `bank` bare carriers (WFK_FCE_BANK)
   int fmul = 0;                 // pseudo-op: multiply them by a stateless function of t - slin: 2 = a finite INTERP table read as a
                                 // continuous piecewise-linear function, 3 = mollifier(r) (lean kernel family 3 only)
   int32_t fmul_f = -1;          // ... the program factor it stands for
@@ -1045,6 +1046,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       rec[WFK_FCE_F32OK] = G.env32 ? 1.0 : 0.0;
     }
     rec[WFK_FCE_D] = dstride;
+    if (G.bank > 0) {
+      rec[WFK_FCE_DEG] += (double)WFK_FCE_BANK;
+      rec[WFK_FCE_SIGMA] = (double)G.bank;
+    }
     if (H.tlist) {
       // (pointwise evaluation: no lane stride; the H slot carries 1 / sigma -- the Gaussian's argument is formed
       //  by a multiplication, one rounding off the reference's division: 2 v^2 ulp <= 1.5e-13 relative at |v| = 26)
@@ -1489,6 +1494,21 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             groups.push_back(E);
           }
         }
+        // Runs of >= 4 bare carriers (the tones of a multiplexed pulse once their envelope is factored out, CW
+        // tones): marked for the lean kernel's compact tone loop -- per tone and tile two state reads, the products
+        // with the amplitude, the phasor advance; no per-op dispatch (wfk_kernels.hip: fce_bank)
+        bool piece_has_bank = false;
+        if (!cur_short && !H.tlist && ns_override == 0 && !std::getenv("WFK_NO_BANK")) {
+          auto bare = [](const FceGroup& g) {
+            return g.W != 0.0 && !g.chirp && g.deg == 0 && !g.has_env && !g.has_exp && !g.envmul && !g.erfmul && !g.fmul && !g.corr;
+          };
+          for (size_t i = 0; i < groups.size();) {
+            size_t j = i;
+            while (j < groups.size() && bare(groups[j]) && groups[j].imag == groups[i].imag) ++j;
+            if (j - i >= 4) { groups[i].bank = (int)(j - i); piece_has_bank = true; }
+            i = j > i ? j : i + 1;
+          }
+        }
         if (cur_short) {
           // compact records of the short tier (WFK_SH_*): one per <= WFK_SH_SUB samples of the piece.  A
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
@@ -1520,6 +1540,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           piece_has_fmul = piece_has_fmul || G.fmul != 0;
           piece_fam = std::max(piece_fam, G.fmul ? 3 : (G.chirp ? 2 : ((G.erfmul || G.envmul) ? 1 : 0)));
         }
+        if (piece_has_bank) piece_fam = std::max(piece_fam, 1);
         const int32_t piece_ops = (int32_t)groups.size();
         int32_t piece_units = 0;
         for (FceGroup& G : groups) {

@@ -929,6 +929,43 @@ __device__ __forceinline__ void fce_erfmul(const double* r, FceSeeds& sd, double
   sd.r = rr;
 }
 
+// A run of n bare carriers (WFK_FCE_BANK: degree 0, no envelope, no correction; the tones of a multiplexed pulse whose
+// shared envelope the closing op applies): acc[k] += A0 (c_k cos.. ) for every tone in ONE rolled loop -- per tone and
+// tile two state reads, two products with the amplitude, 2 FMAs per sample against the broadcast phasor table and
+// the phasor advance.  The per-op path costs ~70 VALU + ~50 scalar instructions of dispatch and set-up per op and
+// tile on top of the same arithmetic (PMC, ten tones: 80 VALU + 30 SALU instructions per sample; rocprof r04 multitone).
+template <typename T, int NS>
+__device__ __forceinline__ void fce_bank(const double* blk, const double* rec0, int n, double* s_st, int lane,
+                                         T (&acc)[NS]) {
+  constexpr int SB = 4;
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) {
+    const double* r = rec0 + i * WFK_FCE_REC;
+    const int fl = uni(WFK_FCE_WORD(r));
+    const double2* tab = reinterpret_cast<const double2*>(blk + WFK_FCE_TABOFF(fl));
+    double* const st = s_st + WFK_FCE_STOFF(fl) + lane;
+    const double c = st[0], sn = st[64];
+    const double A0 = r[WFK_FCE_A];
+    const T ac = (T)(A0 * c), as = (T)(A0 * sn);
+    double2 tb[2][SB];
+    WFK_EACH(SB, kk) tb[0][kk] = tab[kk]; WFK_END
+    WFK_EACH(NS / SB, kb)
+      if constexpr ((kb + 1) * SB < NS) {
+        WFK_EACH(SB, kk) tb[(kb + 1) & 1][kk] = tab[(kb + 1) * SB + kk]; WFK_END
+      }
+      WFK_EACH(SB, kk)
+        constexpr int k = kb * SB + kk;
+        const double2 cs = tb[kb & 1][kk];
+        acc[k] = __builtin_fma(ac, (T)cs.x, acc[k]);
+        acc[k] = __builtin_fma(-as, (T)cs.y, acc[k]);
+      WFK_END
+    WFK_END
+    const double2 e = tab[NS];
+    st[0] = c * e.x - sn * e.y;
+    st[64] = sn * e.x + c * e.y;
+  }
+}
+
 // closing pseudo-ops WITHOUT state (env == 3, deg == 2 | 3; lean kernel family 3): everything accumulated so far is
 // multiplied by F(u_k), u_k = x - s + k D -- the envelope the piece's carriers share, where F has no recurrence form.
 __device__ __forceinline__ double udbl(double v) {   // a wave-uniform double read from LDS: pinned to an SGPR pair
@@ -1472,6 +1509,18 @@ wfk_sample_lean(const KArgs a) {
               }
               st[0] = cd.c; st[64] = cd.s; st[128] = cd.wc; st[192] = cd.ws;
               if (cenv) { st[256] = cd.g; st[320] = cd.r; }
+              continue;
+            }
+          }
+          if constexpr (FAM >= 1) {
+            if (fl & WFK_FCE_BANK) {        // a run of bare carriers: one compact loop over its tones
+              const int nb = uni((int)rec[WFK_FCE_SIGMA]);
+              if (fl & 8) {
+                if constexpr (CPLX) fce_bank<T, NS>(s_par, rec, nb, s_st, lane, acci);
+              } else {
+                fce_bank<T, NS>(s_par, rec, nb, s_st, lane, acc);
+              }
+              op += nb - 1;
               continue;
             }
           }
