@@ -595,6 +595,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool fmul_base = erfmod_base && !nolean && !g_no_chirp && !(nofmul_env && nofmul_env[0] == '1') &&
                          !(nomix_env0 && nomix_env0[0] == '1');
   bool piece_fmul_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
+  bool plan_has_bank = false;  // some piece holds a run of bare carriers (tone loop): longer chunks pay there
 
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
                        int64_t s1, int32_t skip = -1) -> bool {   // skip: a factor handled by the caller
@@ -1541,6 +1542,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           piece_fam = std::max(piece_fam, G.fmul ? 3 : (G.chirp ? 2 : ((G.erfmul || G.envmul) ? 1 : 0)));
         }
         if (piece_has_bank) piece_fam = std::max(piece_fam, 1);
+        plan_has_bank = plan_has_bank || piece_has_bank;
         const int32_t piece_ops = (int32_t)groups.size();
         int32_t piece_units = 0;
         for (FceGroup& G : groups) {
@@ -1633,6 +1635,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool tl_mixed = H.tlist && n_lean_pieces > 0 && !lean_ok;
   if (tl_mixed) H.mixed = true;
   H.lean_par = std::max(256, (H.lean_par + 63) / 64 * 64);      // >= the 2 KB every plan had so far
+  const int32_t lean_units_max = H.lean_ops;                     // most state units of a lean piece (phasors + envelopes)
   H.lean_ops = std::max(8, H.lean_ops);                          // likewise: 8 units = 8 KB of state
   auto chunking = [&](bool lean_geom, int32_t& tile, int32_t& tiles_per_chunk, int64_t& chunks_per_ch,
                       std::vector<int32_t>& chunk_first, int lean_cap = WFK_LEAN_TPC, int64_t lean_div = 2048) {
@@ -1647,6 +1650,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // measured best at 8 tiles (= one seed per chunk) on the headline config while a degree-1 op cost
     // 12 instructions per sample, at 5 since the phasor fold (8: same box 3.19 / 6: 3.11 / 5: 3.07 / 4: 3.16 ms);
     // 4 on C2.
+    // Pieces of many ops (multi-tone pulses): a chunk's first tile seeds EVERY op exactly (libm: ~200 instructions
+    // each), which at 5 tiles per chunk is as much work as the ops' own arithmetic -- longer chunks there
+    // (ten tones per pulse, same box: 5 / 10 / 20 / 40 tiles 2.16 / 1.95 / 1.87 / 1.84 ms; four tones 1.34 / 1.27 / 1.22)
+    if (lean_geom && lean_cap == WFK_LEAN_TPC && lean_units_max >= 5 && plan_has_bank) lean_cap = 20;
     const int64_t tpc = total_tiles / (lean_geom ? lean_div : 8192);
     tiles_per_chunk = (int32_t)std::min<int64_t>(lean_geom ? lean_cap : 16, std::max<int64_t>(1, tpc));
     if (const char* e = std::getenv("WFK_TPC")) {   // tuning override

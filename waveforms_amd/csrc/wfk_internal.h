@@ -115,6 +115,9 @@
 #define WFK_LEAN_RESEED 8     // exact libm reseed every this many tiles (fp64 outputs: drift 9e-13 over 128 steps)
 #endif
 #define WFK_LEAN_RESEED_F32 32 // ... float outputs
+#ifndef WFK_LEAN_RESEED_CS
+#define WFK_LEAN_RESEED_CS 64  // ops that carry a phasor only (advanced once per TILE, not per sample): exact reseed every this many tiles
+#endif
 #define WFK_LEAN_TPC 5         // tiles per chunk of a double lean launch (upper limit; WFK_TPC overrides)
 #define WFK_LEAN_TPC_F32 20    // ... whose lean launches take up to this many tiles per chunk (8 for double), as
                               // long as ~8 chunks per resident wave remain (total tiles / 24576: C3 gets 10);

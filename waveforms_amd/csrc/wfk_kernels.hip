@@ -935,23 +935,31 @@ __device__ __forceinline__ void fce_erfmul(const double* r, FceSeeds& sd, double
 // the phasor advance.  The per-op path costs ~70 VALU + ~50 scalar instructions of dispatch and set-up per op and
 // tile on top of the same arithmetic (PMC, ten tones: 80 VALU + 30 SALU instructions per sample; rocprof r04 multitone).
 template <typename T, int NS>
-__device__ __forceinline__ void fce_bank(const double* blk, const double* rec0, int n, double* s_st, int lane,
+__device__ __forceinline__ void fce_bank(const double* blk, const double* gblk, const double* rec0, int n, double* s_st, int lane,
                                          T (&acc)[NS]) {
   constexpr int SB = 4;
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const double* r = rec0 + i * WFK_FCE_REC;
     const int fl = uni(WFK_FCE_WORD(r));
-    const double2* tab = reinterpret_cast<const double2*>(blk + WFK_FCE_TABOFF(fl));
+#ifndef WFK_BANK_LDS
+    // the phasor table through the SCALAR cache (the block's image in global memory): the entries arrive in SGPRs and
+    // the FMAs take them as scalar operands -- 17 wave-wide LDS broadcasts per tone and tile less, and the 32 VGPRs of
+    // their double buffer (ten tones, same box: 2.15 -> 1.76 ms; -DWFK_BANK_LDS: the LDS form)
+    const WFK_CONST double* tabd = reinterpret_cast<const WFK_CONST double*>(reinterpret_cast<uintptr_t>(gblk + WFK_FCE_TABOFF(fl)));
+#else
+    const double* tabd = blk + WFK_FCE_TABOFF(fl);
+#endif
+    auto tab = [&](int k) __attribute__((always_inline)) { return make_double2(tabd[2 * k], tabd[2 * k + 1]); };
     double* const st = s_st + WFK_FCE_STOFF(fl) + lane;
     const double c = st[0], sn = st[64];
     const double A0 = r[WFK_FCE_A];
     const T ac = (T)(A0 * c), as = (T)(A0 * sn);
     double2 tb[2][SB];
-    WFK_EACH(SB, kk) tb[0][kk] = tab[kk]; WFK_END
+    WFK_EACH(SB, kk) tb[0][kk] = tab(kk); WFK_END
     WFK_EACH(NS / SB, kb)
       if constexpr ((kb + 1) * SB < NS) {
-        WFK_EACH(SB, kk) tb[(kb + 1) & 1][kk] = tab[(kb + 1) * SB + kk]; WFK_END
+        WFK_EACH(SB, kk) tb[(kb + 1) & 1][kk] = tab((kb + 1) * SB + kk); WFK_END
       }
       WFK_EACH(SB, kk)
         constexpr int k = kb * SB + kk;
@@ -960,7 +968,7 @@ __device__ __forceinline__ void fce_bank(const double* blk, const double* rec0, 
         acc[k] = __builtin_fma(-as, (T)cs.y, acc[k]);
       WFK_END
     WFK_END
-    const double2 e = tab[NS];
+    const double2 e = tab(NS);
     st[0] = c * e.x - sn * e.y;
     st[64] = sn * e.x + c * e.y;
   }
@@ -1406,6 +1414,7 @@ wfk_sample_lean(const KArgs a) {
   int state_piece = -1;       // piece whose op state sits in LDS ...
   int64_t state_w0 = -1;      // ... valid for the tile that starts here
   int since_seed = 0;
+  int cs_age = 0;             // tiles since the pure-phasor ops of the piece in LDS were seeded exactly
 
   OutR* const outr = uniptr(reinterpret_cast<OutR*>(a.out) + (int64_t)ch * a.ch_stride);
   OutC* const outc = uniptr(reinterpret_cast<OutC*>(a.out) + (int64_t)ch * a.ch_stride);
@@ -1440,12 +1449,24 @@ wfk_sample_lean(const KArgs a) {
         const int nops = uni((int)s_par[1]);
         double x = grid_time(a, j0);
         if (C.tshift != 0.0) x = x - C.tshift;
-        const bool carried = state_piece == q && state_w0 == w0 && since_seed < a.reseed;
+        const bool valid = state_piece == q && state_w0 == w0;
+        const bool carried = valid && since_seed < a.reseed;
         if (!carried) {
-          // seed phase: libm, nothing else live
+          // seed phase: libm, nothing else live.  A phasor that is only advanced once per tile (seed x table entry per
+          // sample, one complex product per tile) drifts by ~1e-16 per TILE: on a periodic reseed -- there for the
+          // per-sample envelope recurrences -- ops that carry nothing but a phasor are skipped WFK_LEAN_RESEED_CS
+          // tiles long (ten tones per pulse: 10 of 11 seeds, ~9 VALU instructions per sample)
+          bool seed_cs = true;
+          if constexpr (!CORR) {
+            seed_cs = !valid || cs_age >= WFK_LEAN_RESEED_CS;
+          }
+          if (seed_cs) cs_age = 0;
           for (int op = 0; op < nops; ++op) {
             const double* srec = s_par + WFK_BLK_HDR + op * WFK_FCE_REC;
             const int sfl = uni(WFK_FCE_WORD(srec));
+            if constexpr (!CORR) {
+              if (!seed_cs && (sfl & (WFK_FCE_HAS_CS | WFK_FCE_HAS_GR | WFK_FCE_CHIRP)) == WFK_FCE_HAS_CS) continue;
+            }
             if constexpr (FAM >= 2) {
               if (sfl & WFK_FCE_CHIRP) {      // state: (c, s), the step phasor (wc, ws), then (g, r)
                 const ChirpSeeds cd = chirp_make_seeds(srec, x, sfl);
@@ -1516,9 +1537,9 @@ wfk_sample_lean(const KArgs a) {
             if (fl & WFK_FCE_BANK) {        // a run of bare carriers: one compact loop over its tones
               const int nb = uni((int)rec[WFK_FCE_SIGMA]);
               if (fl & 8) {
-                if constexpr (CPLX) fce_bank<T, NS>(s_par, rec, nb, s_st, lane, acci);
+                if constexpr (CPLX) fce_bank<T, NS>(s_par, a.params + P.par_off, rec, nb, s_st, lane, acci);
               } else {
-                fce_bank<T, NS>(s_par, rec, nb, s_st, lane, acc);
+                fce_bank<T, NS>(s_par, a.params + P.par_off, rec, nb, s_st, lane, acc);
               }
               op += nb - 1;
               continue;
@@ -1560,6 +1581,7 @@ wfk_sample_lean(const KArgs a) {
         state_piece = q;
         state_w0 = w0 + WT;
         ++since_seed;
+        ++cs_age;
       }
       // tile base pinned to SGPRs: the stores become `global_store v_lane_off, data, s[base]
       // offset:k*512` (one address VGPR instead of a hoisted 64-bit pointer pair per store)
