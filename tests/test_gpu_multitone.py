@@ -119,3 +119,36 @@ def test_mixed_plan_lean_plateau_generic_edges():
         assert np.max(np.abs(single.run_host(np.float64) - want)) <= 1e-11
     finally:
         del os.environ['WFK_DISABLE_MIXED']
+
+
+@pytest.mark.parametrize('env', ['gauss', 'flat', 'none'])
+def test_tone_loop_on_long_pieces(env, monkeypatch):
+    """Runs of bare carriers go through the lean kernel's rolled tone loop (WFK_FCE_BANK): 20 tiles per chunk, the
+    phasors advanced tile by tile without the periodic reseed of the envelope recurrences.  Long pieces (hundreds of
+    tiles), real and complex amplitudes, float outputs; the same plan with the loop off gives the same numbers."""
+    rng = np.random.default_rng({'gauss': 1, 'flat': 2, 'none': 3}[env])
+    span = 4e-6
+
+    def chan(cplx):
+        w = wf.zero()
+        for k in range(3):
+            e = {'gauss': wf.gaussian(0.8 * span / 3), 'flat': wf.square(0.7 * span / 3, edge=0.05 * span / 3),
+                 'none': wf.square(0.9 * span / 3)}[env]
+            w = w + ((e >> ((k + 0.5) * span / 3)) * tones(rng, 7 if k != 1 else 10, cplx))
+        return w
+    chans = [chan(False), chan(True)]
+    grid = ('linspace', 0.0, span, 2_000_000, False)
+    prog = _flatten.flatten(chans)
+    g = _flatten.grid_from_desc(grid)
+    ora = c_oracle.eval_grid(prog, g, True)
+    pk = max(1.0, float(np.abs(ora).max()))
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.kernel_name(np.complex128).startswith('wfk_sample_lean<double,true,16,false,1>'), plan.kernel_name(np.complex128)
+    got = plan.run_host(np.complex128)
+    assert np.max(np.abs(got - ora)) <= 1e-11 * pk
+    assert np.max(np.abs(plan.run_host(np.float64) - ora.real)) <= 1e-11 * pk
+    assert np.max(np.abs(plan.run_host(np.complex64) - ora)) <= FP32_TOL * pk
+    monkeypatch.setenv('WFK_NO_BANK', '1')
+    off = _engine.Plan(prog, grid=g).run_host(np.complex128)
+    assert np.max(np.abs(off - ora)) <= 1e-11 * pk
+    assert np.max(np.abs(off - got)) <= 1e-12 * pk
