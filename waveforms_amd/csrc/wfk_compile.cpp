@@ -939,7 +939,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       const size_t at = (size_t)it->second * 2;
       if (at + 2 * (size_t)(m + 1) > H.pool.size()) continue;          // (rolled back with its piece)
       bool same = true;
-      for (int64_t j = 0; j < m && same; ++j) same = std::memcmp(&H.pool[at + 2 * (size_t)j], &fp[j], 8) == 0;
+      for (int64_t j = 0; j < m && same; ++j) {
+        const double dj = j + 1 < m ? fp[j + 1] - fp[j] : 0.0;
+        same = std::memcmp(&H.pool[at + 2 * (size_t)j], &fp[j], 8) == 0 && std::memcmp(&H.pool[at + 2 * (size_t)j + 1], &dj, 8) == 0;
+      }
       same = same && H.pool[at + 2 * (size_t)m + 1] == 0.0 && std::memcmp(&H.pool[at + 2 * (size_t)m], &fp[m - 1], 8) == 0;
       if (same) return it->second;
     }
