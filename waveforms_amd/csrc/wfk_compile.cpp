@@ -683,20 +683,29 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           break;
         }
         case WFK_GAUSSIAN: {
-          if (pw != 1.0 || has_env) return false;
+          // exp(-(u/s)^2)^p = exp(-(u / (s / sqrt p))^2): a power of a Gaussian is a narrower (p > 1) or wider one
+          // (the reference takes np.power of the value: the same number to (u/s)^2 p x 2^-52 <= 2e-13 relative)
+          if (!(pw > 0.0) || !std::isfinite(pw) || has_env) return false;
+          const double sg_eff = pw == 1.0 ? a[0] : a[0] / std::sqrt(pw);
+          if (!std::isfinite(sg_eff) || sg_eff == 0.0) return false;
           bool ok64;
-          gauss_range(a[0], sh, tshift, s0, s1, ok64, env32);
-          if (!ok64 || !rate_safe(0.86 / a[0], s0, s1)) return false;
-          has_env = true; sigma = a[0]; sg = sh;
+          gauss_range(sg_eff, sh, tshift, s0, s1, ok64, env32);
+          if (!ok64 || !rate_safe(0.86 / sg_eff, s0, s1)) return false;
+          has_env = true; sigma = sg_eff; sg = sh;
           break;
         }
         case WFK_COS: {
-          if (pw != 1.0 || !std::isfinite(a[0]) || !std::isfinite(sh)) return false;
-          if (ncos == 0) first_cos_shift = sh;
-          ++ncos;
-          if (!times({{1.0L, (long double)a[0], (long double)a[0] * sh}})) return false;
-          const double ua = (ax.at(s0) - tshift) - sh, ub = (ax.at(s1 - 1) - tshift) - sh;
-          cosf.push_back({std::fabs(a[0]), sh, std::fabs(a[0]) * std::max(std::fabs(ua), std::fabs(ub))});
+          // cos^2, cos^3: the factor taken two / three times by product-to-sum (no rounding correction then: the
+          // reference rounds the phase ONCE and raises the cosine, which the corrected form does not mimic)
+          if (!(pw == 1.0 || pw == 2.0 || pw == 3.0) || !std::isfinite(a[0]) || !std::isfinite(sh)) return false;
+          if (pw != 1.0) has_drag = true;
+          for (int rep = 0; rep < (int)pw; ++rep) {
+            if (ncos == 0) first_cos_shift = sh;
+            ++ncos;
+            if (!times({{1.0L, (long double)a[0], (long double)a[0] * sh}})) return false;
+            const double ua = (ax.at(s0) - tshift) - sh, ub = (ax.at(s1 - 1) - tshift) - sh;
+            cosf.push_back({std::fabs(a[0]), sh, std::fabs(a[0]) * std::max(std::fabs(ua), std::fabs(ub))});
+          }
           break;
         }
         case WFK_EXP: {
