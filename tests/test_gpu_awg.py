@@ -243,3 +243,37 @@ def test_bench_shape_2048_rows_full_size(duty30):
     assert bool((y.view(tile, rows // tile, n) == y[:rows // tile].unsqueeze(0)).all())
     sf.close()
     bs.close()
+
+
+def test_generic_shapes_at_awg_rates_are_evaluated_pointwise(monkeypatch):
+    """Pieces of AWG-rate length whose shapes the short tier does not take (libm chirps, sinc, derivatives of
+    mollifiers): the standard tiers would walk every 60-sample piece over whole wave tiles of 1024 samples, so such a
+    grid plan is compiled on the grid's own sample times and runs on the time-list tier, one sample per lane
+    (wfk_api.cpp: plan_create).  Same numbers as the standard tiers (WFK_NO_POINTWISE_GRID=1) and as the oracle."""
+    rng = np.random.default_rng(11)
+    W = wl.SPAN
+    shapes = [lambda: wf.chirp(8e7, 2.5e8, W, type='exponential') * wf.cosPulse(W),
+              lambda: wf.sinc(6 / W) * wf.square(W) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8)),
+              lambda: wf.mixing(wf.mollifier(W), freq=rng.uniform(-2e8, 2e8), DRAGScaling=1e-10)[0]]
+    chans = [wl._tree_sum([rng.uniform(0.2, 1) * mk() >> ((k + 0.5) * W) for k in range(300)]) for mk in shapes]
+    grid = wl.awg_grid(20_000, 2e9)
+    prog = _flatten.flatten(chans)
+    g = _flatten.grid_from_desc(grid)
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.kernel_name() == 'wfk_sample<double,false,true,true,true,1>', plan.kernel_name()
+    ref = c_oracle.eval_grid(prog, g)
+    pk = float(np.abs(ref).max())
+    got = plan.run_host(np.float64)
+    assert np.max(np.abs(got - ref)) <= 1e-11 * pk
+    assert np.max(np.abs(plan.run_host(np.float32) - ref)) <= FP32_TOL * pk
+    # a time slice of the grid (wfk_grid.i0) is those samples of the whole
+    sl = _engine.Plan(prog, grid=_flatten.grid_slice(g, 5000, 12000)).run_host(np.float64)
+    assert np.array_equal(sl, got[:, 5000:12000])
+    monkeypatch.setenv('WFK_NO_POINTWISE_GRID', '1')
+    std = _engine.Plan(prog, grid=g)
+    assert std.kernel_name().startswith('wfk_sample<double,false,false,'), std.kernel_name()
+    assert np.max(np.abs(std.run_host(np.float64) - ref)) <= 1e-9 * pk
+    monkeypatch.delenv('WFK_NO_POINTWISE_GRID')
+    # long pieces of the same shapes stay on the standard tiers
+    long_grid = ('linspace', 0.0, 300 * W, 3_000_000, False)
+    assert not _engine.Plan(prog, grid=_flatten.grid_from_desc(long_grid)).kernel_name().startswith('wfk_sample<double,false,true')

@@ -264,6 +264,7 @@ def test_three_evaluation_tiers_agree(name, monkeypatch):
     a = fused.run_host(np.float64)[0]
     a32 = fused.run_host(np.float32)[0]
     monkeypatch.setenv('WFK_DISABLE_FUSE', '1')
+    monkeypatch.setenv('WFK_NO_POINTWISE_GRID', '1')     # (short pieces without fusion would be evaluated pointwise: not the tiers compared here)
     perfac = _engine.Plan(prog, grid=g)
     assert perfac.info.n_fused == 0
     assert perfac.info.n_fast > 0 or name in ('pow3_term', 'drag_block', 'drag_plateau',

@@ -234,6 +234,27 @@ static int plan_create(const wfk_program* prog, const wfk_grid* grid, const doub
     delete p;
     return fail(rc, err);
   }
+  // A grid whose pieces are tens to hundreds of samples long (AWG rates) with shapes the short tier does not take
+  // (libm shapes, chirps, sinc, derivatives of mollifiers ...): the standard tiers would evaluate EVERY piece over whole
+  // wave tiles of 1024 samples -- 30 to 300 times the work.  The time-list tier evaluates sample by sample (its fused
+  // groups pointwise, the rest by device libm at the exact NumPy times): the plan is compiled on the grid's own sample
+  // times, one sample per lane.  (8 bytes per grid point of device memory, shared by all channels.)
+  std::vector<double> grid_t;
+  const char* nopw = std::getenv("WFK_NO_POINTWISE_GRID");
+  if (grid && p->h.short_gave_up && grid->n > 0 && grid->n <= ((int64_t)1 << 24) && !(nopw && nopw[0] == '1')) {
+    grid_t.resize((size_t)grid->n);
+    wfk_internal_grid_times(grid, grid_t.data());
+    HostPlan h2;
+    std::string err2;
+    wfk_internal_tlist_ns(WFK_NS_TLIST_SMALL);
+    const int rc2 = wfk_compile(prog, nullptr, grid_t.data(), grid->n, h2, err2);
+    wfk_internal_tlist_ns(0);
+    if (rc2 == WFK_OK) {
+      h2.grid_as_tlist = true;
+      p->h = std::move(h2);
+      tlist = grid_t.data();
+    }
+  }
   rc = plan_upload(p, tlist);
   if (rc) {
     wfk_plan_destroy(p);

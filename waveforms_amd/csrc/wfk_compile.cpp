@@ -128,6 +128,13 @@ struct BlockBuilder {
 static thread_local bool g_no_short_fmul = false;   // the FIR chain's sampler plan: fir_short has no table / mollifier multipliers, such pieces stay with the general kernel
 void wfk_internal_no_short_fmul(bool on) { g_no_short_fmul = on; }
 static thread_local bool g_no_chirp = false;   // second compile of a plan that mixes corrected carriers and chirps
+static thread_local int g_tlist_ns = 0;        // samples per lane of this thread's next time-list compiles (0: by size)
+void wfk_internal_tlist_ns(int ns) { g_tlist_ns = ns; }
+// the sample times of a grid, as NumPy forms them (this file is built -ffp-contract=off)
+void wfk_internal_grid_times(const wfk_grid* g, double* out) {
+  const TimeAxis ax{g, nullptr, g->n};
+  for (int64_t i = 0; i < g->n; ++i) out[i] = ax.at(i);
+}
 
 // want_short: -1 = decide from the mean live piece length (grid plans), 0 = never.  Returns
 // WFK_RETRY_STD when the short geometry was chosen but some piece cannot run in it.
@@ -154,6 +161,8 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   // compiled for the contiguous-lane geometry of wfk_short.hip first; a piece that tier cannot take
   // (generic terms, erf edges, corrected carriers) sends the whole plan back to the standard tiers.
   int rc = compile_impl(P, grid, tlist, n_tlist, H, err, true, 64, 0, -1);
+  const bool gave_up = rc == WFK_RETRY_STD;
+  const double mean_len = H.mean_piece_len;      // (of the first compile: the later ones do not take the short-tier decision)
   if (rc == WFK_RETRY_STD) rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
   else if (rc == WFK_OK && H.shortp && H.short_needs_corr) {
     // far from t = 0 fast carriers need the per-sample rounding correction, which only the lean kernel
@@ -172,6 +181,13 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
     if (rc == WFK_OK && H.n_corr > 0 && !H.lean && !H.mixed) rc = compile_impl(P, grid, tlist, n_tlist, H, err, false);
     g_no_chirp = false;
   }
+  // pieces of AWG-rate length that the short tier could not take: the standard tiers walk every piece over whole wave
+  // tiles of 1024 samples (wfk_api.cpp: such grid plans are evaluated pointwise instead)
+  // (not where the standard compile came out lean: chirp pulses stay on the lean kernel's chirp family, measured
+  //  12.6 ms against 17.6 pointwise on 2048 x 1e5 at 2 GS/s)
+  //  12.6 ms against 17.6 pointwise on 2048 x 1e5 at 2 GS/s; and only for pieces well below a wave tile: from a few
+  //  hundred samples per piece on, the general kernel's per-factor fast paths cost less than pointwise libm)
+  if (rc == WFK_OK) H.short_gave_up = gave_up && grid != nullptr && !H.lean && !H.mixed && mean_len > 0.0 && mean_len < 192.0;
   return rc;
 }
 
@@ -191,7 +207,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (grid->i0 < 0) { err = "negative grid.i0"; return WFK_EINVAL; }
     if (ax.n > 1 && !(grid->step > 0)) { err = "grid step must be positive"; return WFK_EINVAL; }
   }
-  H.ns = H.tlist ? (ax.n < WFK_TLIST_SMALL_N ? WFK_NS_TLIST_SMALL : WFK_NS_TLIST) : WFK_NS_GRID;
+  H.ns = H.tlist ? (g_tlist_ns > 0 ? g_tlist_ns : (ax.n < WFK_TLIST_SMALL_N ? WFK_NS_TLIST_SMALL : WFK_NS_TLIST)) : WFK_NS_GRID;
   if (ns_override > 0 && !H.tlist) H.ns = ns_override;
   H.tile = WFK_WG * H.ns;
   int NS = H.ns;
@@ -299,6 +315,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (mode != 0 && live > 0 && (mode == 1 || live_samples < maxlen * live)) {
       shortm = true;
     }
+    H.mean_piece_len = live > 0 ? (double)live_samples / (double)live : 0.0;
   }
   // geometry of the piece being built: lanes one sample apart (short tier) or `lane_stride` apart
   auto set_geom = [&](bool sh) {

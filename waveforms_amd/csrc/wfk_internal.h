@@ -282,6 +282,9 @@ struct HostPlan {
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most state units (128 doubles) of a piece
   // short tier (WFK_SH_*): `params` then holds the compact records
   bool shortp = false;
+  double mean_piece_len = 0.0;     // grid plans: mean length of the live member pieces in samples (the short-tier decision)
+  bool short_gave_up = false;      // grid plan: the pieces are of AWG-rate length but the short tier could not take most of them
+  bool grid_as_tlist = false;      // ... and the plan was therefore compiled on the grid's sample times as a time list (wfk_api.cpp)
   bool short_has_fmul = false;     // some short piece closes with a table / mollifier multiplier (wfk_sample_short evaluates them, fir_short does not)
   bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
   std::vector<ShortUnit> s_units;
@@ -314,6 +317,8 @@ struct ShortWin {        // one half of one pair of windows of one channel
 int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half, int64_t npairs,
                       std::vector<ShortWin>& wins, std::vector<uint32_t>& entries, std::string& err);
 
+void wfk_internal_tlist_ns(int ns);                                   // samples per lane of this thread's next time-list compiles (0: by size)
+void wfk_internal_grid_times(const wfk_grid* g, double* out);         // out[g->n]: the grid's sample times, as NumPy forms them
 // this thread's next plan compiles keep table / mollifier multipliers out of short pieces (the FIR chain's sampler plan)
 void wfk_internal_no_short_fmul(bool on);
 
