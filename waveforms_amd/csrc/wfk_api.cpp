@@ -438,6 +438,8 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
   a.lean_ops = p->h.lean_ops;
   a.corr = p->h.n_corr > 0 ? 1 : 0;
   a.lean_fam = p->h.lean_fam;
+  a.wavepriv = (p->h.tlist && p->h.ns == WFK_NS_TLIST_SMALL && p->h.max_block_len <= WFK_LDS_DOUBLES / 4 &&
+                !std::getenv("WFK_NO_WAVEPRIV")) ? 1 : 0;
   a.reseed = WFK_LEAN_RESEED;
   // float outputs of the lean launch: longer chunks, rarer exact reseeds (HostPlan::f32_*)
   const bool f32_lean = (out_kind == WFK_OUT_F32 || out_kind == WFK_OUT_C64) && p->h.f32_tiles_per_chunk > 0;

@@ -580,6 +580,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       std::memcpy(&B.body[at + WFK_FCE_DEG], &word, sizeof word);
     }
     size_t len = tab_off + B.tables.size();
+    H.max_block_len = std::max<int32_t>(H.max_block_len, (int32_t)len);
     H.params.push_back((double)len);
     H.params.push_back((double)B.n_terms);
     H.params.insert(H.params.end(), B.body.begin(), B.body.end());

@@ -237,6 +237,7 @@ struct KArgs {
   int32_t corr;                // plan holds carriers that need the grid-rounding correction (lean kernel variant)
   int32_t reseed;              // lean kernel: tiles between exact (libm) reseeds of the carried op state
   int32_t lean_fam;            // lean kernel family (HostPlan::lean_fam)
+  int32_t wavepriv;            // one-sample-per-lane time-list builds: every block fits a wave's quarter of the parameter buffer
   int32_t mixed;               // mixed plan: the lean kernel skips the pieces without WFK_PF_LEAN, the general
                                // kernel skips the lean and the zero pieces (two launches, one output)
   int64_t i0;                  // wfk_grid.i0: sample j of the plan is sample i0 + j of the caller's full grid
@@ -282,6 +283,7 @@ struct HostPlan {
   int32_t lean_par = 0, lean_ops = 0;   // largest parameter block (doubles, rounded) / most state units (128 doubles) of a piece
   // short tier (WFK_SH_*): `params` then holds the compact records
   bool shortp = false;
+  int32_t max_block_len = 0;       // longest parameter block of the plan (doubles)
   double mean_piece_len = 0.0;     // grid plans: mean length of the live member pieces in samples (the short-tier decision)
   bool short_gave_up = false;      // grid plan: the pieces are of AWG-rate length but the short tier could not take most of them
   bool grid_as_tlist = false;      // ... and the plan was therefore compiled on the grid's sample times as a time list (wfk_api.cpp)

@@ -1607,7 +1607,7 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENER
 // the body, shared with wfk_sample_wide: T arithmetic / accumulators, E elements of the output
 template <typename T, typename E, bool CPLX, bool TLIST, bool GENERIC, bool DIRECT, int NS, bool SLICE>
 __device__ __forceinline__ void wfk_sample_body(const KArgs& a) {
-  __shared__ __attribute__((aligned(16))) double s_par[WFK_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double s_par_all[WFK_LDS_DOUBLES];
   __shared__ double s_val[DIRECT ? NS * WFK_WG : 1];   // direct-factor values (apply_factor)
   constexpr int WT = 64 * NS;
   constexpr int TILE = WFK_WG * NS;
@@ -1616,6 +1616,10 @@ __device__ __forceinline__ void wfk_sample_body(const KArgs& a) {
 
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
+  // (time-list builds with one sample per lane: wave-private staging of small blocks, see the block loop)
+  constexpr bool WP = TLIST && NS == 1;
+  const bool wp = WP && a.wavepriv != 0;
+  double* const s_par = (WP && wp) ? s_par_all + wave * (WFK_LDS_DOUBLES / 4) : s_par_all;
   const int64_t chunk = xcd_chunk(a);
   if (chunk < 0) return;
   // indices and bases pinned to SGPRs, plan tables read with s_load: see uni64()/cload()
@@ -1673,7 +1677,15 @@ __device__ __forceinline__ void wfk_sample_body(const KArgs& a) {
       int64_t off = P.par_off;
       int len = P.first_len;
       for (int b = 0; b < P.n_blk; ++b) {
-        if (off != staged) {
+        if (WP && wp) {
+          // one-sample-per-lane builds on plans of small blocks: every wave stages for itself, and only the blocks of
+          // pieces that reach into its own 64 samples -- no workgroup barrier (with short pieces the four waves of a
+          // workgroup otherwise take turns: each piece is evaluated by one of them while three wait at its barriers)
+          if (active && off != staged) {
+            for (int i = lane; i < len; i += 64) s_par[i] = a.params[off + i];
+            staged = off;
+          }
+        } else if (off != staged) {
           __syncthreads();  // every wave is done with the previous block
           for (int i = threadIdx.x; i < len; i += WFK_WG) s_par[i] = a.params[off + i];
           __syncthreads();
