@@ -277,3 +277,41 @@ def test_generic_shapes_at_awg_rates_are_evaluated_pointwise(monkeypatch):
     # long pieces of the same shapes stay on the standard tiers
     long_grid = ('linspace', 0.0, 300 * W, 3_000_000, False)
     assert not _engine.Plan(prog, grid=_flatten.grid_from_desc(long_grid)).kernel_name().startswith('wfk_sample<double,false,true')
+
+
+def test_linear_chirps_at_awg_rates_run_on_the_short_tier(monkeypatch):
+    """chirp(f0, f1, T) pulses of 60-240 samples: a quadratic-phase op of the short tier (z_{k+1} = z_k w_k, w_{k+1} = w_k v),
+    under windows with carriers, Gaussian envelopes, complex amplitudes; against the oracle and the same plan with the
+    op off (the lean kernel's chirp family / the general kernel)."""
+    rng = np.random.default_rng(21)
+    W = wl.SPAN
+
+    def pulse(k):
+        T = W * float(rng.choice([1, 2, 4]))
+        ch = wf.chirp(rng.uniform(-2e8, 2e8), rng.uniform(-3e8, 3e8), T, rng.uniform(0, 6))
+        env = [wf.cosPulse(T), wf.square(T), wf.gaussian(T / 3) * wf.square(T), wf.hanning(T) * wf.cos(2 * np.pi * 5e7)][k % 4]
+        amp = rng.uniform(0.2, 1) if k % 5 else complex(rng.uniform(-1, 1), rng.uniform(-1, 1))
+        return amp * ch * env, T
+    chans = []
+    for c in range(3):
+        t, ws = 0.0, []
+        while t < 9e-6:
+            p, T = pulse(len(ws))
+            ws.append(p >> (t + T / 2))
+            t += T
+        chans.append(wl._tree_sum(ws))
+    grid = wl.awg_grid(20_000, 2e9)
+    prog = _flatten.flatten(chans)
+    g = _flatten.grid_from_desc(grid)
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.kernel_name(np.complex128) == 'wfk_sample_short<double,true,false,16>' and plan.info.n_generic == 0
+    ref = c_oracle.eval_grid(prog, g, True)
+    pk = float(np.abs(ref).max())
+    got = plan.run_host(np.complex128)
+    assert np.max(np.abs(got - ref)) <= 5e-11 * pk
+    assert np.max(np.abs(plan.run_host(np.float64) - ref.real)) <= 5e-11 * pk
+    assert np.max(np.abs(plan.run_host(np.complex64) - ref)) <= FP32_TOL * pk
+    monkeypatch.setenv('WFK_NO_SHORT_CHIRP', '1')
+    off = _engine.Plan(prog, grid=g)
+    assert not off.kernel_name(np.complex128).startswith('wfk_sample_short<double,true,false,16>') or ' + ' in off.kernel_name(np.complex128)
+    assert np.max(np.abs(off.run_host(np.complex128) - ref)) <= 1e-9 * pk

@@ -105,6 +105,7 @@ struct FceGroup {
                                 // continuous piecewise-linear function, 3 = mollifier(r) (lean kernel family 3 only)
   int32_t fmul_f = -1;          // ... the program factor it stands for
   long double K = 0;            // chirp: the phase is K t'^2 + W t' - psi_ref (W, psi_ref as for a plain carrier)
+  long double Wl = 0;           // chirp: W before its rounding to double (|W| ~ 2 K |shift|: 2^-53 of it times t' shows in the phase)
   bool chirp = false;
   double tref = 0;              // chirp: reference time inside the piece (the device works in t' - tref)
   bool corr = false;            // carrier needs the per-sample rounding correction (WFK_FCE_PACK bit 7)
@@ -395,7 +396,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool corr_enabled = allow_corr && !shortm && !H.tlist && !(nocorr_env && nocorr_env[0] == '1');
   bool piece_corr_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
   const char* nochirp_env = std::getenv("WFK_DISABLE_CHIRP");
-  const bool chirp_base = !H.tlist && ns_override == 0 && !shortm && !g_no_chirp && !(nochirp_env && nochirp_env[0] == '1');
+  const bool chirp_base = !H.tlist && ns_override == 0 && !g_no_chirp && !(nochirp_env && nochirp_env[0] == '1');
   bool piece_chirp_ok = true;  // likewise: the fused chirp op exists in the lean kernel only
   bool piece_fuse_ok = true;   // time lists: cleared for the second attempt at a piece that kept a generic term (see below)
   bool chirp_ok = false;
@@ -888,7 +889,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         G = &staged.back();
         G->W = W; G->has_env = has_env; G->has_exp = has_exp; G->sigma = sigma; G->sg = sg; G->env32 = env32;
         G->imag = imag;
-        G->K = q.K; G->chirp = is_chirp;
+        G->K = q.K; G->chirp = is_chirp; G->Wl = q.W;
         G->corr = !is_chirp && W != 0.0 && !rate_safe(W, s0, s1);
         G->wm = wm; G->sm = sm;
         G->sref = W == 0.0 ? 0.0 : (ncos == 1 ? cs[0] : (double)(q.Psi / q.W));
@@ -1094,10 +1095,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       // the constant phasor exp(i 2 K D^2)
       const long double PI2 = 6.283185307179586476925286766559005768L;
       const long double tr = G.tref;
-      rec[WFK_FCE_W] = (double)((long double)G.W + 2 * G.K * tr);
+      rec[WFK_FCE_W] = (double)(G.Wl + 2 * G.K * tr);
       rec[WFK_FCE_SREF] = G.tref;
       rec[WFK_FCE_WM] = (double)G.K;
-      rec[WFK_FCE_SM] = (double)remainderl(G.K * tr * tr + (long double)G.W * tr - G.psi_ref, PI2);
+      rec[WFK_FCE_SM] = (double)remainderl(G.K * tr * tr + G.Wl * tr - G.psi_ref, PI2);
       const long double d2 = 2 * G.K * (long double)dstride * (long double)dstride;
       rec[WFK_FCE_TAB] = (double)cosl(d2);
       rec[WFK_FCE_F32OK] = (double)sinl(d2);
@@ -1137,7 +1138,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     int32_t rec_len = 0;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       if (one && gi == 1) continue;
-      rec_len += (groups[gi].deg > 1 || groups[gi].fmul) ? WFK_SH_OP3 : WFK_SH_OP1;
+      rec_len += (groups[gi].deg > 1 || groups[gi].fmul || groups[gi].chirp) ? WFK_SH_OP3 : WFK_SH_OP1;
     }
     n_rec = 0;
     for (int64_t r0 = s0; r0 < s1; r0 += WFK_SH_SUB, ++n_rec) {
@@ -1186,11 +1187,25 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           continue;
         }
         const int env = G.has_exp ? 2 : (G.has_env ? 1 : 0);
-        const uint64_t word = (uint64_t)(uint32_t)((G.deg & 3) | ((G.W != 0.0 ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (env << 4) |
-                                                   (&G == &groups.back() ? WFK_SH_LAST : 0)) |
+        // (a chirp: degree field 2 -- a 16-double record -- and bit 9; its polynomials are of degree <= 1)
+        const uint64_t word = (uint64_t)(uint32_t)((G.chirp ? 2 : (G.deg & 3)) | (((G.W != 0.0 || G.chirp) ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (env << 4) |
+                                                   (&G == &groups.back() ? WFK_SH_LAST : 0) | (G.chirp ? 512 : 0)) |
                               ((uint64_t)(uint32_t)r0 << 32);
         std::memcpy(&o[0], &word, sizeof word);
-        if (G.W != 0.0) {
+        if (G.chirp) {
+          // phase K t'^2 + W t' - psi_ref at sample k after the reference sample x0:
+          //   th0 + k d1 + k^2 d2,  th0 = K x0^2 + W x0 - psi_ref,  d1 = (2 K x0 + W) dt,  d2 = K dt^2
+          // [1] th0 / pi (reduced), [2] d1 / pi, [12] d2 / pi, [3] / [4] (cos, sin)(2 d2): the constant the step phasor advances by
+          const long double dt = (long double)grid->step;
+          const long double th0 = G.K * x0 * x0 + G.Wl * x0 - G.psi_ref;
+          const long double d1 = (2 * G.K * x0 + G.Wl) * dt, d2 = G.K * dt * dt;
+          o[1] = (double)remainderl(th0 / PIl, 2.0L);
+          o[2] = (double)(d1 / PIl);
+          o[12] = (double)(d2 / PIl);
+          o[3] = (double)cosl(2 * d2);
+          o[4] = (double)sinl(2 * d2);
+          H.short_has_fmul = true;      // (an op fir_short does not evaluate: the chain's sampler plan keeps such pieces off the short tier)
+        } else if (G.W != 0.0) {
           const long double th0 = (long double)G.W * x0 - G.psi_ref;
           o[1] = (double)remainderl(th0 / PIl, 2.0L);
           const long double dth = (long double)G.W * (long double)grid->step;
@@ -1248,7 +1263,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           o += WFK_SH_OP1;
           continue;
         }
-        if (G.deg > 1) {
+        if (G.chirp) {
+          o += WFK_SH_OP3;
+        } else if (G.deg > 1) {
           o[12] = (double)Ar[2]; o[13] = (double)Ar[3]; o[14] = (double)Br[2]; o[15] = (double)Br[3];
           o += WFK_SH_OP3;
         } else {
@@ -1303,7 +1320,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       bool piece_lean = false;
       for (int attempt = 0; attempt < 2 && !live.empty(); ++attempt) {
         const int32_t corr_before = H.n_corr;
-        chirp_ok = chirp_base && piece_chirp_ok && can_fuse;   // (chirp_base: never in a short plan, whose other pieces run on the general kernel)
+        // (a short plan: in its short pieces only -- the pieces that tier hands on run on the general kernel, which has no chirp op)
+        chirp_ok = chirp_base && piece_chirp_ok && can_fuse && (!shortm || (cur_short && !g_no_short_fmul && !std::getenv("WFK_NO_SHORT_CHIRP")));
         D.flags |= WFK_PF_HAS_TERMS;
         BlockBuilder B;
         auto room_for = [&](size_t need) -> int {
@@ -1545,7 +1563,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
           // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
           bool ok = generic.empty() && !groups.empty() && groups.size() <= 255;
-          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul);
+          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul) && !(G.chirp && G.deg > 1);
           if (!ok) {
             H.params.resize(snap.params); H.pool.resize(snap.pool);
             H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;

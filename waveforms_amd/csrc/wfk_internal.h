@@ -287,7 +287,7 @@ struct HostPlan {
   double mean_piece_len = 0.0;     // grid plans: mean length of the live member pieces in samples (the short-tier decision)
   bool short_gave_up = false;      // grid plan: the pieces are of AWG-rate length but the short tier could not take most of them
   bool grid_as_tlist = false;      // ... and the plan was therefore compiled on the grid's sample times as a time list (wfk_api.cpp)
-  bool short_has_fmul = false;     // some short piece closes with a table / mollifier multiplier (wfk_sample_short evaluates them, fir_short does not)
+  bool short_has_fmul = false;     // some short piece holds an op wfk_sample_short evaluates and fir_short does not (table / mollifier multipliers, chirps)
   bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
   std::vector<ShortUnit> s_units;
   std::vector<uint32_t> s_slots;

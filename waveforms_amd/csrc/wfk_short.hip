@@ -215,8 +215,12 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         const int w = op_word(rc);
         const bool closing = ((w >> 4) & 3) == 3;       // closing multiplier (erf edge, table, mollifier)
         const bool mine = lv && !closing && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
-        const bool cubic = __any(mine && (w & 3) > 1);
-        if (mine) {
+        const bool chirp = (w & 512) != 0;              // quadratic phase (16-double record, polynomials of degree <= 1)
+        const bool cubic = __any(mine && !chirp && (w & 3) > 1);
+        if (__any(mine && chirp)) {
+          if (mine && chirp) short_chirp<R, CPLX>(rc, opp, w, kf, a.step, acc, acci);
+        }
+        if (mine && !chirp) {
           if (cubic) short_op<R, true, CPLX>(rc, opp, w, kf, a.step, acc, acci);
           else short_op<R, false, CPLX>(rc, opp, w, kf, a.step, acc, acci);
         }

@@ -163,6 +163,61 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
   SH_END
 }
 
+// A chirp op (word bit 9; 16-double record): acc[k] += E_k (A(u_k) c_k + B(u_k) s_k) with the QUADRATIC phase
+//   th(k) = th0 + k d1 + k^2 d2   (reference LINEARCHIRP, _waveform.pyx:323-324, times the carriers it is multiplied with).
+// Along the lane z_{k+1} = z_k w_k, w_{k+1} = w_k v with v = exp(i 2 d2) from the record: the complex twin of the
+// Gaussian recurrence, as in the lean kernel's chirp family; both phasors are seeded exactly at the lane's first sample.
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_chirp(const OpRec& o, const double* op, int w, double kf, double step,
+                                            double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+  const int env = (w >> 4) & 3;
+  const double vc = o.b.y, vs = o.c.x, Hh = o.d.x, q = o.d.y;
+  const double A0 = o.e.x, A1 = o.e.y, B0 = o.f.x, B1 = o.f.y;
+  const double d2 = op[12];                          // d2 / pi
+  double c, s, wc, ws;
+  {
+    const double x = fma(kf, fma(kf, d2, o.b.x), o.a.y);          // phase / pi at the lane's first sample
+    const double n = rint(x);
+    sincospi_small(x - n, &s, &c);
+    if (((int)n) & 1) { c = -c; s = -s; }
+    const double y = fma(2.0 * kf + 1.0, d2, o.b.x);              // th(k + 1) - th(k), / pi
+    const double m = rint(y);
+    sincospi_small(y - m, &ws, &wc);
+    if (((int)m) & 1) { wc = -wc; ws = -ws; }
+  }
+  const double vv = fma(kf, Hh, o.c.y);
+  const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
+  const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
+  double g = exp_small(ea), r = exp_small(eb);
+  double u = kf * step;
+  double mr = 1.0, mi = 0.0;
+  if constexpr (CPLX) {
+    if (w & 8) { mr = 0.0; mi = 1.0; }
+  }
+  SH_EACH(R, k)
+    const double pa = fma(A1, u, A0), pb = fma(B1, u, B0);
+    const double val = fma(pa, c, pb * s);
+    if constexpr (CPLX) {
+      const double t = val * g;
+      acc[k] = fma(mr, t, acc[k]);
+      acci[k] = fma(mi, t, acci[k]);
+    } else {
+      acc[k] = fma(val, g, acc[k]);
+    }
+    if constexpr (k + 1 < R) {
+      g *= r;
+      r *= q;
+      const double cn = fma(c, wc, -(s * ws));
+      s = fma(s, wc, c * ws);
+      c = cn;
+      const double wn = fma(wc, vc, -(ws * vs));
+      ws = fma(ws, vc, wc * vs);
+      wc = wn;
+      u += step;
+    }
+  SH_END
+}
+
 // libm erf behind a call: inlined sixteen times into the closing op it would triple the kernel
 static __device__ __attribute__((noinline)) double erf_call(double x) { return erf(x); }
 
