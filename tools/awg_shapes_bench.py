@@ -18,6 +18,15 @@ SHAPES = {
     'ten tones': lambda rng: wf.gaussian(20e-9) * sum((rng.uniform(0.05, 0.2) * wf.cos(2 * np.pi * rng.uniform(-3e8, 3e8), rng.uniform(0, 6)) for _ in range(9)),
                                                    0.1 * wf.cos(2 * np.pi * 1e8)),
 }
+def _mixed(rng):      # one pulse in ten of a libm shape among Gaussian pulses: a mixed short plan
+    if rng.integers(10) == 0:
+        return wf.chirp(rng.uniform(5e7, 1e8), rng.uniform(1.5e8, 3e8), W, type='exponential') * wf.cosPulse(W)
+    return wf.mixing(wf.gaussian(20e-9), freq=rng.uniform(-2e8, 2e8), phase=rng.uniform(0, 6), DRAGScaling=1e-10)[0]
+
+
+SHAPES['1 in 10 exp chirp'] = _mixed
+SHAPES['far (t0 = 1 ms)'] = SHAPES['gaussian+drag']
+SHAPES['two overlapping trains'] = lambda rng: wf.gaussian(20e-9) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8)) + ((wf.gaussian(20e-9) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8))) >> (W / 2))
 names = sys.argv[1:] or list(SHAPES)
 n_pts, rate = 100_000, 2e9
 nseg = int(n_pts / rate / W)
@@ -25,8 +34,10 @@ for name in names:
     chans = []
     for c in range(16):
         rng = np.random.default_rng(900 + c)
-        chans.append(wl._tree_sum([rng.uniform(0.2, 1) * SHAPES[name](rng) >> ((k + 0.5) * W) for k in range(nseg)]))
-    bs = BatchSampler(chans, wl.awg_grid(n_pts, rate), tile=128)
+        t00 = 1e-3 if name.startswith('far') else 0.0
+        chans.append(wl._tree_sum([rng.uniform(0.2, 1) * SHAPES[name](rng) >> (t00 + (k + 0.5) * W) for k in range(nseg)]))
+    grid = ('arange', 1e-3, 1e-3 + n_pts / rate, 1.0 / rate) if name.startswith('far') else wl.awg_grid(n_pts, rate)
+    bs = BatchSampler(chans, grid, tile=128)
     out = torch.empty((bs.n_channels, bs.n), dtype=torch.float64, device='cuda')
     for _ in range(2): bs.launch_torch(out)
     torch.cuda.synchronize()

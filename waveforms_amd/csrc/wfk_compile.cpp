@@ -129,6 +129,8 @@ struct BlockBuilder {
 static thread_local bool g_no_short_fmul = false;   // the FIR chain's sampler plan: fir_short has no table / mollifier multipliers, such pieces stay with the general kernel
 void wfk_internal_no_short_fmul(bool on) { g_no_short_fmul = on; }
 static thread_local bool g_no_chirp = false;   // second compile of a plan that mixes corrected carriers and chirps
+static thread_local bool g_keep_mixed_short = false;   // the FIR chain's sampler plan: fir_short fuses the short pieces, the rest is copied in
+void wfk_internal_keep_mixed_short(bool on) { g_keep_mixed_short = on; }
 static thread_local int g_tlist_ns = 0;        // samples per lane of this thread's next time-list compiles (0: by size)
 void wfk_internal_tlist_ns(int ns) { g_tlist_ns = ns; }
 // the sample times of a grid, as NumPy forms them (this file is built -ffp-contract=off)
@@ -189,6 +191,11 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   //  12.6 ms against 17.6 pointwise on 2048 x 1e5 at 2 GS/s; and only for pieces well below a wave tile: from a few
   //  hundred samples per piece on, the general kernel's per-factor fast paths cost less than pointwise libm)
   if (rc == WFK_OK) H.short_gave_up = gave_up && grid != nullptr && !H.lean && !H.mixed && mean_len > 0.0 && mean_len < 192.0;
+  // A short plan that hands more than a few per cent of its samples on: the general kernel's launch over those pieces costs
+  // ~1.2 ms per per cent on 2e8 samples (every piece over a wave tile), the whole plan evaluated pointwise ~2.5 ms
+  if (rc == WFK_OK && grid && H.shortp && H.mixed && H.foreign_frac >= 0.02 && mean_len > 0.0 && mean_len < 192.0 &&
+      !g_keep_mixed_short && !std::getenv("WFK_KEEP_MIXED_SHORT"))
+    H.short_gave_up = true;
   return rc;
 }
 
@@ -1728,6 +1735,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     H.shortp = true;
     H.lean = false;
     H.mixed = n_foreign_pieces > 0;       // foreign pieces: a second launch of the general kernel
+    H.foreign_frac = n_short_samples > 0 ? (double)n_foreign_samples / (double)(n_short_samples + n_foreign_samples) : 0.0;
     H.tile = 64 * WFK_SH_R;
     for (int32_t c = 0; c < P->n_channels; ++c) {
       ShortUnit U{};

@@ -727,7 +727,9 @@ static int chain_plan_create(const wfk_program* prog, const wfk_grid* grid, cons
   if (kind != WFK_OUT_F64 && kind != WFK_OUT_F32) return chain_fail(WFK_EINVAL, "chain kind must be F64 or F32");
   wfk_chain_plan* p = new wfk_chain_plan();
   p->kind = kind;
+  wfk_internal_keep_mixed_short(true);       // (fir_short samples the short pieces itself: a mixed short plan stays one)
   int rc = wfk_plan_create_grid(prog, grid, &p->sampler);
+  wfk_internal_keep_mixed_short(false);
   if (rc) { wfk_chain_plan_destroy(p); return rc; }
   {
     // pieces that close with a table / mollifier multiplier: fir_short does not evaluate those, the general kernel
@@ -739,7 +741,9 @@ static int chain_plan_create(const wfk_program* prog, const wfk_grid* grid, cons
       wfk_plan_destroy(p->sampler);
       p->sampler = nullptr;
       wfk_internal_no_short_fmul(true);
+      wfk_internal_keep_mixed_short(true);
       rc = wfk_plan_create_grid(prog, grid, &p->sampler);
+      wfk_internal_keep_mixed_short(false);
       wfk_internal_no_short_fmul(false);
       if (rc) { wfk_chain_plan_destroy(p); return rc; }
     }

@@ -284,6 +284,7 @@ struct HostPlan {
   // short tier (WFK_SH_*): `params` then holds the compact records
   bool shortp = false;
   int32_t max_block_len = 0;       // longest parameter block of the plan (doubles)
+  double foreign_frac = 0.0;       // short plans: fraction of the evaluated samples in pieces handed to the general kernel
   double mean_piece_len = 0.0;     // grid plans: mean length of the live member pieces in samples (the short-tier decision)
   bool short_gave_up = false;      // grid plan: the pieces are of AWG-rate length but the short tier could not take most of them
   bool grid_as_tlist = false;      // ... and the plan was therefore compiled on the grid's sample times as a time list (wfk_api.cpp)
@@ -319,6 +320,7 @@ struct ShortWin {        // one half of one pair of windows of one channel
 int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, int64_t half, int64_t npairs,
                       std::vector<ShortWin>& wins, std::vector<uint32_t>& entries, std::string& err);
 
+void wfk_internal_keep_mixed_short(bool on);                          // this thread's next compiles keep mixed short plans (the FIR chain's sampler)
 void wfk_internal_tlist_ns(int ns);                                   // samples per lane of this thread's next time-list compiles (0: by size)
 void wfk_internal_grid_times(const wfk_grid* g, double* out);         // out[g->n]: the grid's sample times, as NumPy forms them
 // this thread's next plan compiles keep table / mollifier multipliers out of short pieces (the FIR chain's sampler plan)
