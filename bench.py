@@ -820,6 +820,21 @@ def run_rank(args):
                                 'fused_ops': int(b2.plan.info.n_fused), 'generic_terms': int(b2.plan.info.n_generic)}
         b2.close()
         del o2
+        shapes = {}
+        for shape in ('flat_top', 'linear_chirp', 'ten_tones', 'exp_chirp'):
+            b2 = BatchSampler([wl.awg_shape_channel(wfm, shape, c) for c in range(16)], wl.awg_grid(), tile=128)
+            o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)
+            ms = timed(lambda: b2.launch_torch(o2), 3, 1)
+            nb = b2.n_channels * b2.n * 8
+            shapes[shape] = {'kernel': b2.plan.kernel_name(), 'kernel_ms': ms, 'msamples_per_s': b2.n_channels * b2.n / (ms * 1e-3) / 1e6,
+                             'frac': nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'fused_ops': int(b2.plan.info.n_fused),
+                             'generic_terms': int(b2.plan.info.n_generic)}
+            b2.close()
+            del o2
+        shapes['workload'] = ('2048 rows (16 distinct x 128) x 1e5 pts at 2 GS/s, 60-sample pulses back to back: flat tops with erf edges / '
+                              'linear chirps (short tier ops), a Gaussian under ten tones, exponential chirps (device libm: evaluated '
+                              'pointwise, one sample per lane)')
+        also['awg_shapes'] = shapes
         also['direct'] = direct
         b2 = BatchSampler([wl.multitone_channel(wfm, c) for c in range(8)], wl.c2_grid(), tile=8)
         o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)

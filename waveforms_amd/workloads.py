@@ -148,6 +148,30 @@ def awg_interp_channel(ns, c, n_pts=100000, rate=2e9, nshapes=8, knots=301):
     return _tree_sum(ws)
 
 
+def awg_shape_channel(ns, shape, c, n_pts=100000, rate=2e9):
+    """One channel of 60-sample pulses of another shape at an AWG sample rate, back to back (bench.py `also.awg_shapes`,
+    tools/awg_shapes_bench.py): 'flat_top' (erf edges under a carrier), 'linear_chirp', 'exp_chirp' (device libm: the
+    pointwise tier), 'ten_tones' (a Gaussian under ten carriers)."""
+    rng = np.random.default_rng(900 + c)
+    nseg = int(n_pts / rate / SPAN)
+
+    def pulse():
+        if shape == 'flat_top':
+            return ns.square(0.6 * SPAN, edge=0.1 * SPAN) * ns.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6))
+        if shape == 'linear_chirp':
+            return ns.chirp(rng.uniform(5e7, 1e8), rng.uniform(1.5e8, 3e8), SPAN) * ns.cosPulse(SPAN)
+        if shape == 'exp_chirp':
+            return ns.chirp(rng.uniform(5e7, 1e8), rng.uniform(1.5e8, 3e8), SPAN, type='exponential') * ns.cosPulse(SPAN)
+        if shape == 'ten_tones':
+            tones = None
+            for _ in range(10):
+                tone = rng.uniform(0.05, 0.2) * ns.cos(2 * np.pi * rng.uniform(-3e8, 3e8), rng.uniform(0, 6))
+                tones = tone if tones is None else tones + tone
+            return ns.gaussian(W) * tones
+        raise ValueError(shape)
+    return _tree_sum([rng.uniform(0.2, 1) * pulse() >> ((k + 0.5) * SPAN) for k in range(nseg)])
+
+
 def awg_grid(n_pts=100000, rate=2e9):
     """np.arange(0, n_pts / rate, 1 / rate): the grid of Waveform.sample (waveform.py:190)."""
     return ('arange', 0.0, n_pts / rate, 1.0 / rate)
