@@ -1183,6 +1183,19 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           o += WFK_SH_OP3;
           continue;
         }
+        if (G.envmul) {
+          // closing op of a multi-tone piece: everything accumulated so far *= the Gaussian the tones share
+          // (word: closing kind 1; [5] v0, [6] H, [7] q as for an op's own Gaussian)
+          const uint64_t word = (uint64_t)(uint32_t)(1 | (3 << 4) | (&G == &groups.back() ? WFK_SH_LAST : 0)) | ((uint64_t)(uint32_t)r0 << 32);
+          std::memcpy(&o[0], &word, sizeof word);
+          const long double Hh = (long double)grid->step / G.sigma;
+          o[5] = (double)((x0 - (long double)G.sg) / G.sigma);
+          o[6] = (double)Hh;
+          o[7] = (double)expl(-2.0L * Hh * Hh);
+          H.short_has_fmul = true;      // (an op fir_short does not evaluate)
+          o += WFK_SH_OP1;
+          continue;
+        }
         if (G.erfmul) {
           // closing op of a flat-top edge: everything accumulated so far *= m0 + m1 erf(v), v = v0 + koff H
           const uint64_t word = (uint64_t)(uint32_t)((3 << 4) | (&G == &groups.back() ? WFK_SH_LAST : 0)) | ((uint64_t)(uint32_t)r0 << 32);
@@ -1537,7 +1550,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // pulse), the envelope is factored out: the ops run without envelope and one closing
         // pseudo-op multiplies the accumulators by it -- 2 instead of 5 FMAs per sample and tone.
         // (From four carriers on: the extra op costs a pair of pieces what it saves them.)
-        if (groups.size() >= 4 && !mod_on && !cur_short) {
+        // (short pieces too: a tone costs a phasor seed and 7 instructions per sample there instead of the seeds of its own
+        //  Gaussian and 13; not for the FIR chain's sampler plan, whose fir_short does not know the closing op)
+        if (groups.size() >= 4 && !mod_on && (!cur_short || (!g_no_short_fmul && !std::getenv("WFK_NO_SHORT_ENVMUL")))) {
           bool shared = true, e32 = true;
           for (const FceGroup& g : groups) {
             shared = shared && g.has_env && !g.has_exp && g.sigma == groups[0].sigma && g.sg == groups[0].sg;
@@ -1570,7 +1585,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
           // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
           bool ok = generic.empty() && !groups.empty() && groups.size() <= 255;
-          for (const FceGroup& G : groups) ok = ok && !(G.corr || G.envmul) && !(G.chirp && G.deg > 1);
+          for (const FceGroup& G : groups) ok = ok && !G.corr && !(G.chirp && G.deg > 1);
           if (!ok) {
             H.params.resize(snap.params); H.pool.resize(snap.pool);
             H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;

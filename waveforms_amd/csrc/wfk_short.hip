@@ -229,7 +229,10 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
           if (__any(lv && closing && own)) {
             if (lv && closing && own && (CPLX || !(w & 8))) short_cmul<R, CPLX>(rc, a.pool, w, kf, acc, acci);
           }
-          const int kind = own ? -1 : (w & 3);      // 0: erf edge; 2: INTERP table, 3: mollifier (stateless multipliers)
+          const int kind = own ? -1 : (w & 3);      // 0: erf edge; 1: shared Gaussian; 2: INTERP table, 3: mollifier (stateless multipliers)
+          if (__any(lv && closing && kind == 1)) {
+            if (lv && closing && kind == 1) short_envmul<R, CPLX>(rc, kf, acc, acci);
+          }
           if (__any(lv && closing && kind == 0)) {
             if (lv && closing && kind == 0) short_erfmul<R, CPLX>(rc, kf, acc, acci);
           }

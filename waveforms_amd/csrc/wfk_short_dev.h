@@ -108,10 +108,12 @@ __device__ __forceinline__ int op_ref(const OpRec& r) { return (int)__double2hii
 
 // one fused op over the lane's run: acc[k] += E_k (A(u_k) c_k + B(u_k) s_k), all state per lane.
 // `kf`: samples between the record's reference sample and the lane's first one.
-template <int R, bool CUBIC, bool CPLX>
+// ENV = false: no lane of the wave has an envelope on this op (the tones of a multi-tone piece, cosine pulses): no
+// envelope seeds (two inline exponentials per lane) and no recurrence.
+template <int R, bool CUBIC, bool CPLX, bool ENV = true>
 __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w, double kf, double step,
                                          double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
-  const int env = (w >> 4) & 3;
+  const int env = ENV ? (w >> 4) & 3 : 0;
   const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.x, q = o.d.y;
   const double A0 = o.e.x, A1 = o.e.y, B0 = o.f.x, B1 = o.f.y;
   double A2 = 0.0, A3 = 0.0, B2 = 0.0, B3 = 0.0;
@@ -126,10 +128,14 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
     sincospi_small(x - n, &s, &c);
     if (((int)n) & 1) { c = -c; s = -s; }
   }
-  const double vv = fma(kf, Hh, o.c.y);
-  const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
-  const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
-  double g = exp_small(ea), r = exp_small(eb);
+  double g = 1.0, r = 1.0;
+  if (ENV && __any(env != 0)) {       // (no lane with an envelope -- the tones of a multi-tone piece, cosine pulses: no envelope seeds)
+    const double vv = fma(kf, Hh, o.c.y);
+    const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
+    const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
+    g = exp_small(ea);
+    r = exp_small(eb);
+  }
   double u = kf * step;
   double mr = 1.0, mi = 0.0;
   if constexpr (CPLX) {
@@ -146,15 +152,18 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
     }
     const double val = fma(pa, c, pb * s);
     if constexpr (CPLX) {
-      const double t = val * g;
+      const double t = ENV ? val * g : val;
       acc[k] = fma(mr, t, acc[k]);
       acci[k] = fma(mi, t, acci[k]);
     } else {
-      acc[k] = fma(val, g, acc[k]);
+      if constexpr (ENV) acc[k] = fma(val, g, acc[k]);
+      else acc[k] += val;
     }
     if constexpr (k + 1 < R) {
-      g *= r;
-      r *= q;
+      if constexpr (ENV) {
+        g *= r;
+        r *= q;
+      }
       const double cn = fma(c, C1, -(s * S1));
       s = fma(s, C1, c * S1);
       c = cn;
@@ -214,6 +223,23 @@ __device__ __forceinline__ void short_chirp(const OpRec& o, const double* op, in
       ws = fma(ws, vc, wc * vs);
       wc = wn;
       u += step;
+    }
+  SH_END
+}
+
+// Closing op of a multi-tone piece (closing kind 1): the Gaussian the piece's tones share multiplies what they accumulated
+// (g_k by the two-multiplier recurrence from exact seeds, as an op's own envelope)
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_envmul(const OpRec& o, double kf, double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+  const double Hh = o.d.x, q = o.d.y;
+  const double vv = fma(kf, Hh, o.c.y);
+  double g = exp_small(-(vv * vv)), r = exp_small(-Hh * (2.0 * vv + Hh));
+  SH_EACH(R, k)
+    acc[k] *= g;
+    if constexpr (CPLX) acci[k] *= g;
+    if constexpr (k + 1 < R) {
+      g *= r;
+      r *= q;
     }
   SH_END
 }
