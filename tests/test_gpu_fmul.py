@@ -166,7 +166,7 @@ def test_optimised_pulses_at_awg_rates_run_on_the_short_tier():
 
 
 def test_short_tier_mollifiers_complex_amplitudes_offsets_and_mixed_plans(monkeypatch):
-    # (a short plan that hands more than 2 % of its samples on is evaluated pointwise as a whole: keep the mixed form here)
+    # (a short plan that hands more than 5 % of its samples on is evaluated pointwise as a whole: keep the mixed form here)
     monkeypatch.setenv('WFK_KEEP_MIXED_SHORT', '1')
     rng = np.random.default_rng(5)
     moll = wl._tree_sum([rng.uniform(0.3, 1) * (wf.mollifier(30e-9) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6)))

@@ -191,9 +191,11 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   //  12.6 ms against 17.6 pointwise on 2048 x 1e5 at 2 GS/s; and only for pieces well below a wave tile: from a few
   //  hundred samples per piece on, the general kernel's per-factor fast paths cost less than pointwise libm)
   if (rc == WFK_OK) H.short_gave_up = gave_up && grid != nullptr && !H.lean && !H.mixed && mean_len > 0.0 && mean_len < 192.0;
-  // A short plan that hands more than a few per cent of its samples on: the general kernel's launch over those pieces costs
-  // ~1.2 ms per per cent on 2e8 samples (every piece over a wave tile), the whole plan evaluated pointwise ~2.5 ms
-  if (rc == WFK_OK && grid && H.shortp && H.mixed && H.foreign_frac >= 0.02 && mean_len > 0.0 && mean_len < 192.0 &&
+  // A short plan that hands more than a few per cent of its samples on: on 2e8 samples the general kernel's launch over those
+  // pieces costs ~1.25 ms per per cent (every piece over a wave tile) next to 0.4 ms for the short pieces; evaluated pointwise
+  // the fused pieces take ~4.5 ms and the rest 0.34 ms per per cent (rocprofv3 --stats, one exponential chirp in ten
+  // pulses: 12.9 -> 7.9 ms) -- break-even near 4.5 %
+  if (rc == WFK_OK && grid && H.shortp && H.mixed && H.foreign_frac >= 0.05 && mean_len > 0.0 && mean_len < 192.0 &&
       !g_keep_mixed_short && !std::getenv("WFK_KEEP_MIXED_SHORT"))
     H.short_gave_up = true;
   return rc;
