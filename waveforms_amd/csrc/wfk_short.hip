@@ -221,8 +221,8 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
           if (mine && chirp) short_chirp<R, CPLX>(rc, opp, w, kf, a.step, acc, acci);
         }
         if (mine && !chirp) {
-          if (cubic) short_op<R, true, CPLX>(rc, opp, w, kf, a.step, acc, acci);
-          else short_op<R, false, CPLX>(rc, opp, w, kf, a.step, acc, acci);
+          if (cubic) short_op<R, true, CPLX, true>(rc, opp, w, kf, a.step, acc, acci);
+          else short_op<R, false, CPLX, true>(rc, opp, w, kf, a.step, acc, acci);
         }
         if (__any(lv && closing)) {
           const bool own = (w & 128) != 0;      // envelope x carrier in one op: adds its own term
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
             if (lv && closing && kind == 1) short_envmul<R, CPLX>(rc, kf, acc, acci);
           }
           if (__any(lv && closing && kind == 0)) {
-            if (lv && closing && kind == 0) short_erfmul<R, CPLX>(rc, kf, acc, acci);
+            if (lv && closing && kind == 0) short_erfmul_run<R, CPLX>(rc, kf, seg.len, acc, acci);
           }
           if (__any(lv && closing && kind == 2)) {
             if (lv && closing && kind == 2) short_tabmul<R, CPLX>(rc, a.pool, kf, acc, acci);

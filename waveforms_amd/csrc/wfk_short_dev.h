@@ -108,12 +108,13 @@ __device__ __forceinline__ int op_ref(const OpRec& r) { return (int)__double2hii
 
 // one fused op over the lane's run: acc[k] += E_k (A(u_k) c_k + B(u_k) s_k), all state per lane.
 // `kf`: samples between the record's reference sample and the lane's first one.
-// ENV = false: no lane of the wave has an envelope on this op (the tones of a multi-tone piece, cosine pulses): no
-// envelope seeds (two inline exponentials per lane) and no recurrence.
-template <int R, bool CUBIC, bool CPLX, bool ENV = true>
+// SKIP (the sampler; not fir_short, whose 168-register budget the branch overflows): where no lane of the wave has an
+// envelope on this op -- the tones of a multi-tone piece, cosine pulses -- the two inline exponentials of the envelope
+// seeds are skipped.
+template <int R, bool CUBIC, bool CPLX, bool SKIP = false>
 __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w, double kf, double step,
                                          double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
-  const int env = ENV ? (w >> 4) & 3 : 0;
+  const int env = (w >> 4) & 3;
   const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.x, q = o.d.y;
   const double A0 = o.e.x, A1 = o.e.y, B0 = o.f.x, B1 = o.f.y;
   double A2 = 0.0, A3 = 0.0, B2 = 0.0, B3 = 0.0;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
     if (((int)n) & 1) { c = -c; s = -s; }
   }
   double g = 1.0, r = 1.0;
-  if (ENV && __any(env != 0)) {       // (no lane with an envelope -- the tones of a multi-tone piece, cosine pulses: no envelope seeds)
+  if (!SKIP || __any(env != 0)) {
     const double vv = fma(kf, Hh, o.c.y);
     const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
     const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
@@ -152,18 +153,15 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
     }
     const double val = fma(pa, c, pb * s);
     if constexpr (CPLX) {
-      const double t = ENV ? val * g : val;
+      const double t = val * g;
       acc[k] = fma(mr, t, acc[k]);
       acci[k] = fma(mi, t, acci[k]);
     } else {
-      if constexpr (ENV) acc[k] = fma(val, g, acc[k]);
-      else acc[k] += val;
+      acc[k] = fma(val, g, acc[k]);
     }
     if constexpr (k + 1 < R) {
-      if constexpr (ENV) {
-        g *= r;
-        r *= q;
-      }
+      g *= r;
+      r *= q;
       const double cn = fma(c, C1, -(s * S1));
       s = fma(s, C1, c * S1);
       c = cn;
@@ -391,6 +389,22 @@ __device__ __forceinline__ void short_cmul(const OpRec& o, const double* pool, i
       }
     SH_END
     __builtin_amdgcn_sched_barrier(0);
+  SH_END
+}
+// short_erfmul for the sampler: `len` = samples of the lane's run; an edge piece is 6-12 samples, and the erf call is
+// skipped -- for the whole wave, once no lane is left inside its run -- for the samples behind it, which are never stored.
+// (A function of its own: in fir_short the extra branches cost its 168-register budget up to 42 spills.)
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_erfmul_run(const OpRec& o, double kf, int len, double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+  const double h = o.d.x, m0 = o.e.x, m1 = o.e.y;
+  double v = fma(kf, h, o.c.y);
+  SH_EACH(R, k)
+    double e = 0.0;
+    if (k < len) e = erf_call(v);
+    const double m = fma(m1, e, m0);
+    acc[k] *= m;
+    if constexpr (CPLX) acci[k] *= m;
+    v += h;
   SH_END
 }
 
