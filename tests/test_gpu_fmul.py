@@ -174,7 +174,8 @@ def test_short_tier_mollifiers_complex_amplitudes_offsets_and_mixed_plans(monkey
     cplx = wl._tree_sum([complex(rng.uniform(-1, 1), rng.uniform(-1, 1)) * hann(64) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8))
                          >> ((k + 0.5) * 30e-9) for k in range(1600)])
     chans = [moll + 0.25, cplx, (wl.awg_interp_channel(wf, 7) >> 0.2e-9) - 0.5,
-             wl.awg_channel(wf, 3) + (hann(200) * wf.cos(1e9) >> 10e-6) + (hann(100) >> 10.004e-6)]   # two tables overlap: generic there
+             wl.awg_channel(wf, 3) + (hann(200) * wf.cos(1e9) >> 10e-6) +
+             (hann(100) * (wf.cos(2e9) + wf.cos(3e9)) >> 10.004e-6)]   # two tables overlap, one of them over two carriers: generic there
     got, name, info = run(chans, AWG, np.complex128)
     assert name.startswith('wfk_sample_short<double,true,') and ' + wfk_sample<' in name, name     # (a mixed short plan)
     ref = oracle(chans, AWG, True)
@@ -208,3 +209,33 @@ def test_fir_chain_keeps_its_fused_form_next_to_table_envelopes():
     assert np.max(np.abs(sf.to_host() - want)) <= AWG_TOL * np.abs(want).max()
     assert 'fir_short<' in sf.plan.kernel_name() or '+ FIR' in sf.plan.kernel_name()
     sf.close()
+
+
+def test_overlapping_envelopes_in_short_pieces():
+    """Crosstalk-compensated channels: a channel is its own pulses plus scaled copies of its neighbours' -- pulses of
+    DIFFERENT table / mollifier envelopes overlapping in time.  In a short piece every envelope x carrier term is an
+    own-term op (acc += F (A cos + B sin)), so any number of them share a piece; envelopes over several carriers or
+    with complex amplitudes keep the single-envelope forms or go to the exact path."""
+    own = [wl.awg_interp_channel(wf, c, 40_000) for c in range(3)]
+    rng = np.random.default_rng(8)
+    moll = wl._tree_sum([rng.uniform(0.3, 1) * (wf.mollifier(30e-9) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6)))
+                         >> ((k + 0.5) * 30e-9 + 11e-9) for k in range(600)])
+    chans = [own[0] + 0.07 * (own[1] >> 3e-9) - 0.04 * (own[2] >> 7.5e-9),        # three table trains, shifted against each other
+             own[1] + 0.1 * moll,                                                 # tables and mollifiers overlapping
+             own[2] + 0.05 * own[0] + (wf.gaussian(20e-9) * wf.cos(1e9) >> 5.01e-6)]
+    grid = wl.awg_grid(40_000, 2e9)
+    got, name, info = run(chans, grid)
+    assert name == 'wfk_sample_short<double,false,false,16>' and info.n_generic == 0, (name, info.n_generic)
+    ref = oracle(chans, grid)
+    assert np.max(np.abs(got - ref)) <= AWG_TOL * np.abs(ref).max()
+    off, name_off, info_off = run(chans, grid, env={'WFK_NO_SHORT_MULTI': '1'})
+    assert info_off.n_generic > 0
+    assert np.max(np.abs(off - ref)) <= AWG_TOL * np.abs(ref).max()
+    f32, _, _ = run(chans, grid, np.float32)
+    assert np.max(np.abs(f32 - ref)) <= FP32_TOL * np.abs(ref).max()
+    # an envelope over TWO carriers next to another envelope: not an own-term op -- the exact path, same numbers
+    two = (hann(300) * (wf.cos(2e9) + 0.5 * wf.cos(3e9))) >> 1e-6
+    chans = [wl._tree_sum([two >> (k * 30e-9) for k in range(300)]) + 0.1 * (own[0] >> 1e-6)]
+    got, name, info = run(chans, grid)
+    ref = oracle(chans, grid)
+    assert np.max(np.abs(got - ref)) <= AWG_TOL * max(1.0, np.abs(ref).max())

@@ -104,6 +104,7 @@ struct FceGroup {
   int fmul = 0;                 // pseudo-op: multiply them by a stateless function of t - slin: 2 = a finite INTERP table read as a
                                 // continuous piecewise-linear function, 3 = mollifier(r) (lean kernel family 3 only)
   int32_t fmul_f = -1;          // ... the program factor it stands for
+  bool fmul_own = false;        // short tier: the multiplier belongs to the ONE group in front of it (envelope x carrier as one op)
   long double K = 0;            // chirp: the phase is K t'^2 + W t' - psi_ref (W, psi_ref as for a plain carrier)
   long double Wl = 0;           // chirp: W before its rounding to double (|W| ~ 2 K |shift|: 2^-53 of it times t' shows in the phase)
   bool chirp = false;
@@ -1144,9 +1145,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // op followed by the closing multiplier in a record of its own (a dependent load per piece)
     const bool one = groups.size() >= 2 && groups[1].fmul && groups[0].deg == 0 && !groups[0].has_env && !groups[0].has_exp &&
                      !groups[0].erfmul && !groups[0].envmul && !groups[0].chirp && !groups[0].fmul && !std::getenv("WFK_NO_SHORT_CMUL");
+    // (several envelopes in one piece: the host marked every (group, multiplier) pair -- FceGroup::fmul_own)
+    auto own_pair = [&](size_t gi) { return gi + 1 < groups.size() && groups[gi + 1].fmul && (groups[gi + 1].fmul_own || (one && gi == 0)); };
     int32_t rec_len = 0;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
-      if (one && gi == 1) continue;
+      if (gi > 0 && own_pair(gi - 1)) continue;
       rec_len += (groups[gi].deg > 1 || groups[gi].fmul || groups[gi].chirp) ? WFK_SH_OP3 : WFK_SH_OP1;
     }
     n_rec = 0;
@@ -1159,7 +1162,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       double* o = H.params.data() + at;
       for (size_t gi = 0; gi < groups.size(); ++gi) {
         const FceGroup& G = groups[gi];
-        if (one && gi == 1) continue;           // (folded into the record of group 0, below)
+        if (gi > 0 && own_pair(gi - 1)) continue;           // (folded into the record of the group in front of it, below)
         if (G.fmul) {
           // stateless closing multiplier (wfk_short_dev.h: short_tabmul / short_mollmul); the word's degree field
           // (2 | 3) names the kind, so the record is stepped over as a 16-double one.  [5] position at the
@@ -1258,15 +1261,15 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             Br[i] += G.B[m] * f;
           }
         o[8] = (double)Ar[0]; o[9] = (double)Ar[1]; o[10] = (double)Br[0]; o[11] = (double)Br[1];
-        if (one && gi == 0) {
+        if (own_pair(gi)) {
           // envelope x carrier in one op (wfk_short_dev.h: short_cmul): the carrier fields as above, [5] / [6] the
           // envelope's position at the reference sample and its step per sample (knot units | units of r),
           // table: [7] m - 1, [9] first entry in the pool (16-byte entries)
-          const FceGroup& E = groups[1];
+          const FceGroup& E = groups[gi + 1];
           const int32_t f = E.fmul_f;
           const double* fa = P->pool + P->fc_arg_off[f];
           const uint64_t w2 = (uint64_t)(uint32_t)(((G.W != 0.0 ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (3 << 4) |
-                                                   (groups.size() == 2 ? WFK_SH_LAST : 0) | 128 | (E.fmul == 3 ? 256 : 0)) |
+                                                   (gi + 2 == groups.size() ? WFK_SH_LAST : 0) | 128 | (E.fmul == 3 ? 256 : 0)) |
                               ((uint64_t)(uint32_t)r0 << 32);
           std::memcpy(&o[0], &w2, sizeof w2);
           const long double ue = x0 - (long double)P->fc_shift[f];
@@ -1394,8 +1397,21 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // (a short plan: in its short pieces only -- the pieces that tier hands on go to the general kernel)
         const bool fmul_now = fmul_base && piece_fmul_ok && (!shortm || (cur_short && !g_no_short_fmul)) && std::isfinite(ax.at(s0)) && std::isfinite(ax.at(s1 - 1));
         // a term's ONE factor of a kind the closing multipliers take (power 1); -1: none, or not admissible here
+        // Short pieces may hold SEVERAL envelopes (overlapping pulses of different shapes: crosstalk-compensated channels),
+        // as long as each stands over one plain carrier: every such term is an own-term op, acc += F (A cos + B sin).
+        struct XMod { int kind; int32_t f; std::vector<FceGroup> g; };
+        std::vector<XMod> xmods;      // the envelopes after the first one
+        const bool multi_ok = cur_short && !std::getenv("WFK_NO_SHORT_MULTI");
+        auto same_mod = [&](int32_t a_, int32_t b_) {
+          const int64_t na = P->fc_arg_off[a_ + 1] - P->fc_arg_off[a_];
+          if (P->fc_type[a_] != P->fc_type[b_] || P->fc_shift[a_] != P->fc_shift[b_] || na != P->fc_arg_off[b_ + 1] - P->fc_arg_off[b_]) return false;
+          return P->fc_arg_off[a_] == P->fc_arg_off[b_] ||
+                 std::memcmp(P->pool + P->fc_arg_off[a_], P->pool + P->fc_arg_off[b_], (size_t)na * sizeof(double)) == 0;
+        };
+        int fslot = 0;                // fmul_factor_of: 0 the piece's first envelope, i + 1: xmods[i], xmods.size() + 1: a new one
         auto fmul_factor_of = [&](int32_t k, int& kind_out) -> int32_t {
           if (!fmul_now || mod_kind == 1) return -1;
+          fslot = 0;
           int32_t at = -1;
           for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
             if (P->fc_type[f] == WFK_INTERP || P->fc_type[f] == WFK_MOLLIFIER) {
@@ -1410,11 +1426,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           const int kind = P->fc_type[at] == WFK_INTERP ? 2 : 3;
           if (mod_f >= 0) {
             // one multiplier per piece: the same primitive, arguments and shift as the first term's
-            if (kind != mod_kind || sh != P->fc_shift[mod_f] || na != P->fc_arg_off[mod_f + 1] - P->fc_arg_off[mod_f]) return -1;
-            if (P->fc_arg_off[at] != P->fc_arg_off[mod_f] &&
-                std::memcmp(fa, P->pool + P->fc_arg_off[mod_f], (size_t)na * sizeof(double)) != 0) return -1;
-            kind_out = kind;
-            return at;
+            if (same_mod(at, mod_f)) { kind_out = kind; return at; }
+            if (!multi_ok) return -1;
+            for (size_t i = 0; i < xmods.size(); ++i)
+              if (same_mod(at, xmods[i].f)) { fslot = (int)i + 1; kind_out = kind; return at; }
+            fslot = (int)xmods.size() + 1;      // a new envelope: admitted below
           }
           if (kind == 2) {
             // a finite table on increasing linspace knots, slopes inside the grid-rounding budget (as WFK_M_INTERP_LIN)
@@ -1472,9 +1488,18 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           if (fe >= 0 && fuse_term(mgroups, k, C.tshift, s0, s1, fe)) {
             mod_on = true; mod_sigma = esg; mod_shift = esh; mod_kind = 1;
             ++H.n_fused;
-          } else if (ff >= 0 && fuse_term(mgroups, k, C.tshift, s0, s1, ff)) {
+          } else if (ff >= 0 && fslot == 0 && fuse_term(mgroups, k, C.tshift, s0, s1, ff)) {
             mod_on = true; mod_kind = fkind;
             if (mod_f < 0) mod_f = ff;
+            ++H.n_fused;
+          } else if (ff >= 0 && fslot >= 1 && fslot <= (int)xmods.size() && fuse_term(xmods[(size_t)fslot - 1].g, k, C.tshift, s0, s1, ff)) {
+            ++H.n_fused;
+          } else if (ff >= 0 && fslot == (int)xmods.size() + 1 && [&] {
+                       XMod x{fkind, ff, {}};
+                       if (!fuse_term(x.g, k, C.tshift, s0, s1, ff)) return false;
+                       xmods.push_back(std::move(x));
+                       return true;
+                     }()) {
             ++H.n_fused;
           } else if (fuse_now && fuse_term(groups, k, C.tshift, s0, s1)) ++H.n_fused;
           else generic.push_back(k);
@@ -1491,7 +1516,28 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           piece_fuse_ok = false;
           continue;
         }
-        if (mod_on && mod_kind >= 2) {
+        bool multi_bad = false;
+        if (mod_on && mod_kind >= 2 && !xmods.empty()) {
+          // several envelopes: each over ONE plain group (degree 0, no envelope of its own), emitted as own-term ops
+          auto simple = [](const std::vector<FceGroup>& g) {
+            return g.size() == 1 && g[0].deg == 0 && !g[0].has_env && !g[0].has_exp && !g[0].chirp && !g[0].corr;
+          };
+          multi_bad = !simple(mgroups);
+          for (const XMod& x : xmods) multi_bad = multi_bad || !simple(x.g);
+          std::vector<FceGroup> all;
+          if (!multi_bad) {
+            FceGroup E;
+            E.fmul = mod_kind; E.fmul_f = mod_f; E.fmul_own = true;
+            all.push_back(mgroups[0]); all.push_back(E);
+            for (const XMod& x : xmods) {
+              FceGroup Ex;
+              Ex.fmul = x.kind; Ex.fmul_f = x.f; Ex.fmul_own = true;
+              all.push_back(x.g[0]); all.push_back(Ex);
+            }
+            all.insert(all.end(), groups.begin(), groups.end());
+            groups.swap(all);
+          }
+        } else if (mod_on && mod_kind >= 2) {
           // out = F S1 + S0: the groups of the modulated terms, the closing multiplier, then the rest
           FceGroup E;
           E.fmul = mod_kind; E.fmul_f = mod_f;
@@ -1586,7 +1632,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // compact records of the short tier (WFK_SH_*): one per <= WFK_SH_SUB samples of the piece.  A
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
           // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
-          bool ok = generic.empty() && !groups.empty() && groups.size() <= 255;
+          bool ok = generic.empty() && !groups.empty() && groups.size() <= 255 && !multi_bad;
           for (const FceGroup& G : groups) ok = ok && !G.corr && !(G.chirp && G.deg > 1);
           if (!ok) {
             H.params.resize(snap.params); H.pool.resize(snap.pool);
