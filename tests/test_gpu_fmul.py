@@ -121,7 +121,7 @@ def test_what_the_multiplier_does_not_take():
               (env ** 2) >> 1e-6,
               wf.samplingPoints(-SPAN / 2, SPAN / 2, np.r_[np.hanning(50), np.inf, np.hanning(50)]) >> 1e-6,
               wf.mollifier(20e-9, d=1) >> 1e-6,
-              ((env >> 1e-6) * wf.cos(2e9)) + (hann(100) >> 1.004e-6)):      # (two tables where the pulses overlap only)
+              ((env * (wf.cos(2e9) + wf.cos(2.5e9))) >> 1e-6) + (hann(100) >> 1.004e-6)):   # (two tables overlapping, one over two carriers)
         got, name, info = run([w], GRID)
         if info.n_fused:
             assert name.startswith('wfk_sample_lean<double,false,16,false,3> + wfk_sample<'), name   # a mixed plan
@@ -239,3 +239,32 @@ def test_overlapping_envelopes_in_short_pieces():
     got, name, info = run(chans, grid)
     ref = oracle(chans, grid)
     assert np.max(np.abs(got - ref)) <= AWG_TOL * max(1.0, np.abs(ref).max())
+
+
+def test_overlapping_envelopes_on_fine_grids():
+    """The lean kernel's own-term op (WFK_FCE_OWNMUL): overlapping pulses of different table / mollifier envelopes, each
+    over one carrier (or none), complex amplitudes through the single-envelope forms or the exact path."""
+    rng = np.random.default_rng(13)
+
+    def train(mk, n, period, t0=0.0):
+        return wl._tree_sum([rng.uniform(0.3, 1) * mk(k) >> (t0 + (k + 0.5) * period) for k in range(n)])
+    a = train(lambda k: hann(300 + k) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6)), 60, 50e-9)
+    b = train(lambda k: hann(64, 0.8) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8)), 55, 54e-9, 7e-9)
+    m = train(lambda k: wf.mollifier(40e-9) * wf.cos(2 * np.pi * rng.uniform(-1e8, 1e8), 0.3 * k), 50, 60e-9, 3e-9)
+    chans = [a + 0.1 * b, a + 0.05 * b - 0.2 * m, 0.3 * hann(500) * 1.0 >> 1e-6, b + (wf.gaussian(20e-9) * wf.cos(1e9) >> 1.5e-6) + 0.1 * m]
+    chans[2] = chans[2] + (0.2 * hann(100) >> 1.004e-6)          # two bare tables (no carrier) overlapping
+    grid = ('linspace', 0.0, 3e-6, 1_500_000, False)
+    got, name, info = run(chans, grid)
+    assert name == 'wfk_sample_lean<double,false,16,false,4>' and info.n_generic == 0, (name, info.n_generic)
+    ref = oracle(chans, grid)
+    pk = np.abs(ref).max()
+    assert np.max(np.abs(got - ref)) <= 1e-12 * pk
+    off, name_off, info_off = run(chans, grid, env={'WFK_NO_LEAN_MULTI': '1'})
+    assert info_off.n_generic > 0 and np.max(np.abs(off - ref)) <= 1e-12 * pk
+    f32, name32, _ = run(chans, grid, np.float32)
+    assert name32.startswith('wfk_sample_lean<float,') and np.max(np.abs(f32 - ref)) <= FP32_TOL * pk
+    # complex amplitudes: two groups per term -- not an own-term op; same numbers on whatever path
+    cplx = [(0.5 + 0.3j) * a + 0.1 * b]
+    gotc, _, _ = run(cplx, grid, np.complex128)
+    refc = oracle(cplx, grid, True)
+    assert np.max(np.abs(gotc - refc)) <= 1e-12 * np.abs(refc).max()

@@ -70,7 +70,7 @@ for case in range(n_cases):
     cplx = bool(rng.integers(2))
     plan = _engine.Plan(prog, grid=g)
     name = plan.kernel_name(np.complex128 if cplx else np.float64)
-    fam3 += ',3>' in name or (name.startswith('wfk_sample_short<') and plan.info.n_generic == 0)
+    fam3 += ',3>' in name or ',4>' in name or (name.startswith('wfk_sample_short<') and plan.info.n_generic == 0)
     got = plan.run_host(np.complex128 if cplx else np.float64)
     ref = c_oracle.eval_grid(prog, g, cplx)
     pk = max(1.0, float(np.abs(ref).max()))

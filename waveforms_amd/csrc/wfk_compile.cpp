@@ -104,6 +104,8 @@ struct FceGroup {
   int fmul = 0;                 // pseudo-op: multiply them by a stateless function of t - slin: 2 = a finite INTERP table read as a
                                 // continuous piecewise-linear function, 3 = mollifier(r) (lean kernel family 3 only)
   int32_t fmul_f = -1;          // ... the program factor it stands for
+  int own_kind = 0;             // lean kernel: this plain carrier group carries an envelope of its own (2 table, 3 mollifier) ...
+  int32_t own_f = -1;           // ... the program factor of it (WFK_FCE_OWNMUL)
   bool fmul_own = false;        // short tier: the multiplier belongs to the ONE group in front of it (envelope x carrier as one op)
   long double K = 0;            // chirp: the phase is K t'^2 + W t' - psi_ref (W, psi_ref as for a plain carrier)
   long double Wl = 0;           // chirp: W before its rounding to double (|W| ~ 2 K |shift|: 2^-53 of it times t' shows in the phase)
@@ -1092,6 +1094,25 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       rec[WFK_FCE_DEG] += (double)WFK_FCE_BANK;
       rec[WFK_FCE_SIGMA] = (double)G.bank;
     }
+    if (G.own_kind) {
+      // (a plain carrier -- degree 0, B folded into the phase -- or a constant: the slots of the higher coefficients are free)
+      const int32_t f = G.own_f;
+      const double* fa = P->pool + P->fc_arg_off[f];
+      rec[WFK_FCE_DEG] += (double)WFK_FCE_OWNMUL;
+      rec[WFK_FCE_SLIN] = P->fc_shift[f];
+      if (G.own_kind == 2) {
+        const int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 2;
+        rec[WFK_FCE_B + 3] = 0.0;
+        rec[WFK_FCE_B + 2] = fa[0];
+        rec[WFK_FCE_A + 1] = (double)(m - 1);
+        rec[WFK_FCE_A + 2] = (double)(m - 1) / (fa[1] - fa[0]);
+        rec[WFK_FCE_A + 3] = (double)fmul_table(f);
+        rec[WFK_FCE_B + 1] = dstride * rec[WFK_FCE_A + 2];
+      } else {
+        rec[WFK_FCE_B + 3] = 1.0;
+        rec[WFK_FCE_A + 1] = 1.0 / fa[0];
+      }
+    }
     if (H.tlist) {
       // (pointwise evaluation: no lane stride; the H slot carries 1 / sigma -- the Gaussian's argument is formed
       //  by a multiplication, one rounding off the reference's division: 2 v^2 ulp <= 1.5e-13 relative at |v| = 26)
@@ -1401,7 +1422,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // as long as each stands over one plain carrier: every such term is an own-term op, acc += F (A cos + B sin).
         struct XMod { int kind; int32_t f; std::vector<FceGroup> g; };
         std::vector<XMod> xmods;      // the envelopes after the first one
-        const bool multi_ok = cur_short && !std::getenv("WFK_NO_SHORT_MULTI");
+        const bool multi_ok = !std::getenv(cur_short ? "WFK_NO_SHORT_MULTI" : "WFK_NO_LEAN_MULTI");
         auto same_mod = [&](int32_t a_, int32_t b_) {
           const int64_t na = P->fc_arg_off[a_ + 1] - P->fc_arg_off[a_];
           if (P->fc_type[a_] != P->fc_type[b_] || P->fc_shift[a_] != P->fc_shift[b_] || na != P->fc_arg_off[b_ + 1] - P->fc_arg_off[b_]) return false;
@@ -1656,13 +1677,30 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         int piece_fam = 0;          // lean kernel family the piece needs: 0 plain ops, 1 closing ops, 2 chirps, 3 stateless multipliers
         for (const FceGroup& G : groups) {
           piece_has_chirp = piece_has_chirp || G.chirp;
-          piece_has_fmul = piece_has_fmul || G.fmul != 0;
+          piece_has_fmul = piece_has_fmul || G.fmul != 0;     // (own multipliers are still separate entries here: fmul set)
           piece_fam = std::max(piece_fam, G.fmul ? 3 : (G.chirp ? 2 : ((G.erfmul || G.envmul) ? 1 : 0)));
         }
+        for (size_t gi = 0; gi + 1 < groups.size(); ++gi)
+          if (!cur_short && groups[gi + 1].fmul && groups[gi + 1].fmul_own) piece_fam = 4;     // own-term ops: family 4
         if (piece_has_bank) piece_fam = std::max(piece_fam, 1);
         plan_has_bank = plan_has_bank || piece_has_bank;
         const int32_t piece_ops = (int32_t)groups.size();
         int32_t piece_units = 0;
+        if (!cur_short) {
+          // (lean pieces: a (group, own multiplier) pair is ONE op -- the multiplier's parameters ride in the group's record)
+          std::vector<FceGroup> folded;
+          for (size_t gi = 0; gi < groups.size(); ++gi) {
+            if (gi + 1 < groups.size() && groups[gi + 1].fmul && groups[gi + 1].fmul_own) {
+              FceGroup g = groups[gi];
+              g.own_kind = groups[gi + 1].fmul; g.own_f = groups[gi + 1].fmul_f;
+              folded.push_back(g);
+              ++gi;
+            } else {
+              folded.push_back(groups[gi]);
+            }
+          }
+          groups.swap(folded);
+        }
         for (FceGroup& G : groups) {
           if (room_for(WFK_FCE_REC + 2 * (NS + 1)) < 0) { err = "LDS parameter buffer too small"; return WFK_EINVAL; }
           if (H.tlist) {
@@ -1696,7 +1734,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         piece_lean = piece_lean && D.n_blk == 1 && len <= lean_par_cap && piece_units <= 63;
         (void)piece_ops;
         if ((!piece_lean && (H.n_corr > corr_before || piece_has_chirp || piece_has_fmul) && attempt == 0) ||
-            (piece_has_fmul && H.n_corr > corr_before && attempt == 0)) {
+            ((multi_bad || (piece_has_fmul && H.n_corr > corr_before)) && attempt == 0)) {
           // roll back and build the piece again without corrected carriers / fused chirps (lean kernel only)
           H.params.resize(snap.params); H.pool.resize(snap.pool);
           H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;

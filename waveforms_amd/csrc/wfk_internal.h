@@ -63,6 +63,10 @@
 #define WFK_FCE_CHIRP (1 << 28)    // quadratic phase: W = W' (frequency at SREF = tref), WM = K, SM = phase at tref,
                                    // TAB / F32OK = (cos, sin)(2 K D^2); state: (c, s), the step phasor (wc, ws), then (g, r)
 #define WFK_FCE_TLSMALL (1 << 29)   // tlist plans (ops evaluated pointwise): |W (t' - s_ref)| <= 1.6e6 over the piece -> cheap phase reduction
+#define WFK_FCE_OWNMUL (1u << 31)   // lean family 4: a plain carrier op (degree 0) whose term is multiplied by an envelope of its own --
+                                    // acc += F(u_k) A0 cos(th_k), F a table (B+3 = 0) or a mollifier (B+3 = 1): envelope shift in SLIN,
+                                    // table: B+2 start, A+1 m - 1, A+2 (m - 1) / (stop - start), A+3 first entry, B+1 lane stride in knots;
+                                    // mollifier: A+1 = 1 / r.  Any number per piece (overlapping pulses of different envelopes).
 #define WFK_FCE_BANK (1 << 30)      // first of a run of bare carriers (degree 0, no envelope, no correction, same part of the output):
                                     // SIGMA holds the run's length; the lean kernel (family >= 1) evaluates the run in one compact loop
 #define WFK_FCE_EXPENV (1 << 27)   // the envelope is exp(alpha (t - ref)): SIGMA = alpha, SG = ref, H = alpha * D, Q = 1

@@ -1036,6 +1036,71 @@ __device__ __forceinline__ void fce_mollmul(const double* r, double x, T (&acc)[
   }
 }
 
+// WFK_FCE_OWNMUL (family 4): a plain carrier op whose term carries an envelope of its own,
+//   acc[k] += F(u_k) A0 cos(th_k)        (A0 alone without a carrier),
+// F a finite INTERP table read as in fce_tabmul or a mollifier as in fce_mollmul.  Unlike the closing multipliers it
+// touches nothing but its own term, so a piece may hold any number of them: overlapping pulses of different envelopes.
+template <typename T, int NS>
+__device__ __forceinline__ void fce_ownmul(const double* blk, const double* r, const KArgs& a, double x, double* st,
+                                           int fl, T (&acc)[NS]) {
+  const bool car = (fl & 4) != 0;
+  double c = 1.0, sn = 0.0;
+  if (car) { c = st[0]; sn = st[64]; }
+  const double A0 = r[WFK_FCE_A];
+  const double ac = A0 * c, as = A0 * sn;
+  const double2* ptab = reinterpret_cast<const double2*>(blk + WFK_FCE_TABOFF(fl));
+  if (uni((int)r[WFK_FCE_B + 3]) == 0) {
+    const double qmax = udbl(r[WFK_FCE_A + 1]), Dq = udbl(r[WFK_FCE_B + 1]);
+    double q = ((x - r[WFK_FCE_SLIN]) - r[WFK_FCE_B + 2]) * r[WFK_FCE_A + 2];
+    const double2* tab = uniptr(reinterpret_cast<const double2*>(a.pool) + uni64((int64_t)r[WFK_FCE_A + 3]));
+    constexpr int IB = NS % 8 == 0 ? 8 : 1;
+#pragma unroll
+    for (int k0 = 0; k0 < NS; k0 += IB) {
+      double fr[IB];
+      double2 e[IB];
+#pragma unroll
+      for (int kk = 0; kk < IB; ++kk) {
+        const double qc = fmin(fmax(q, 0.0), qmax);
+        fr[kk] = __builtin_amdgcn_fract(qc);
+        e[kk] = tab[(uint32_t)(int)qc];
+        q += Dq;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // gathers above, uses below
+#pragma unroll
+      for (int kk = 0; kk < IB; ++kk) {
+        double val = ac;
+        if (car) {
+          const double2 cs = ptab[k0 + kk];
+          val = fma(ac, cs.x, -(as * cs.y));
+        }
+        acc[k0 + kk] += (T)(val * fma(fr[kk], e[kk].y, e[kk].x));
+      }
+    }
+  } else {
+    const double u0 = x - r[WFK_FCE_SLIN];
+    const double D = udbl(r[WFK_FCE_D]), ir = udbl(r[WFK_FCE_A + 1]);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const double xx = fma((double)k, D, u0) * ir;
+      const double qv = fma(xx, xx, -1.0);
+      const double qq = qv < -1e-300 ? qv : -1.0;
+      const double v = exp_inline(rcp_nr(qq) + 1.0);
+      double val = ac;
+      if (car) {
+        const double2 cs = ptab[k];
+        val = fma(ac, cs.x, -(as * cs.y));
+      }
+      acc[k] += (T)(qv < 0.0 ? val * v : 0.0);
+      if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (car) {
+    const double2 e = ptab[NS];
+    st[0] = c * e.x - sn * e.y;
+    st[64] = sn * e.x + c * e.y;
+  }
+}
+
 // ---- fused chirp op (lean kernel, family 2): E_k (A(u_k) cos th_k + B(u_k) sin th_k) with a QUADRATIC
 // phase, th(tau) = K tau^2 + W' tau + phi0 about tau = t' - tref (reference LINEARCHIRP,
 // _waveform.pyx:323-324, times whatever carriers the term multiplies it with).  Along a lane (stride D)
@@ -1375,7 +1440,9 @@ __device__ __forceinline__ int64_t xcd_chunk(const KArgs& a) {
 // does not inflate the kernel's register allocation).  No barriers between waves at all.
 // FAM: op families compiled into this instantiation -- 0: carrier / envelope ops only (every BASELINE
 // config), 1: + the closing ops (erf edges, shared envelopes), 2: + chirps, 3: + the stateless closing multipliers
-// (INTERP tables, mollifiers).  The host picks the smallest
+// (INTERP tables, mollifiers), 4: + carrier terms under envelopes of their own (several envelopes per piece: a family
+// of its own so that the single-envelope shapes keep family 3's register allocation: 161 VGPRs against 167 + 2 spills,
+// 1-2 % on bench.py direct_interp / direct_mollifier).  The host picks the smallest
 // family a plan needs, so a shape added to one family cannot move the register allocation and code
 // layout of the others (round 2 took the chirp op out again for exactly that: inlined into the one
 // kernel it cost the multi-tone workloads 4-9 %).
@@ -1542,6 +1609,16 @@ wfk_sample_lean(const KArgs a) {
                 fce_bank<T, NS>(s_par, a.params + P.par_off, rec, nb, s_st, lane, acc);
               }
               op += nb - 1;
+              continue;
+            }
+          }
+          if constexpr (FAM >= 4) {
+            if (fl < 0) {                   // WFK_FCE_OWNMUL: a carrier term under an envelope of its own
+              if (fl & 8) {
+                if constexpr (CPLX) fce_ownmul<T, NS>(s_par, rec, a, x, st, fl, acci);
+              } else {
+                fce_ownmul<T, NS>(s_par, rec, a, x, st, fl, acc);
+              }
               continue;
             }
           }
@@ -1784,7 +1861,8 @@ int launch(const KArgs& a, int64_t blocks, hipStream_t s, bool lean, bool generi
           return hipGetLastError() == hipSuccess ? 0 : -1;
         }
       }
-      if (a.lean_fam >= 3) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 3>), g, dim3(64), lds, s, a);
+      if (a.lean_fam >= 4) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 4>), g, dim3(64), lds, s, a);
+      else if (a.lean_fam == 3) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 3>), g, dim3(64), lds, s, a);
       else if (a.lean_fam == 2) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 2>), g, dim3(64), lds, s, a);
       else if (a.lean_fam == 1) hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 1>), g, dim3(64), lds, s, a);
       else hipLaunchKernelGGL((wfk_sample_lean<T, CPLX, NS, false, 0>), g, dim3(64), lds, s, a);
