@@ -268,3 +268,31 @@ def test_overlapping_envelopes_on_fine_grids():
     gotc, _, _ = run(cplx, grid, np.complex128)
     refc = oracle(cplx, grid, True)
     assert np.max(np.abs(gotc - refc)) <= 1e-12 * np.abs(refc).max()
+
+
+@pytest.mark.parametrize('fine', [True, False])
+def test_new_ops_under_vstacks_shifts_offsets_and_clips(fine):
+    """Own-term envelope ops, closing multipliers and (AWG rates) chirps inside WaveVStack members with a channel time
+    shift, offsets and clips: the same samples as the oracle on the lean kernel / the short tier."""
+    rng = np.random.default_rng(31)
+    period = 60e-9
+    n_p = 40
+    a = wl._tree_sum([rng.uniform(0.3, 1) * hann(200) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6))
+                      >> ((k + 0.5) * period) for k in range(n_p)])
+    b = wl._tree_sum([rng.uniform(0.3, 1) * wf.mollifier(40e-9) * wf.cos(2 * np.pi * rng.uniform(-1e8, 1e8))
+                      >> ((k + 0.5) * period + 9e-9) for k in range(n_p)])
+    c = wl._tree_sum([rng.uniform(0.3, 1) * wf.chirp(5e7, 2e8, 50e-9) * wf.cosPulse(50e-9)
+                      >> ((k + 0.5) * period) for k in range(n_p)])
+    stack = (wf.WaveVStack([a, 0.2 * b, 0.1 * c]) + 0.25) >> 3.3e-9
+    clipped = (a + 0.3 * b) >> 1.7e-9
+    clipped.max, clipped.min = 0.7, -0.6
+    chans = [stack, clipped, (a + 0.1 * (a >> 11e-9)) - 0.4]
+    span = n_p * period
+    grid = ('linspace', 0.0, span, 1_200_000, False) if fine else ('arange', 0.0, span, 0.5e-9)
+    got, name, info = run(chans, grid)
+    assert name.startswith('wfk_sample_lean<' if fine else 'wfk_sample_short<'), name
+    ref = oracle(chans, grid)
+    tol = 1e-12 if fine else AWG_TOL
+    assert np.max(np.abs(got - ref)) <= tol * max(1.0, np.abs(ref).max())
+    f32, _, _ = run(chans, grid, np.float32)
+    assert np.max(np.abs(f32 - ref)) <= FP32_TOL * max(1.0, np.abs(ref).max())
