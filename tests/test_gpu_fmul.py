@@ -296,3 +296,22 @@ def test_new_ops_under_vstacks_shifts_offsets_and_clips(fine):
     assert np.max(np.abs(got - ref)) <= tol * max(1.0, np.abs(ref).max())
     f32, _, _ = run(chans, grid, np.float32)
     assert np.max(np.abs(f32 - ref)) <= FP32_TOL * max(1.0, np.abs(ref).max())
+
+
+def test_time_slices_of_the_new_tiers_are_the_same_samples():
+    """wfk_grid.i0: a slice of a grid is those samples of the whole grid -- for the closing multipliers / own-term ops of
+    the lean kernel and for the short tier's table and chirp ops (time-sharded sampling)."""
+    fine = [wl.direct_channel(wf, 'interp'), wl.direct_channel(wf, 'mollifier')]
+    g = _flatten.grid_from_desc(GRID)
+    whole = _engine.Plan(_flatten.flatten(fine), grid=g).run_host(np.float64)
+    for a, b in ((0, 400_000), (400_000, 1_100_000), (1_100_000, 1_500_000)):
+        part = _engine.Plan(_flatten.flatten(fine), grid=_flatten.grid_slice(g, a, b)).run_host(np.float64)
+        assert np.max(np.abs(part - whole[:, a:b])) <= 1e-12 * np.abs(whole).max()
+    awg = [wl.awg_interp_channel(wf, 0, 40_000), wl.awg_shape_channel(wf, 'linear_chirp', 1, 40_000)]
+    g = _flatten.grid_from_desc(wl.awg_grid(40_000, 2e9))
+    plan = _engine.Plan(_flatten.flatten(awg), grid=g)
+    assert plan.kernel_name().startswith('wfk_sample_short<')
+    whole = plan.run_host(np.float64)
+    for a, b in ((0, 13_000), (13_000, 40_000)):
+        part = _engine.Plan(_flatten.flatten(awg), grid=_flatten.grid_slice(g, a, b)).run_host(np.float64)
+        assert np.max(np.abs(part - whole[:, a:b])) <= 1e-11 * np.abs(whole).max()
