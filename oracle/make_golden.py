@@ -8,7 +8,9 @@ imported with a stub for the absent `antlr4` package.
 Nothing from the reference is written into this repository: only numeric
 input/output vectors derived by *running* it.
 
-    python oracle/make_golden.py            # rewrites tests/golden/
+    python oracle/make_golden.py                  # rewrites every fixture under tests/golden/
+    python oracle/make_golden.py spectral iir     # only these fixture groups (see FIXTURES)
+    python oracle/make_golden.py --check [NAME…]  # regenerate into a temp dir, compare bit for bit
 
 Outputs
   tests/golden/frontend.json      reference tolist() for every case in tests/cases.py
@@ -264,33 +266,9 @@ def make_iir(ref, gold):
     np.savez_compressed(os.path.join(gold, 'iir.npz'), **iir)
 
 
-def main():
-    sys.path.insert(0, REPO)
-    sys.path.insert(0, os.path.join(REPO, 'tests'))
-    ref = import_reference()
+def make_design(ref, gold):
+    """Filter-design helpers of distortion.py (host-side, no sampling)."""
     import cases
-    from waveforms_amd import workloads as wl
-    from waveforms.waveform import WaveVStack
-
-    gold = os.path.join(REPO, 'tests', 'golden')
-    os.makedirs(gold, exist_ok=True)
-    if sys.argv[1:] == ['c4_full']:        # regenerate this fixture only
-        make_c4_full(ref, gold)
-        return
-    if sys.argv[1:] == ['late']:           # regenerate this fixture only
-        make_late(ref, gold)
-        return
-    if sys.argv[1:] == ['awg']:            # regenerate this fixture only
-        make_awg(ref, gold)
-        return
-    if sys.argv[1:] == ['iir']:            # regenerate this fixture only
-        make_iir(ref, gold)
-        return
-    if sys.argv[1:] == ['n4']:             # regenerate this fixture only
-        make_n4(ref, gold)
-        return
-
-    # ---- filter-design helpers of distortion.py (host-side, no sampling) ----------
     import waveforms.distortion as rdist
     design = {}
     for i, (n, fs, bw, skip) in enumerate(cases.extract_cases()):
@@ -304,10 +282,12 @@ def main():
         design[f'fac{i}'] = np.array([list(x) + list(y) for x, y in secs], dtype=complex)
     design['stable'] = np.array([rdist.stable_filter(f, fs) for f, fs in cases.stable_cases()])
     np.savez_compressed(os.path.join(gold, 'design.npz'), **design)
-    if sys.argv[1:] == ['design']:         # regenerate this fixture only
-        return
 
-    # ---- marker / mask / | / & (host-side symbolic layer) -------------------
+
+def make_logic(ref, gold):
+    """marker / mask / | / & (host-side symbolic layer): flat lists."""
+    import cases
+    from waveforms.waveform import WaveVStack
     logic = {}
     plain = [(n_, b_) for n_, (b_, _g) in cases.CASES.items() if not isinstance(b_(ref), WaveVStack)]
     for i, (name, build) in enumerate(plain):
@@ -324,10 +304,12 @@ def main():
             logic[name] = {'error': type(exc).__name__}
     with open(os.path.join(gold, 'logic.json'), 'w') as f:
         json.dump(logic, f)
-    if sys.argv[1:] == ['logic']:          # regenerate this fixture only
-        return
 
-    # ---- Python-callable primitives: function() / registerBaseFunc / function_lib= -------
+
+def make_user(ref, gold):
+    """Python-callable primitives: function() / registerBaseFunc / function_lib=."""
+    import cases
+    from waveforms.waveform import WaveVStack
     user = {}
     for name, build in cases.USER_CASES.items():
         w, lib, x = build(ref)
@@ -341,10 +323,12 @@ def main():
     user['sample.full'] = w.sample(function_lib=lib)
     user['sample.chunked'] = np.concatenate(list(w.sample(chunk_size=257, function_lib=lib)))
     np.savez_compressed(os.path.join(gold, 'user.npz'), **user)
-    if sys.argv[1:] == ['user']:           # regenerate this fixture only
-        return
 
-    # ---- random scripts (tests/cases.py: random_channel), evaluated by the reference ----
+
+def make_fuzz(ref, gold):
+    """Random scripts (tests/cases.py: random_channel), evaluated by the reference."""
+    import cases
+    from waveforms_amd import workloads as wl
     fuzz, fuzz_lists = {}, {}
     for seed in range(cases.FUZZ_GOLD):
         w, grid = cases.fuzz_golden_case(ref, seed)
@@ -360,19 +344,25 @@ def main():
     np.savez_compressed(os.path.join(gold, 'fuzz.npz'), **fuzz)
     with open(os.path.join(gold, 'fuzz_frontend.json'), 'w') as f:
         json.dump(fuzz_lists, f)
-    if sys.argv[1:] == ['fuzz']:           # regenerate these fixtures only
-        return
 
-    # ---- edge inputs of __call__: empty / single / off-support / non-uniform x ----
+
+def make_edges(ref, gold):
+    """Edge inputs of __call__: empty / single / off-support / non-uniform x."""
+    import cases
     edges = {}
     for name, (build, xs) in cases.edge_cases().items():
         w = build(ref)
         for k, x in enumerate(xs):
             edges[f'{name}.{k}'] = np.asarray(w(x))
     np.savez_compressed(os.path.join(gold, 'edges.npz'), **edges)
-    if sys.argv[1:] == ['edges']:          # regenerate this fixture only
-        return
 
+
+def make_samples(ref, gold):
+    """Every case of tests/cases.py CASES: tolist(), simplify().tolist(), wav(t), searchsorted indices;
+    Waveform.sample() per sos_case."""
+    import cases
+    from waveforms_amd import workloads as wl
+    from waveforms.waveform import WaveVStack
     frontend, samples = {}, {}
     for name, (build, grid) in cases.CASES.items():
         w = build(ref)
@@ -406,7 +396,11 @@ def main():
         api[name] = w.sample()
     np.savez_compressed(os.path.join(gold, 'sample_api.npz'), **api)
 
-    # ---- big configs: subsets only -------------------------
+
+def make_big(ref, gold):
+    """Big configs C2 / C3 / C4: subsets only."""
+    from waveforms_amd import workloads as wl
+    from waveforms.waveform import WaveVStack
     big = {}
 
     def subset(name, w, grid, stride):
@@ -442,9 +436,10 @@ def main():
         big[f'c4_{c}.fir'] = z[big[f'c4_{c}.pick']]
         big[f'c4_{c}.firsum'] = np.array([z.sum(), np.abs(z).sum()])
     np.savez_compressed(os.path.join(gold, 'big.npz'), **big)
-    make_c4_full(ref, gold)
 
-    # ---- FIR vectors (reference distortion.py:323-337; untested upstream) ----
+
+def make_fir(ref, gold):
+    """FIR vectors (reference distortion.py:323-337; untested upstream)."""
     fir = {}
     rng = np.random.default_rng(42)
     for i, (n, k) in enumerate([(1, 1), (5, 3), (64, 8), (100, 7), (1000, 64),
@@ -457,9 +452,12 @@ def main():
         fir[f'{i}.out'] = ref.distortion.predistort(sig, ker=kr)
     np.savez_compressed(os.path.join(gold, 'fir.npz'), **fir)
 
-    make_iir(ref, gold)
 
-    # ---- FFT-domain ops -------------------------------------
+def make_spectral(ref, gold):
+    """FFT-domain ops: reflection / correct_reflection / shift / zDistortKernel
+    (reference distortion.py:12-60,208-223)."""
+    import cases
+    dist = ref.distortion
     spec = {}
     for i, (n, A, tau, fs) in enumerate(cases.spectral_cases()):
         sig = cases.spectral_input(i)
@@ -468,9 +466,81 @@ def main():
         spec[f'{i}.shift'] = dist.shift(sig, 3.3 / fs * (1 if i % 2 else -1), 1 / fs)
     spec['zker'] = dist.zDistortKernel(1e-9, [(50e-9, 0.02), (400e-9, -0.01)])
     np.savez_compressed(os.path.join(gold, 'spectral.npz'), **spec)
-    make_late(ref, gold)
-    make_awg(ref, gold)
-    make_n4(ref, gold)
+
+
+# fixture group -> (generator, files it writes); `python oracle/make_golden.py NAME...` runs only those
+FIXTURES = {
+    'design': (make_design, ['design.npz']),
+    'logic': (make_logic, ['logic.json']),
+    'user': (make_user, ['user.npz']),
+    'fuzz': (make_fuzz, ['fuzz.npz', 'fuzz_frontend.json']),
+    'edges': (make_edges, ['edges.npz']),
+    'samples': (make_samples, ['frontend.json', 'frontend_simplified.json', 'samples.npz', 'sample_api.npz']),
+    'big': (make_big, ['big.npz']),
+    'c4_full': (make_c4_full, ['c4_full.npz']),
+    'fir': (make_fir, ['fir.npz']),
+    'iir': (make_iir, ['iir.npz']),
+    'spectral': (make_spectral, ['spectral.npz']),
+    'late': (make_late, ['late.npz']),
+    'awg': (make_awg, ['awg.npz', 'awg_c4.npz']),
+    'n4': (make_n4, ['n4.npz']),
+}
+
+
+def same_file(a, b):
+    """Bit-for-bit equality of the CONTENT of two fixtures (npz members array by array incl. dtype and
+    shape, json by parsed value): compressed container bytes may differ between zlib builds."""
+    if a.endswith('.json'):
+        with open(a) as fa, open(b) as fb:
+            return [] if json.load(fa) == json.load(fb) else ['json differs']
+    bad = []
+    with np.load(a, allow_pickle=False) as za, np.load(b, allow_pickle=False) as zb:
+        if sorted(za.files) != sorted(zb.files):
+            bad.append('keys differ: %s' % sorted(set(za.files) ^ set(zb.files))[:6])
+        for k in za.files:
+            if k not in zb.files:
+                continue
+            x, y = za[k], zb[k]
+            if x.dtype != y.dtype or x.shape != y.shape or x.tobytes() != y.tobytes():
+                bad.append(k)
+    return bad
+
+
+def check(ref, names):
+    """Regenerate the named fixture groups into a scratch directory and compare them, bit for bit,
+    with the committed files.  Returns the number of differing files."""
+    import tempfile
+    gold = os.path.join(REPO, 'tests', 'golden')
+    nbad = 0
+    with tempfile.TemporaryDirectory(prefix='wfk_golden_') as tmp:
+        for name in names:
+            fn, files = FIXTURES[name]
+            fn(ref, tmp)
+            for f in files:
+                bad = same_file(os.path.join(gold, f), os.path.join(tmp, f))
+                print('%-28s %s' % (f, 'identical' if not bad else 'DIFFERS: %s' % bad[:8]), flush=True)
+                nbad += bool(bad)
+    return nbad
+
+
+def main():
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    args = sys.argv[1:]
+    do_check = '--check' in args
+    names = [a for a in args if a != '--check'] or list(FIXTURES)
+    unknown = [a for a in names if a not in FIXTURES]
+    if unknown:
+        sys.exit('unknown fixture group(s) %s; known: %s' % (unknown, ' '.join(FIXTURES)))
+    ref = import_reference()
+    if do_check:
+        nbad = check(ref, names)
+        print('check: %d file(s) differ' % nbad)
+        sys.exit(1 if nbad else 0)
+    gold = os.path.join(REPO, 'tests', 'golden')
+    os.makedirs(gold, exist_ok=True)
+    for name in names:
+        FIXTURES[name][0](ref, gold)
     for f in sorted(os.listdir(gold)):
         print(f, os.path.getsize(os.path.join(gold, f)))
 

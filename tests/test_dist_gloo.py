@@ -114,3 +114,51 @@ def test_grid_slices_are_the_same_samples():
             assert np.array_equal(c_oracle.member_index(prog, 0, grid=sl), np.clip(ref.member_index(0) - lo, 0, hi - lo))
     with pytest.raises(ValueError):
         _flatten.grid_slice(g, 5, n + 1)
+
+
+def _poison_worker(rank, world, port, q):
+    """rank 1 of 3 fails in its own pass: ranks 1 AND 2 must raise (rank 2 receives a NaN-poisoned state instead
+    of waiting in recv for ever), rank 0 completes"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from waveforms_amd._dist import TimeShardedIir
+
+        class _Sampler:
+            n_channels = 3
+
+        class _Stage(TimeShardedIir):
+            def __init__(self):
+                self.sampler, self.D = _Sampler(), 2
+                self.sampler.rank, self.sampler.world = rank, world
+
+            def apply_local(self, x, y, state, initial=0.0):
+                if rank == 1:
+                    raise RuntimeError('IIR stage timed out')
+                return state + 1.0
+
+        x = torch.zeros((3, 8), dtype=torch.float64)
+        try:
+            zf = _Stage().apply_torch(x, x)
+            q.put((rank, 'done' if zf is None else 'state'))
+        except RuntimeError as e:
+            q.put((rank, 'raised: ' + str(e)[:40]))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_poisons_the_iir_hand_off_instead_of_hanging_it():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_poison_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == 'done' and res[1].startswith('raised: IIR stage timed out'), res
+    assert res[2].startswith('raised: IIR stage: rank 2 received a poisoned'), res

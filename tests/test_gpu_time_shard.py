@@ -149,6 +149,20 @@ def _worker(rank, world, port, q):
         host = gather_rows_to_host(rows, 5, root=0, slab_bytes=8000 * 2)
         if rank == 0:
             assert np.array_equal(host[:, 7], np.arange(5.0))
+        # BOUNDED device memory on root: 128 rows over 2 ranks in slabs of ONE row = 64 gathers; root may hold its
+        # block + the staging slab + the ring of 2 x world receive slabs, whatever the number of gathers
+        nrow, ncol = 128, 1 << 17
+        a, b = channel_block(nrow, rank, world)
+        rows = torch.arange(a, b, dtype=torch.float64, device='cuda')[:, None].repeat(1, ncol)
+        slab = ncol * 8
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        host = gather_rows_to_host(rows, nrow, root=0, slab_bytes=slab)
+        peak = torch.cuda.max_memory_allocated() - base
+        assert peak <= 3 * world * slab + (1 << 20), (peak, slab)
+        if rank == 0:
+            assert np.array_equal(host[:, 0], np.arange(float(nrow))) and np.array_equal(host[:, -1], np.arange(float(nrow)))
         q.put((rank, 'ok'))
     except Exception as e:  # pragma: no cover
         import traceback

@@ -78,6 +78,8 @@ def gather_rows_to_host(local, n_channels, root=0, slab_bytes=2 << 30, group=Non
     HBM): the row blocks travel to `root` in SLABS of <= `slab_bytes` per rank (dist.gather: RCCL on GPUs, gloo
     on CPU), and root copies every slab into its place of ONE host array -- page-locked, from the library's
     block cache (`_engine.pinned_empty`), so the D2H copy of slab k overlaps the gather of slab k + 1.
+    Root's device footprint next to its own block is (1 + 2 * world) slabs, independent of the job size (C5 fp64:
+    41 GB block + 17 x 2 GB).
     -> the (n_channels, n) NumPy array on root, None on the other ranks."""
     import torch
     import torch.distributed as dist
@@ -94,26 +96,40 @@ def gather_rows_to_host(local, n_channels, root=0, slab_bytes=2 << 30, group=Non
     if rank == root:
         host = _engine.pinned_empty((n_channels, n), np_dtype) if local.is_cuda else np.empty((n_channels, n), np_dtype)
     copy_stream = torch.cuda.Stream() if local.is_cuda else None
-    pending = []
-    for r0 in range(0, width, slab):
-        part = torch.zeros((slab, n), dtype=local.dtype, device=local.device)
+    # Device memory on root is BOUNDED: one staging slab + a ring of RING receive sets (world slabs each), whatever
+    # the number of iterations -- a set is reused only after the D2H copies that read it have completed (an event
+    # per set on the copy stream, waited for by the stream the next gather is ordered on).
+    RING = 2
+    part = torch.zeros((slab, n), dtype=local.dtype, device=local.device)
+    ring = [[torch.empty_like(part) for _ in range(world)] for _ in range(RING)] if rank == root else None
+    done = [None] * RING
+    for it, r0 in enumerate(range(0, width, slab)):
         mine = local[r0:r0 + slab]
         part[:mine.shape[0]] = mine
-        parts = [torch.empty_like(part) for _ in range(world)] if rank == root else None
+        if mine.shape[0] < slab:
+            part[mine.shape[0]:].zero_()
+        parts = None
+        if rank == root:
+            parts = ring[it % RING]
+            if done[it % RING] is not None:
+                torch.cuda.current_stream().wait_event(done[it % RING])
         dist.gather(part, parts, dst=root, group=group)
         if rank == root:
+            if copy_stream is not None:
+                copy_stream.wait_stream(torch.cuda.current_stream())
             for (a, b), p in zip(rows, parts):
                 lo, hi = a + r0, min(b, a + r0 + slab)
                 if hi <= lo:
                     continue
                 dst = torch.from_numpy(host[lo:hi])
                 if copy_stream is not None:
-                    copy_stream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(copy_stream):
                         dst.copy_(p[:hi - lo], non_blocking=True)
-                    pending.append(p)              # keep the slab alive until its copy has run
                 else:
                     dst.copy_(p[:hi - lo])
+            if copy_stream is not None:
+                done[it % RING] = torch.cuda.Event()
+                done[it % RING].record(copy_stream)
     if copy_stream is not None:
         copy_stream.synchronize()
     return host
@@ -233,9 +249,23 @@ class TimeShardedIir:
                 state.copy_(h)
             else:
                 dist.recv(state, src=rank - 1, group=group)
-        zf = self.apply_local(x, y, state, initial)
+        # A rank that cannot produce its state still hands a message on -- a NaN-poisoned one -- so that the ranks
+        # behind it raise as well instead of waiting in recv for ever.
+        err = None
+        if rank > 0 and bool(torch.isnan(state).any()):
+            err = RuntimeError('IIR stage: rank %d received a poisoned state (an earlier rank failed)' % rank)
+            zf = state
+        else:
+            try:
+                zf = self.apply_local(x, y, state, initial)
+            except RuntimeError as exc:
+                err = exc
+                zf = torch.full_like(state, float('nan'))
         if rank + 1 < world:
             dist.send(zf.cpu() if dist.get_backend(group) == 'gloo' else zf, dst=rank + 1, group=group)
+        if err is not None:
+            raise err
+        if rank + 1 < world:
             return None
         return zf[:, :D]
 

@@ -96,7 +96,9 @@ def _finish(w, plan, frag, out, accumulate):
 # scan that changes another channel): the plan of such a call is kept -- keyed by the identity of the waveform's
 # immutable (bounds, seq) tuples, which the entry keeps alive, and by the grid's numbers -- and the repeat costs the
 # launch alone.  Per thread (a plan owns scratch for its launches), 16 entries, never for trees with Python callables
-# (their values are the callable's business at every call).
+# (their values are the callable's business at every call), never for a Waveform built on MUTABLE sequences (lists
+# handed to the constructor: identity says nothing about content), never for the chunk grids of `_sample_iter`
+# (each is used once).  The registry's generation counter is part of the key.
 _PLAN_CACHE_SIZE = 16
 _PLAN_CACHE_MAX_N = 1 << 20
 _tls = threading.local()
@@ -108,13 +110,17 @@ def _tree_key(w):
         return None, None
     if isinstance(w, WaveVStack):
         members = tuple(w.wlist)
+        if not all(type(m) is tuple and type(m[0]) is tuple and type(m[1]) is tuple for m in members):
+            return None, None
         return (('v', w.offset, w.shift) + tuple((id(b), id(s)) for b, s in members)), members
+    if type(w.bounds) is not tuple or type(w.seq) is not tuple:
+        return None, None
     return ('w', id(w.bounds), id(w.seq), w.min, w.max), (w.bounds, w.seq)
 
 
-def _cached_grid_plan(w, grid, function_lib):
+def _cached_grid_plan(w, grid, function_lib, no_cache=False):
     """-> (plan, owned): owned plans are the caller's to close, cached ones stay open"""
-    key, keep = (None, None) if function_lib is not None else _tree_key(w)
+    key, keep = (None, None) if (function_lib is not None or no_cache) else _tree_key(w)
     if int(grid.n) > _PLAN_CACHE_MAX_N:
         key = None                              # (a cached plan keeps its result buffer on the device: small calls only)
     if key is None:
@@ -122,8 +128,9 @@ def _cached_grid_plan(w, grid, function_lib):
     cache = getattr(_tls, 'plans', None)
     if cache is None:
         cache = _tls.plans = collections.OrderedDict()
-    from .waveform import _baseFunc
-    key = key + (grid.t0, grid.step, int(grid.n), int(grid.has_last), grid.last, int(grid.i0), len(_baseFunc))
+    from . import waveform as _wmod
+    key = key + (grid.t0, grid.step, int(grid.n), int(grid.has_last), grid.last, int(grid.i0),
+                 _wmod._registry_generation)
     hit = cache.get(key)
     if hit is not None and hit[0]._h:          # (a plan someone closed behind the cache's back is rebuilt)
         cache.move_to_end(key)
@@ -291,9 +298,9 @@ def _sample_filtered(w, plan, sos, initial, zi):
     return sig, zf
 
 
-def _sample_on_grid(w, grid, out, function_lib, filters=None, zi=None):
+def _sample_on_grid(w, grid, out, function_lib, filters=None, zi=None, no_cache=False):
     from .waveform import WaveVStack
-    plan, owned = _cached_grid_plan(w, grid, function_lib)
+    plan, owned = _cached_grid_plan(w, grid, function_lib, no_cache)
     try:
         if filters is not None:
             sos, initial = filters
@@ -342,13 +349,13 @@ def _sample_iter(w, sample_rate, chunk_size, out, function_lib, filters):
         grid = _flatten.grid_linspace(start, stop, size, endpoint=False)
         if filters is None:
             yield _sample_on_grid(w, grid, None if out is None else out[start_n:],
-                                  function_lib)
+                                  function_lib, no_cache=True)
         else:
             if size == 0:
                 # a last chunk of zero samples (start one ulp short of stop): the reference hands
                 # it to scipy.signal.sosfilt, which rejects an empty signal (waveform.py:249)
                 raise ValueError('cannot reshape array of size 0 into shape (0)')
-            sig, zi = _sample_on_grid(w, grid, None, function_lib, filters, zi)
+            sig, zi = _sample_on_grid(w, grid, None, function_lib, filters, zi, no_cache=True)
             if out is not None:
                 out[start_n:start_n + size] = sig
             yield sig

@@ -222,14 +222,26 @@ int wfk_set_device(int ordinal) {
   return WFK_OK;
 }
 
-static int plan_create(const wfk_program* prog, const wfk_grid* grid, const double* tlist,
-                       int64_t n, wfk_plan** out) {
-  if (!out) return fail(WFK_EINVAL, "null out");
-  *out = nullptr;
+namespace {
+// resets the compiler's thread-local "samples per lane of the time-list tier" on every way out of a scope
+struct TlistNsGuard {
+  explicit TlistNsGuard(int ns) { wfk_internal_tlist_ns(ns); }
+  ~TlistNsGuard() { wfk_internal_tlist_ns(0); }
+};
+}  // namespace
+
+static int plan_create_impl(const wfk_program* prog, const wfk_grid* grid, const double* tlist,
+                            int64_t n, wfk_plan** out) {
   wfk_plan* p = new (std::nothrow) wfk_plan();
   if (!p) return fail(WFK_ENOMEM, "out of host memory");
   std::string err;
-  int rc = wfk_compile(prog, grid, tlist, n, p->h, err);
+  int rc;
+  try {
+    rc = wfk_compile(prog, grid, tlist, n, p->h, err);
+  } catch (...) {
+    delete p;
+    throw;
+  }
   if (rc) {
     delete p;
     return fail(rc, err);
@@ -242,26 +254,52 @@ static int plan_create(const wfk_program* prog, const wfk_grid* grid, const doub
   std::vector<double> grid_t;
   const char* nopw = std::getenv("WFK_NO_POINTWISE_GRID");
   if (grid && p->h.short_gave_up && grid->n > 0 && grid->n <= ((int64_t)1 << 24) && !(nopw && nopw[0] == '1')) {
-    grid_t.resize((size_t)grid->n);
-    wfk_internal_grid_times(grid, grid_t.data());
-    HostPlan h2;
-    std::string err2;
-    wfk_internal_tlist_ns(WFK_NS_TLIST_SMALL);
-    const int rc2 = wfk_compile(prog, nullptr, grid_t.data(), grid->n, h2, err2);
-    wfk_internal_tlist_ns(0);
-    if (rc2 == WFK_OK) {
-      h2.grid_as_tlist = true;
-      p->h = std::move(h2);
-      tlist = grid_t.data();
+    // (an allocation failure in here -- up to 128 MB of times plus a second compile -- keeps the grid plan
+    // that is already compiled)
+    try {
+      grid_t.resize((size_t)grid->n);
+      wfk_internal_grid_times(grid, grid_t.data());
+      HostPlan h2;
+      std::string err2;
+      TlistNsGuard ns_guard(WFK_NS_TLIST_SMALL);
+      const int rc2 = wfk_compile(prog, nullptr, grid_t.data(), grid->n, h2, err2);
+      if (rc2 == WFK_OK) {
+        h2.grid_as_tlist = true;
+        h2.t0 = p->h.t0; h2.step = p->h.step; h2.last = p->h.last;     // introspection: the grid it stands for
+        h2.has_last = p->h.has_last; h2.i0 = p->h.i0;
+        p->h = std::move(h2);
+        tlist = grid_t.data();
+      }
+    } catch (const std::bad_alloc&) {
+      grid_t.clear();
     }
   }
-  rc = plan_upload(p, tlist);
+  try {
+    rc = plan_upload(p, tlist);
+  } catch (...) {
+    wfk_plan_destroy(p);
+    throw;
+  }
   if (rc) {
     wfk_plan_destroy(p);
     return rc;
   }
   *out = p;
   return WFK_OK;
+}
+
+// No exception crosses the C boundary: the compiler and the upload allocate host vectors.
+static int plan_create(const wfk_program* prog, const wfk_grid* grid, const double* tlist,
+                       int64_t n, wfk_plan** out) {
+  if (!out) return fail(WFK_EINVAL, "null out");
+  *out = nullptr;
+  try {
+    return plan_create_impl(prog, grid, tlist, n, out);
+  } catch (const std::bad_alloc&) {
+    return fail(WFK_ENOMEM, "out of host memory while compiling the plan");
+  } catch (const std::exception& e) {
+    return fail(WFK_EINVAL, std::string("plan creation failed: ") + e.what());
+  }
 }
 
 int wfk_plan_create_grid(const wfk_program* prog, const wfk_grid* grid, wfk_plan** out) {

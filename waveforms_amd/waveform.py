@@ -58,15 +58,18 @@ class BuiltinPrimitive:
 #: device then reads the values as a per-sample table factor (_flatten.py, WFK_SAMPLED).
 _baseFunc: dict[int, object] = {i: BuiltinPrimitive(i) for i in range(1, _ir.FIRST_USER_TYPE)}
 _next_type_id = _ir.FIRST_USER_TYPE
+#: bumped whenever `_baseFunc` changes (keys of cached plans include it: `_sampling._cached_grid_plan`)
+_registry_generation = 0
 
 
 def registerBaseFunc(func) -> int:
     """Register a Python callable `func(t_shifted_array, *args) -> array` as a primitive and
     return its id (reference: _waveform.pyx:264-271)."""
-    global _next_type_id
+    global _next_type_id, _registry_generation
     type_id = _next_type_id
     _next_type_id += 1
     _baseFunc[type_id] = func
+    _registry_generation += 1
     return type_id
 
 
@@ -79,7 +82,9 @@ def packBaseFunc():
 def updateBaseFunc(buf):
     """reference: _waveform.pyx:278-279"""
     import pickle
+    global _registry_generation
     _baseFunc.update(pickle.loads(buf))
+    _registry_generation += 1
 
 
 def registerDerivative(type_id, rule):
