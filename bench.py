@@ -177,10 +177,13 @@ def workload(name, channels, points):
     import numpy as np
     import waveforms_amd as wf
     from waveforms_amd import workloads as wl
-    if name in ('sampler256', 'c4', 'c5'):
+    if name in ('sampler256', 'c4', 'c5', 'iir_chain', 'iir_chain4'):
         return (lambda c: wl.sum_channel(wf, 100, 1000 + c)), wl.c2_grid(points), np.float64, (
             f'{channels} ch/GPU x {points:.0e} pts, 100 gaussian+DRAG pulses/ch, seeds '
-            f'1000+c (SURVEY 8(d) C4/C5 channel spec), grid mode')
+            f'1000+c (SURVEY 8(d) C4/C5 channel spec), grid mode' +
+            ('; then sosfilt with two biquads (butter(4, 0.1)): Waveform.sample(filters=), sampler inside the IIR scan' if name == 'iir_chain' else
+             '; then four first-order exponential-correction sections: predistort(wav(t), filters), sampler inside the IIR scan'
+             if name == 'iir_chain4' else ''))
     if name == 'c2':
         return (lambda c: wl.c2_channel(wf)), wl.c2_grid(points), np.float64, (
             f'C2: 1 ch x 100 gaussian+DRAG pulses x {points:.0e} pts')
@@ -226,6 +229,16 @@ def workload(name, channels, points):
 
 
 TILE = {'awg': 128, 'awg_duty30': 128, 'awg_c4': 128, 'awg_interp': 128, 'multitone': 8, 'direct_sinc': 8, 'direct_mollifier': 8, 'direct_interp': 8}     # rows = TILE copies of rows / TILE distinct channels
+
+
+def iir_shapes():
+    """the two IIR cascades of the bench: a two-biquad sosfilt cascade (Waveform.sample(filters=)) and four first-order
+    exponential-correction sections (predistort(filters=))"""
+    import numpy as np
+    from scipy.signal import butter
+    return {'two_biquads': [(s_[:3], s_[3:]) for s_ in butter(4, 0.1, output='sos')],
+            'four_first_order': [(np.array([1.02, -np.exp(-1 / t_) * 1.01]), np.array([1.0, -np.exp(-1 / t_)]))
+                                 for t_ in (50.0, 400.0, 3000.0, 20000.0)]}
 
 
 def default_shape(name):
@@ -493,7 +506,7 @@ def run_rank(args):
     tile = TILE.get(name, 1)
     if channels % tile:
         raise SystemExit(f'--channels must be a multiple of {tile} for workload {name}')
-    time_sharded = args.shard == 'time' and name not in ('tlist', 'c4', 'awg_c4')
+    time_sharded = args.shard == 'time' and name not in ('tlist', 'c4', 'awg_c4', 'iir_chain', 'iir_chain4')
     if time_sharded:
         from waveforms_amd._dist import TimeShardedSampler
         if channels % tile:
@@ -517,6 +530,14 @@ def run_rank(args):
         if not chain.fused:
             fir = FirStage(wl.c4_kernel(), bs.n, bs.n_channels, dtype)
             out2 = torch.empty_like(out)
+    if name in ('iir_chain', 'iir_chain4'):
+        # sample(filters=) / predistort(wav(t), filters): the wave that owns a chunk of the IIR scan evaluates its input
+        from waveforms_amd.distortion import SampledIir
+        a0, b0 = sh.start, sh.stop
+        chain = SampledIir([make_channel(c) for c in range(a0 // tile, b0 // tile)], grid,
+                           iir_shapes()['two_biquads' if name == 'iir_chain' else 'four_first_order'], None, dtype, tile=tile)
+        if not chain.fused:
+            raise SystemExit('iir_chain: the chain did not fuse: ' + chain.why_not)
 
     def step():
         if chain is not None and chain.fused:
@@ -597,9 +618,9 @@ def run_rank(args):
         roof['kernel'] = chain.plan.kernel_name()
         roof['table_bytes_per_launch'] = chain.plan.table_bytes()
         roof['frac_incl_tables'] = (algo_bytes + roof['table_bytes_per_launch']) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        roof['note'] = ('sampler fused into the FIR transform: algorithmic bytes = B_out per sample '
+        roof['note'] = ('sampler fused into the %s: algorithmic bytes = B_out per sample '
                         '(SURVEY 8(d) "fused sampler->FIR: B_out only"); the kernel is bound by fp64 VALU issue, '
-                        'not by HBM: see roofline_valu')
+                        'not by HBM: see roofline_valu' % ('IIR scan' if name.startswith('iir_chain') else 'FIR transform'))
         rv = valu_roofline(name, kern_ms, bs.n_channels * bs.n)
         if rv is not None:
             roof['roofline_valu'] = rv
@@ -693,13 +714,10 @@ def run_rank(args):
         # N1): a two-biquad sosfilt cascade and four first-order (exponential-correction) sections;
         # 16 B/sample algorithmic (read + write), kernel time by HIP events
         try:
-            from scipy.signal import butter
             from waveforms_amd import _engine
             stream = torch.cuda.current_stream().cuda_stream
             iir = {}
-            shapes = {'two_biquads': [(s_[:3], s_[3:]) for s_ in butter(4, 0.1, output='sos')],
-                      'four_first_order': [(np.array([1.02, -np.exp(-1 / t_) * 1.01]), np.array([1.0, -np.exp(-1 / t_)]))
-                                           for t_ in (50.0, 400.0, 3000.0, 20000.0)]}
+            shapes = iir_shapes()
             for sname, secs in shapes.items():
                 ip = _engine.IirPlan(secs, bs.n, bs.n_channels, dtype)
                 zi = torch.zeros((bs.n_channels, ip.state_dim), dtype=torch.float64, device='cuda')
@@ -713,6 +731,22 @@ def run_rank(args):
             also['iir'] = iir
         except Exception as e:      # (the stage is outside the headline path: report, do not fail the line)
             also['iir'] = {'error': repr(e)}
+        # the same cascades with the sampler INSIDE the scan (wfk_chain_iir_*): sample(filters=) / predistort(wav(t),
+        # filters) device-resident; 8 B/sample algorithmic (the filtered output only)
+        try:
+            from waveforms_amd.distortion import SampledIir
+            ic = {}
+            for sname, secs in iir_shapes().items():
+                sc = SampledIir([make_channel(c) for c in range(sh.start, sh.stop)], grid, secs, None, dtype)
+                ms = timed(lambda: sc.launch_torch(out2), 5, 2)
+                ic[sname] = {'kernel': sc.plan.kernel_name(), 'fused': sc.fused, 'ms': ms,
+                             'msamples_per_s': bs.n_channels * bs.n / (ms * 1e-3) / 1e6,
+                             'frac': algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'unfused_ms': kern_ms + also['iir'].get(sname, {}).get('ms', float('nan'))}
+                sc.close()
+            also['iir_chain'] = ic
+        except Exception as e:
+            also['iir_chain'] = {'error': repr(e)}
         del out2
         # the same 256 x 1e7 plan launched into a float buffer (4 B/sample)
         if dtype == np.float64:

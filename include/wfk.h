@@ -265,6 +265,34 @@ int wfk_iir_apply(wfk_iir_plan* plan, const void* in_dev, int64_t in_stride, voi
 int wfk_iir_status(wfk_iir_plan* plan, void* hip_stream);
 int wfk_iir_plan_destroy(wfk_iir_plan* plan);
 
+/* -- sampler -> IIR (-> FIR) chain ------------------------------------------------------------ */
+/* out = F(wav(t) - initial) + initial for every channel of `prog` on `grid`, F the cascade of wfk_iir_plan_create
+ * (same section layout, same zi / zf state layout, [n_channels][state_dim]) -- Waveform.sample(filters=(sos, initial))
+ * (waveforms/waveform.py:190-203, chunked with carried zi :244-251); with `ker_host` != NULL followed by the FIR of
+ * wfk_fir_plan_create (ker_per_row != 0: kers_host[channel * K + k]) -- predistort(wav(t), filters, ker)
+ * (waveforms/distortion.py:298-337).  Everything stays on the device.  When the program is fully fused (carrier-envelope
+ * ops only, real amplitudes, no clip) and the cascade's first pass is in the single-pass form (state dimension <= 4),
+ * the wave that owns a 2048-sample chunk of the scan EVALUATES its input instead of loading it (iir_sampled): the
+ * unfiltered samples never touch HBM and the pass moves the 8 (4) B/sample of its output only.  Otherwise
+ * sampler -> (in place) IIR.  The FIR stage reads the filtered rows from a workspace the plan owns.
+ * wfk_chain_iir_launch() allocates nothing and does not synchronise; status / timeout semantics as wfk_iir_status
+ * (after a timeout the plan runs unfused in the three-launch form).                                            */
+typedef struct wfk_chain_iir_plan wfk_chain_iir_plan;
+int wfk_chain_iir_plan_create(const wfk_program* prog, const wfk_grid* grid, int32_t n_sections,
+                              const int32_t* orders, const double* b, const double* a,
+                              const double* ker_host /* or NULL */, int32_t K, int32_t ker_per_row,
+                              int kind /* WFK_OUT_F64|F32 */, wfk_chain_iir_plan** out);
+int wfk_chain_iir_is_fused(const wfk_chain_iir_plan* plan);
+const char* wfk_chain_iir_unfused_reason(const wfk_chain_iir_plan* plan);
+/* "iir_sampled<T,NSEC,ORD,PLAIN>" (+ later passes / FIR) or the kernels of the unfused path */
+const char* wfk_chain_iir_kernel_name(const wfk_chain_iir_plan* plan);
+int64_t wfk_chain_iir_table_bytes(const wfk_chain_iir_plan* plan);
+int wfk_chain_iir_state_dim(const wfk_chain_iir_plan* plan);
+int wfk_chain_iir_launch(wfk_chain_iir_plan* plan, void* out_dev, int64_t out_stride, const double* zi_dev,
+                         double* zf_dev, double initial, void* hip_stream);
+int wfk_chain_iir_status(wfk_chain_iir_plan* plan, void* hip_stream);
+int wfk_chain_iir_plan_destroy(wfk_chain_iir_plan* plan);
+
 /* -- whole-signal transfer function ------------------- */
 /* out = irfft(rfft(in) * H) per row; rows contiguous (stride n); H_dev = n/2+1 complex128
  * bins on the device (f_k = k*fs/n).  Replaces the scipy.fftpack calls of

@@ -232,7 +232,7 @@ def make_iir(ref, gold):
         b, a = butter(order, fc, 'lowpass', fs=rate)
         w.filters = (tf2sos(b, a), initial)
         iir[name + '.full'] = w.sample()
-        iir[name + '.chunked'] = np.concatenate(list(w.sample(chunk_size=300)))
+        iir[name + '.chunked'] = np.concatenate(list(w.sample(chunk_size=cases.iir_chunk(name))))
     dist = ref.distortion
     for i, (n, params, initial, k) in enumerate(cases.predistort_cases()):
         sig, ker = cases.predistort_inputs(i)      # seeded: inputs are not stored

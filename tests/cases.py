@@ -211,7 +211,17 @@ def iir_cases():
         # complex-valued waveform through the (real) sections: scipy.signal.sosfilt takes complex input
         'iir_cplx': (lambda ns: (1 + 0.5j) * ns.square(0.8, edge=0.1) * ns.cos(40.0) + 0.2j * (ns.gaussian(0.5) >> 0.6),
                      -1, 1.5, 4000, 4, 90.0, 0.3),
+        # fully fused trees on rows long enough for the single-pass scan: the sampler runs INSIDE the IIR pass
+        # (wfk_chain_iir_*, iir_sampled: rows of >= 32 768 samples); 42 000 samples, chunked in 36 000s (the first chunk
+        # fuses, the last does not)
+        'iir_fused2': (lambda ns: 0.1 + wl.sum_channel(ns, 14, 31), 0, 420e-9, 1e11, 4, 2e9, 0.1),
+        'iir_fused1': (lambda ns: wl.vstack_channel(ns, 14, 32), 0, 420e-9, 1e11, 2, 5e9, 0),
     }
+
+
+def iir_chunk(name):
+    """chunk_size of the chunked sample() of an iir_case"""
+    return 36000 if name.startswith('iir_fused') else 300
 
 
 def predistort_cases():

@@ -68,8 +68,9 @@ def test_sample_with_filters(name):
     assert np.max(np.abs(got - np_oracle.sample_filtered(w))) <= 1e-10
     # chunked: state carried chunk to chunk, also written into `out`
     wantc = IIR[name + '.chunked']
-    out = np.zeros(len(wantc) + 300, dtype=want.dtype)
-    gotc = np.concatenate(list(w.sample(chunk_size=300, out=out)))
+    cs = cases.iir_chunk(name)
+    out = np.zeros(len(wantc) + cs, dtype=want.dtype)
+    gotc = np.concatenate(list(w.sample(chunk_size=cs, out=out)))
     assert gotc.shape == wantc.shape
     assert np.max(np.abs(gotc - wantc)) <= 1e-10 * max(1.0, np.abs(wantc).max())
     assert np.array_equal(out[:len(gotc)], gotc)

@@ -90,6 +90,18 @@ def lib():
         l.wfk_chain_table_bytes.restype = I64
         l.wfk_chain_launch.argtypes = [VP, VP, I64, VP]
         l.wfk_chain_plan_destroy.argtypes = [VP]
+        l.wfk_chain_iir_plan_create.argtypes = [P(wfk_program), P(wfk_grid), I32, VP, VP, VP, VP, I32, I32, C.c_int, P(VP)]
+        l.wfk_chain_iir_is_fused.argtypes = [VP]
+        l.wfk_chain_iir_unfused_reason.argtypes = [VP]
+        l.wfk_chain_iir_unfused_reason.restype = C.c_char_p
+        l.wfk_chain_iir_kernel_name.argtypes = [VP]
+        l.wfk_chain_iir_kernel_name.restype = C.c_char_p
+        l.wfk_chain_iir_table_bytes.argtypes = [VP]
+        l.wfk_chain_iir_table_bytes.restype = I64
+        l.wfk_chain_iir_state_dim.argtypes = [VP]
+        l.wfk_chain_iir_launch.argtypes = [VP, VP, I64, VP, VP, C.c_double, VP]
+        l.wfk_chain_iir_status.argtypes = [VP, VP]
+        l.wfk_chain_iir_plan_destroy.argtypes = [VP]
         l.wfk_iir_plan_create.argtypes = [I32, VP, VP, VP, I64, I32, C.c_int, P(VP)]
         l.wfk_iir_state_dim.argtypes = [VP]
         l.wfk_iir_apply.argtypes = [VP, VP, I64, VP, I64, VP, VP, C.c_double, VP]
@@ -325,6 +337,80 @@ class ChainPlan:
     __del__ = close
 
 
+def _pack_sections(sections):
+    """list of (b, a) -> (orders int32, b flat, a flat), every section padded to max(len(b), len(a))"""
+    orders, bs, as_ = [], [], []
+    for b, a in sections:
+        b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+        a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+        m = max(len(b), len(a))
+        bs.append(np.concatenate([b, np.zeros(m - len(b))]))
+        as_.append(np.concatenate([a, np.zeros(m - len(a))]))
+        orders.append(m - 1)
+    return (np.asarray(orders, dtype=np.int32), np.ascontiguousarray(np.concatenate(bs)),
+            np.ascontiguousarray(np.concatenate(as_)))
+
+
+class ChainIirPlan:
+    """sampler -> IIR cascade (-> FIR) for every channel of `prog` on `grid`, device-resident:
+    `sosfilt(sos, wav(t) - initial, zi) + initial` of Waveform.sample(filters=) (reference waveform.py:190-203,
+    244-251) and `predistort(wav(t), filters, ker)` (distortion.py:298-337).  When the program is fully fused and the
+    (first pass of the) cascade has a state dimension <= 4, the wave that owns a chunk of the IIR scan EVALUATES its
+    input (`iir_sampled<...>`): the unfiltered samples never touch HBM (`fused`, `why_not`, `kernel_name()`).
+    `ker` (K,) or (n_channels, K): an FIR stage behind the cascade."""
+
+    def __init__(self, prog: Program, grid: wfk_grid, sections, ker=None, dtype=np.float64):
+        orders, bflat, aflat = _pack_sections(sections)
+        self.prog, self.grid, self.dtype = prog, grid, np.dtype(dtype)
+        self.n, self.n_channels = int(grid.n), prog.n_channels
+        self._h = C.c_void_p()
+        kp, K, rows = None, 0, 0
+        if ker is not None:
+            ker = np.ascontiguousarray(ker, dtype=np.float64)
+            if ker.ndim == 2 and ker.shape[0] != prog.n_channels:
+                raise ValueError('per-channel kernels: ker must have shape (n_channels, K)')
+            kp, K, rows = ker.ctypes.data, ker.shape[-1], int(ker.ndim == 2)
+        check(lib().wfk_chain_iir_plan_create(C.byref(prog.struct), C.byref(grid), len(orders), orders.ctypes.data,
+                                              bflat.ctypes.data, aflat.ctypes.data, kp, K, rows,
+                                              _KIND_OF[self.dtype], C.byref(self._h)))
+        self.state_dim = int(sum(orders))
+        self.why_not = lib().wfk_chain_iir_unfused_reason(self._h).decode()
+
+    @property
+    def fused(self) -> bool:
+        return bool(lib().wfk_chain_iir_is_fused(self._h))
+
+    def launch(self, out_ptr: int, out_stride: int, zi_ptr=None, zf_ptr=None, initial=0.0, stream: int = 0) -> bool:
+        """-> False when the library refused the launch with WFK_ETIMEOUT (an earlier launch of this plan ran into a
+        look-back timeout; the plan has switched to the unfused three-launch form: launch again)"""
+        rc = lib().wfk_chain_iir_launch(self._h, out_ptr, out_stride, zi_ptr, zf_ptr, float(initial), stream)
+        if rc == E_TIMEOUT:
+            return False
+        check(rc)
+        return True
+
+    def status(self, stream=0) -> bool:
+        """Synchronise `stream`; False if a launch since the last check timed out in a look-back (outputs hold NaN)"""
+        rc = lib().wfk_chain_iir_status(self._h, stream)
+        if rc == E_TIMEOUT:
+            return False
+        check(rc)
+        return True
+
+    def kernel_name(self) -> str:
+        return lib().wfk_chain_iir_kernel_name(self._h).decode()
+
+    def table_bytes(self) -> int:
+        return int(lib().wfk_chain_iir_table_bytes(self._h))
+
+    def close(self):
+        if self._h and _lib is not None:
+            _lib.wfk_chain_iir_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
 class IirPlan:
     """Cascade of direct-form-II-transposed sections along each of `batch` rows.
 
@@ -333,17 +419,7 @@ class IirPlan:
     list [(row[:3], row[3:]) for row in sos] (scipy.signal.sosfilt)."""
 
     def __init__(self, sections, n: int, batch: int = 1, dtype=np.float64):
-        orders, bs, as_ = [], [], []
-        for b, a in sections:
-            b = np.atleast_1d(np.asarray(b, dtype=np.float64))
-            a = np.atleast_1d(np.asarray(a, dtype=np.float64))
-            m = max(len(b), len(a))
-            bs.append(np.concatenate([b, np.zeros(m - len(b))]))
-            as_.append(np.concatenate([a, np.zeros(m - len(a))]))
-            orders.append(m - 1)
-        orders = np.asarray(orders, dtype=np.int32)
-        bflat = np.ascontiguousarray(np.concatenate(bs))
-        aflat = np.ascontiguousarray(np.concatenate(as_))
+        orders, bflat, aflat = _pack_sections(sections)
         self.n, self.batch, self.dtype = int(n), int(batch), np.dtype(dtype)
         self._h = C.c_void_p()
         check(lib().wfk_iir_plan_create(len(orders), orders.ctypes.data, bflat.ctypes.data,

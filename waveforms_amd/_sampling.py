@@ -253,31 +253,32 @@ def _sample_filtered(w, plan, sos, initial, zi):
         cplx = True          # a chunk of real samples behind complex ones: the carried state is complex
     n = plan.n
     rows = 2 if cplx else 1
-    iir = _engine.IirPlan(_sos_sections(sos), n, 1, np.float64)
-    D = iir.state_dim
+    # one sampler -> IIR chain per real row (wfk_chain_iir_*): the wave that owns a chunk of the IIR scan evaluates its
+    # input itself when the tree is fully fused (the unfiltered samples never exist in memory), otherwise sampler and
+    # filter run back to back on the device buffer
+    sections = _sos_sections(sos)
+    chains = [_engine.ChainIirPlan(plan.prog, plan.grid, sections)]
+    D = chains[0].state_dim
     buf = _engine.DeviceBuffer(max(n, 1) * 8 * rows)
     dzi = _engine.DeviceBuffer(max(D, 1) * 8 * rows)
     dzf = _engine.DeviceBuffer(max(D, 1) * 8 * rows)
-    plan_im = None
     try:
         z0 = np.zeros(D, dtype=np.complex128) if zi is None else np.asarray(zi, dtype=np.complex128).reshape(-1)
         init = complex(initial or 0.0)
         if cplx:
-            plan_im = _engine.Plan(_rotated(plan.prog), grid=plan.grid)
+            chains.append(_engine.ChainIirPlan(_rotated(plan.prog), plan.grid, sections))
         dzi.upload(np.ascontiguousarray(np.concatenate([z0.real, z0.imag])[:D * rows]))
         for attempt in range(2):
-            plan.launch(buf.ptr, n, _engine.OUT_F64)
-            if cplx:
-                plan_im.launch(buf.ptr + max(n, 1) * 8, n, _engine.OUT_F64)
             ok = True
-            for r in range(rows):
+            for r, chain in enumerate(chains):
                 off, zoff = r * max(n, 1) * 8, r * max(D, 1) * 8
-                ok = iir.apply(buf.ptr + off, n, buf.ptr + off, n, dzi.ptr + zoff, dzf.ptr + zoff,
-                               init.imag if r else init.real) and ok           # in place
-            if iir.status() and ok:
+                ok = chain.launch(buf.ptr + off, max(n, 1), dzi.ptr + zoff, dzf.ptr + zoff,
+                                  init.imag if r else init.real) and ok
+            ok = all([chain.status() for chain in chains]) and ok
+            if ok:
                 break
-            # a single-pass look-back timed out: the filter ran in place, so sample again; the plan has
-            # switched to the three-launch form
+            # a single-pass look-back timed out (its outputs hold NaN): the chains have switched to the
+            # three-launch form behind the plain sampler; launch again
             if attempt == 1:
                 raise _engine.EngineError('IIR stage failed twice')
         _engine.sync()
@@ -292,9 +293,8 @@ def _sample_filtered(w, plan, sos, initial, zi):
         buf.close()
         dzi.close()
         dzf.close()
-        iir.close()
-        if plan_im is not None:
-            plan_im.close()
+        for chain in chains:
+            chain.close()
     return sig, zf
 
 

@@ -2203,3 +2203,22 @@ int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, i
   }
   return bad.empty() ? WFK_OK : WFK_EINVAL;
 }
+
+// diagnostics (tools/): piece statistics of a plan compiled for another geometry -- out[0] pieces, out[1] live pieces,
+// out[2] shortest / out[3] longest live piece (samples), out[4] lean, out[5] largest first_len
+extern "C" int wfk_internal_geom_stats(const wfk_program* P, const wfk_grid* grid, int lane_stride, int ns, int64_t* out) {
+  HostPlan H;
+  std::string err;
+  const int rc = wfk_compile_geom(P, grid, lane_stride, ns, H, err);
+  if (rc) return rc;
+  int64_t live = 0, lo = INT64_MAX, hi = 0, fl = 0;
+  for (const DevPiece& p : H.pieces)
+    if (p.n_blk > 0) {
+      ++live;
+      lo = std::min(lo, p.stop - p.start);
+      hi = std::max(hi, p.stop - p.start);
+      fl = std::max<int64_t>(fl, p.first_len);
+    }
+  out[0] = (int64_t)H.pieces.size(); out[1] = live; out[2] = live ? lo : 0; out[3] = hi; out[4] = H.lean; out[5] = fl;
+  return 0;
+}

@@ -30,6 +30,8 @@
 #include <vector>
 
 #include "wfk.h"
+#include "wfk_chain_dev.h"
+#include "wfk_internal.h"
 
 #define IIR_MAXD 16
 #define IIR_MAXSEC 8
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   // ---- load: sample j = i*64 + lane of the chunk belongs to block j / OP_LB, position j % OP_LB
   // (a whole chunk loads unconditionally: with the bounds test inside the loop every load sits in
   //  its own branch and is waited for before the next one is issued -- the whole kernel then runs
-  //  at a fraction of the copy rate, tools/attic/iir_stream_probe.hip)
+  //  at a fraction of the copy rate, the stream probe of round 2, HISTORY)
   if (whole) {
     T v[OP_LB];
 #pragma unroll
@@ -619,6 +621,430 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
   }
 }
 
+// ---- the sampler inside the single pass: iir_sampled ----------------------------------------------------------
+// Reference chain: Waveform.sample(filters=(sos, initial)) = sosfilt(sos, wav(t) - initial) + initial
+// (waveforms/waveform.py:190-203, chunked :244-251) and predistort(wav(t), filters) (waveforms/distortion.py:298-321).
+// Unfused, the samples make a round trip through HBM: 8 B written by the sampler, 8 B read and 8 B written by the
+// filter.  Here the wave that owns a chunk EVALUATES its input with fir_sampled's arithmetic (wfk_chain_dev.h: one
+// exact seed per fused op and lane, phasor table / Gaussian recurrence stepping by dt, no libm; the plan compiled for
+// that geometry by wfk_compile_geom(1, 32)) straight into the registers the sweep reads: no load, no input transpose.
+//
+// What iir_onepass pays per 2048-sample chunk -- ticket, flag polls, aggregate loads: dependent memory round trips
+// that two waves per SIMD cannot hide (its 256 x 1e7 launch waits three quarters of its time) -- is paid here per chunk
+// of 8192: a lane owns a RUN of OPS_RUN = 128 consecutive samples, taken in four rounds of 32 with the sampler's op
+// state (phasor, Gaussian pair) and the filter state carried from round to round.  A sample costs ~10 VALU
+// instructions to evaluate, so the chunk is not kept between the two sweeps (that would be 64 KB per wave), it is
+// evaluated TWICE:
+//   pass 1  four rounds: evaluate 32, sweep on from the running state (zero at the run's start); then the in-wave
+//           scan of the 64 run states (TL = 128-step transition), aggregate, look-back (as iir_onepass);
+//   pass 2  four rounds again from the true state v_(l-1) + TL^l S_in: evaluate, sweep, transpose through LDS, store.
+// All parameter blocks of the pieces a chunk overlaps are staged in LDS once per chunk (the host admits a plan only
+// if they fit).  Algorithmic traffic: the 8 (4) B/sample of the filtered output.
+#ifndef OPS_RUN
+#define OPS_RUN 128
+#endif
+#define OPS_ROUNDS (OPS_RUN / OP_LB)
+#define OPS_CHUNK (64 * OPS_RUN)
+#ifndef OPS_WAVES
+#define OPS_WAVES 2
+#endif
+#define OPS_PAR 768             // doubles of LDS for the parameter blocks of the pieces a chunk overlaps
+#define OPS_NCAR 2              // ops of a piece whose state is carried in registers from round to round
+
+struct IirSampArgs {
+  const DevChannel* channels;
+  const DevPiece* pieces;
+  const double* params;
+  const int32_t* chunk_first;   // [rows * nchunks] first piece overlapping each chunk of OPS_CHUNK samples
+  int64_t nchunks;
+  double t0, step, last;
+  int32_t has_last, pad;
+  int64_t n, i0;
+};
+
+// The pieces a chunk overlaps (zero pieces included), as the wave staged them: piece i covers samples
+// [start[i], start[i + 1]) of the row and has its parameter block at s_par + off[i] (off < 0: a zero piece).
+#define OPS_PMAX 16
+struct OpsPieces {
+  int64_t start[OPS_PMAX + 1];
+  int32_t off[OPS_PMAX];
+};
+
+// One round of a lane's run: the OP_LB consecutive samples js .. js + 31 of the row -> acc (channel offset included;
+// zeros past the end of the row).  FAST form: every live piece of the chunk has the same op shapes (the host / the
+// staging pass checks the packed op words) -- the usual pulse train.  Each LANE then reads the record and the phasor
+// table of ITS OWN piece (per-lane LDS addresses; all lanes of a wave sit in one or two pieces), so a chunk that
+// crosses piece edges costs what an interior chunk costs.  A lane whose 32 samples lie inside one piece runs the
+// unmasked loop and carries its op state (phasor, Gaussian pair) to the next round as long as it stays in that piece;
+// the one or two lanes per edge whose segment STRADDLES it take a per-sample-masked pass of their own (entered only when
+// some lane of the wave straddles).  Live pieces are >= 32 samples long (host check): a segment meets at most two.
+template <typename T>
+__device__ __forceinline__ void ops_round(const IirSampArgs& a, const DevChannel& C, const double* s_par,
+                                          const OpsPieces& pd, int m, int nops, int shape_off, bool deg1,
+                                          int64_t js, bool first_round, int& prev_p, ChSeeds (&car)[OPS_NCAR],
+                                          T (&acc)[OP_LB]) {
+  constexpr int CL = OP_LB;
+  const double2* const unit_tab = reinterpret_cast<const double2*>(s_par + OPS_PAR);
+  CH_EACH(CL, k) acc[k] = (T)0; CH_END
+  double x;
+  {
+#pragma clang fp contract(off)
+    const double mm = (double)(js + a.i0) * a.step;
+    x = mm + a.t0;
+    if (a.has_last && js == a.n - 1) x = a.last;
+  }
+  if (C.tshift != 0.0) x = x - C.tshift;
+  // the lane's piece at its first and at its last sample
+  int p0 = 0, p1 = 0;
+  for (int i = 1; i < m; ++i) {
+    const int64_t st = pd.start[i];
+    p0 += st <= js ? 1 : 0;
+    p1 += st <= js + (CL - 1) ? 1 : 0;
+  }
+  const int o0 = pd.off[p0], o1 = pd.off[p1];
+  const bool inside = p1 == p0;
+  const bool main_on = inside && o0 >= 0;                      // the whole segment in one live piece
+  const bool part0 = !inside && o0 >= 0, part1 = !inside && o1 >= 0;
+  const double* const blk0 = s_par + (o0 >= 0 ? o0 : shape_off);
+  const double* const blk1 = s_par + (o1 >= 0 ? o1 : shape_off);
+  const bool keep = !first_round && main_on && prev_p == p0;   // the carried state continues this lane's run in this piece
+  prev_p = main_on ? p0 : -1;
+  const bool any_main = __any(main_on), any_fresh = __any(main_on && !keep), any_part = __any(!inside);
+  for (int op = 0; op < nops; ++op) {
+    const int fl = cuni(WFK_FCE_WORD(s_par + shape_off + WFK_BLK_HDR + op * WFK_FCE_REC));   // the same in every live piece
+    const int env = (fl >> 4) & 3, carrier = (fl >> 2) & 1;
+    if (any_main) {
+      const double* rec = blk0 + WFK_BLK_HDR + op * WFK_FCE_REC;
+      const bool fresh = !keep || op >= OPS_NCAR;
+      ChSeeds sd, nx;
+      sd.c = 1.0; sd.s = 0.0; sd.g = 1.0; sd.r = 1.0;
+      if (op == 0) sd = car[0];
+      if (OPS_NCAR > 1 && op == 1) sd = car[OPS_NCAR > 1 ? 1 : 0];
+      if (any_fresh || op >= OPS_NCAR) {
+        const ChSeeds ex = chain_make_seeds(rec, x, fl);       // exact
+        if (fresh) sd = ex;
+      }
+      nx = sd;
+      if (main_on) {
+        if (env == 3) {
+          chain_envmul<T, CL, CL>(rec, sd, acc, 0, CL, nx);
+        } else {
+          const double2* tab = carrier ? reinterpret_cast<const double2*>(blk0 + WFK_FCE_TABOFF(fl)) : unit_tab;
+          const double qq = env ? rec[WFK_FCE_Q] : 1.0;
+          const double u0 = x - rec[WFK_FCE_SLIN];
+          if (deg1) chain_loop<T, CL, CL, false, true>(tab, rec, sd, u0, qq, acc, 0, CL, nx);
+          else chain_loop<T, CL, CL, false, false>(tab, rec, sd, u0, qq, acc, 0, CL, nx);
+        }
+      }
+      if (op == 0) car[0] = nx;
+      if (OPS_NCAR > 1 && op == 1) car[OPS_NCAR > 1 ? 1 : 0] = nx;
+    }
+    if (any_part) {
+      // segments that straddle a piece edge: samples [0, e0) belong to piece p0, [e1, CL) to piece p1
+      const int64_t d0 = pd.start[p0 + 1] - js, d1 = pd.start[p1] - js;
+      const int e0 = d0 > CL ? CL : (int)d0, e1 = d1 < 0 ? 0 : (int)d1;
+      ChSeeds nx;
+      if (part0) {
+        const double* rec = blk0 + WFK_BLK_HDR + op * WFK_FCE_REC;
+        const ChSeeds sd = chain_make_seeds(rec, x, fl);
+        if (env == 3) {
+          chain_envmul<T, CL, -1, true>(rec, sd, acc, 0, e0, nx);
+        } else {
+          const double2* tab = carrier ? reinterpret_cast<const double2*>(blk0 + WFK_FCE_TABOFF(fl)) : unit_tab;
+          chain_loop<T, CL, -1, true, false, true>(tab, rec, sd, x - rec[WFK_FCE_SLIN], env ? rec[WFK_FCE_Q] : 1.0, acc, 0, e0, nx);
+        }
+      }
+      if (part1) {
+        const double* rec = blk1 + WFK_BLK_HDR + op * WFK_FCE_REC;
+        const ChSeeds sd = chain_make_seeds(rec, x, fl);
+        if (env == 3) {
+          chain_envmul<T, CL, -1, true>(rec, sd, acc, e1, CL, nx);
+        } else {
+          const double2* tab = carrier ? reinterpret_cast<const double2*>(blk1 + WFK_FCE_TABOFF(fl)) : unit_tab;
+          chain_loop<T, CL, -1, true, false, true>(tab, rec, sd, x - rec[WFK_FCE_SLIN], env ? rec[WFK_FCE_Q] : 1.0, acc, e1, CL, nx);
+        }
+      }
+    }
+  }
+  const T base = (T)C.offset;
+  if (js + CL <= a.n) {
+    CH_EACH(CL, k) acc[k] += base; CH_END
+  } else {
+    CH_EACH(CL, k) acc[k] = js + k < a.n ? acc[k] + base : (T)0; CH_END
+  }
+}
+
+template <typename T, int NSEC, int ORD, bool PLAIN>
+__global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, const IirSampArgs sa,
+                                                  T* __restrict__ out, int64_t out_stride,
+                                                  unsigned* __restrict__ status, double* __restrict__ aggbuf,
+                                                  double* __restrict__ prefbuf, unsigned* __restrict__ ticket,
+                                                  const double* __restrict__ pwL, const double* __restrict__ lanepL,
+                                                  const double* __restrict__ lanepU, const double* __restrict__ wdot,
+                                                  const double* __restrict__ zi, double* __restrict__ zf, int64_t n,
+                                                  int64_t nchunks, int rows, unsigned epoch, double pre_sub,
+                                                  double post_add, int persist, unsigned* __restrict__ fault,
+                                                  int spin_limit) {
+  constexpr int DD = NSEC * ORD;       // state dimension (<= 4)
+  __shared__ __attribute__((aligned(16))) double s_par[OPS_PAR + 2 * (OP_LB + 1) + 2];
+  __shared__ T tile[64][OP_LB / 2 + 1];
+  __shared__ OpsPieces pd;
+  // PLAIN: the run's end state from zero state as a DOT PRODUCT, f = sum_k W[k] x_k with W[k] = TL-step response to a
+  // unit sample at position k (host, quad precision): DD independent fmas per sample instead of the sweep's 5 per
+  // section in one dependent chain.  (Only where the transition powers have entries of order 1: no cancellation.)
+  __shared__ __attribute__((aligned(16))) double s_w[PLAIN ? OPS_RUN * 4 : 4];
+  const int lane = threadIdx.x;
+  if (PLAIN) {
+    for (int i = lane; i < OPS_RUN * 4; i += 64) s_w[i] = wdot[i];
+  }
+  const int row = (int)(blockIdx.x % (unsigned)rows);
+  const DevChannel C = sa.channels[row];
+  if (lane <= OP_LB) reinterpret_cast<double2*>(s_par + OPS_PAR)[lane] = make_double2(1.0, 0.0);   // phasor table of ops without a carrier
+  for (;;) {
+  unsigned t = 0;
+  if (lane == 0) t = atomicAdd(ticket + 16 * row, 1u);
+  t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+  const int64_t chunk = t;
+  if (chunk >= nchunks) return;
+  const int64_t base = chunk * OPS_CHUNK, chunk_end = base + OPS_CHUNK;
+  const int64_t jrun = base + (int64_t)lane * OPS_RUN;         // first sample of this lane's run
+  T* y = out + (int64_t)row * out_stride + base;
+
+  // ---- stage the pieces the chunk overlaps: descriptors (zero pieces included) and the parameter blocks of the live
+  // ones, back to back (the host has checked that they fit, that there are <= OPS_PMAX, and that all live pieces of
+  // the plan have the same op shapes)
+  int m = 0, shape_off = 0;
+  bool have_live = false;
+  {
+    __syncthreads();                                           // the previous chunk is done with the blocks
+    int off = 0;
+    bool& have = have_live;
+    for (int q = cuni(sa.chunk_first[(int64_t)row * sa.nchunks + chunk]); q < C.piece_end && m < OPS_PMAX; q = cuni(q + 1)) {
+      const DevPiece P = sa.pieces[q];
+      if (P.start >= chunk_end) break;
+      if (lane == 0) {
+        pd.start[m] = m == 0 ? INT64_MIN : P.start;
+        pd.start[m + 1] = INT64_MAX;
+        pd.off[m] = P.n_blk == 0 ? -1 : off;
+      }
+      ++m;
+      if (P.n_blk == 0) continue;
+      for (int i = lane; i < P.first_len; i += 64) s_par[off + i] = sa.params[P.par_off + i];
+      if (!have) { shape_off = off; have = true; }
+      off = cuni(off + ((P.first_len + 1) & ~1));
+    }
+    __syncthreads();
+  }
+  const int nops = have_live ? cuni((int)s_par[shape_off + 1]) : 0;
+  bool deg1 = true;
+  for (int op = 0; op < nops; ++op) {
+    const int fl = cuni(WFK_FCE_WORD(s_par + shape_off + WFK_BLK_HDR + op * WFK_FCE_REC));
+    deg1 = deg1 && (fl & 3) <= 1 && ((fl >> 4) & 3) != 3;
+  }
+  int prev_p = -1;
+
+  // ---- pass 1: the run from zero state, round by round
+  ChSeeds car[OPS_NCAR];
+#pragma unroll
+  for (int i = 0; i < OPS_NCAR; ++i) { car[i].c = 1.0; car[i].s = 0.0; car[i].g = 1.0; car[i].r = 1.0; }
+  double z[IIR_MAXD];
+#pragma unroll
+  for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
+#pragma unroll 1
+  for (int r = 0; r < OPS_ROUNDS; ++r) {
+    const int64_t js = jrun + r * OP_LB;
+    if (base + r * OP_LB >= n) break;                          // (wave-uniform: no lane has a sample in this round)
+    T acc[OP_LB];
+    ops_round<T>(sa, C, s_par, pd, m, nops, shape_off, deg1, js, r == 0, prev_p, car, acc);
+    const int64_t rest = n - js;
+    if (PLAIN && chunk_end <= n) {                             // (wave-uniform: every run of the chunk is whole)
+      const double* w = s_w + r * OP_LB * 4;
+#pragma unroll
+      for (int i = 0; i < OP_LB; ++i) {
+        const double xv = (double)acc[i] - pre_sub;
+#pragma unroll
+        for (int j = 0; j < DD; ++j) z[j] = fma(w[i * 4 + j], xv, z[j]);
+      }
+    } else if (rest >= OP_LB) {
+#pragma unroll
+      for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z);
+    } else {
+#pragma unroll
+      for (int i = 0; i < OP_LB; ++i)
+        if (i < rest) (void)iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z);
+    }
+  }
+  // (a run past the end of the row leaves its state alone; the scan still multiplies by TL per run, which only matters
+  //  AFTER the last sample -- nothing there is used)
+  if (PLAIN) wave_scan_plain<DD>(z, pwL, lane);
+  else wave_scan<DD>(z, pwL, DD, lane);                        // z = v_l (inclusive)
+  double vprev[DD], agg[DD];
+#pragma unroll
+  for (int i = 0; i < DD; ++i) {
+    const double up = __shfl_up(z[i], 1);
+    vprev[i] = lane == 0 ? 0.0 : up;
+    agg[i] = __shfl(z[i], 63);
+  }
+  const int64_t slot = ((int64_t)row * nchunks + chunk);
+  const unsigned F_AGG = epoch * 4u + 1u, F_PRE = epoch * 4u + 2u;
+  if (chunk > 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < DD; ++i) op_store(aggbuf + slot * DD + i, agg[i]);
+    __builtin_amdgcn_s_waitcnt(0);                             // the state is in memory before the flag is
+    __hip_atomic_store(status + slot, F_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- state at the chunk's start: decoupled look-back, window by window (see iir_onepass)
+  double sin_[IIR_MAXD];
+#pragma unroll
+  for (int i = 0; i < IIR_MAXD; ++i) sin_[i] = 0.0;
+  bool poisoned = false;
+  if (chunk == 0) {
+#pragma unroll
+    for (int i = 0; i < DD; ++i) sin_[i] = zi ? zi[(int64_t)row * DD + i] : 0.0;
+  } else {
+    double hop[IIR_MAXD];
+#pragma unroll
+    for (int i = 0; i < IIR_MAXD; ++i) hop[i] = 0.0;
+    int spins = 0;
+    for (int w = 0;; ++w) {
+      const int64_t pc = chunk - 1 - 64 * (int64_t)w - lane;
+      const unsigned* f = status + (int64_t)row * nchunks + (pc >= 0 ? pc : 0);
+      unsigned st = 0;
+      int kstop = -1;
+      bool whole_window = false;
+      for (; spins < spin_limit; ++spins) {
+        if (pc >= 0 && !(st == F_PRE)) st = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool pre = pc >= 0 && st == F_PRE;
+        const bool ag = pc >= 0 && (st == F_AGG || st == F_PRE);
+        const unsigned long long has_pre = __ballot(pre), has_agg = __ballot(ag);
+        if (has_pre != 0ull) {
+          const int k = __ffsll((long long)has_pre) - 1;       // nearest chunk with a prefix
+          const unsigned long long need = k == 0 ? 0ull : (~0ull >> (64 - k));   // lanes 0 .. k-1
+          if ((has_agg & need) == need) { kstop = k; break; }
+        } else if (has_agg == ~0ull && w < OP_WINDOWS - 1) {
+          whole_window = true;
+          kstop = 64;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (kstop < 0) { poisoned = true; kstop = 0; }
+      double contrib[IIR_MAXD];
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i) contrib[i] = 0.0;
+      if (lane <= kstop && pc >= 0) {
+        const double* src = (lane == kstop ? prefbuf : aggbuf) + ((int64_t)row * nchunks + pc) * DD;
+        double v[IIR_MAXD];
+#pragma unroll
+        for (int i = 0; i < IIR_MAXD; ++i) v[i] = i < DD ? op_load(src + i) : 0.0;
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < DD; ++i) contrib[i] = v[i];     // U^0
+        } else {
+          dd_matvec_add<DD>(contrib, lanepU + (int64_t)(lane - 1) * DD * DD * 2, v, DD);   // U^lane
+        }
+      }
+      double wsum[IIR_MAXD];
+#pragma unroll
+      for (int i = 0; i < IIR_MAXD; ++i) wsum[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < DD; ++i) {
+        double sum = contrib[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        wsum[i] = sum;
+      }
+      for (int q = 0; q < w; ++q) {                            // this window lies 64 w chunks back: U^(64 w)
+        double nx[IIR_MAXD];
+#pragma unroll
+        for (int i = 0; i < IIR_MAXD; ++i) nx[i] = 0.0;
+        dd_matvec_add<DD>(nx, lanepU + (int64_t)63 * DD * DD * 2, wsum, DD);
+#pragma unroll
+        for (int i = 0; i < IIR_MAXD; ++i) wsum[i] = nx[i];
+      }
+#pragma unroll
+      for (int i = 0; i < DD; ++i) hop[i] += wsum[i];
+      if (!whole_window) break;
+    }
+#pragma unroll
+    for (int i = 0; i < DD; ++i) sin_[i] = hop[i];
+  }
+  poisoned = __any(poisoned);
+  if (poisoned && lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
+  // ---- publish the inclusive prefix: agg + U * S_in
+  if (lane == 0) {
+    double so[IIR_MAXD];
+#pragma unroll
+    for (int i = 0; i < IIR_MAXD; ++i) so[i] = i < DD ? agg[i < DD ? i : 0] : 0.0;
+    dd_matvec_add<DD>(so, lanepU, sin_, DD);
+    if (chunk + 1 < nchunks) {
+#pragma unroll
+      for (int i = 0; i < DD; ++i) op_store(prefbuf + slot * DD + i, so[i]);
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_store(status + slot, F_PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  // ---- pass 2: the run again from its true state v_(l-1) + TL^l S_in: evaluate, sweep, store
+#pragma unroll
+  for (int i = 0; i < IIR_MAXD; ++i) z[i] = i < DD ? vprev[i < DD ? i : 0] : 0.0;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < DD; ++i) z[i] = sin_[i];
+  } else if (PLAIN) {
+    matvec_add_plain<DD>(z, lanepL + (int64_t)(lane - 1) * DD * DD * 2, sin_);
+  } else {
+    dd_matvec_add<DD>(z, lanepL + (int64_t)(lane - 1) * DD * DD * 2, sin_, DD);
+  }
+  const double bad = poisoned ? __builtin_nan("") : 0.0;
+#pragma unroll 1
+  for (int r = 0; r < OPS_ROUNDS; ++r) {
+    const int64_t js = jrun + r * OP_LB;
+    if (base + r * OP_LB >= n) break;                          // (wave-uniform)
+    T acc[OP_LB];
+    ops_round<T>(sa, C, s_par, pd, m, nops, shape_off, deg1, js, r == 0, prev_p, car, acc);
+    const int64_t rest = n - js;                               // samples of the row from this lane's segment on
+    if (rest >= OP_LB) {
+#pragma unroll
+      for (int i = 0; i < OP_LB; ++i) acc[i] = (T)(iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z) + post_add + bad);
+    } else {
+#pragma unroll
+      for (int i = 0; i < OP_LB; ++i)
+        if (i < rest) acc[i] = (T)(iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z) + post_add + bad);
+    }
+    // final state of the row: the segment that holds its last sample
+    if (zf && rest > 0 && rest <= OP_LB)
+      for (int i = 0; i < DD; ++i) zf[(int64_t)row * DD + i] = z[i];
+    // Store, in two halves of 16 samples per lane through the LDS tile: tile row l then holds samples
+    // l * OPS_RUN + 32 r + 16 h + [0, 16) of the chunk -- one 128-byte line; a wave instruction stores four rows.
+    // (The store phase's view of the lane index is opaque: left to itself the compiler computes the LDS addresses and
+    // global offsets of this phase once, above the chunk loop, and spills them.)
+    int lt = lane;
+    asm volatile("" : "+v"(lt));
+    constexpr int HS = OP_LB / 2, RPI = 64 / HS;               // samples per half; tile rows per wave instruction
+    const int col = lt % HS, rsub = lt / HS;                   // rows RPI i + rsub, column col
+    const T* tp = &tile[0][0] + rsub * (HS + 1) + col;
+    CH_EACH(2, h)
+      __syncthreads();                                         // the previous half's stores have read the tile
+      CH_EACH(HS, i) tile[lane][i] = acc[h * HS + i]; CH_END
+      __syncthreads();
+      T* ys = y + (int64_t)rsub * OPS_RUN + r * OP_LB + h * HS + col;
+      if (chunk_end <= n) {
+#pragma unroll
+        for (int i = 0; i < 64 / RPI; ++i) ys[(int64_t)i * RPI * OPS_RUN] = tp[i * RPI * (HS + 1)];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 64 / RPI; ++i)
+          if (base + (int64_t)(RPI * i + rsub) * OPS_RUN + r * OP_LB + h * HS + col < n) ys[(int64_t)i * RPI * OPS_RUN] = tp[i * RPI * (HS + 1)];
+      }
+    CH_END
+  }
+  if (!persist) return;
+  }
+}
+
 // state dimension 0 (every section is a bare gain): y = g (x - pre) + post
 template <typename T>
 __global__ void __launch_bounds__(256) iir_scale(const T* __restrict__ in, int64_t in_stride,
@@ -694,6 +1120,12 @@ struct wfk_iir_plan {
   double* op_pw1 = nullptr;
   double* op_lanep1 = nullptr;
   double* op_lanepU = nullptr;
+  // iir_sampled: a lane owns a run of OPS_RUN samples: TL = T1^(OPS_RUN / OP_LB), UL = TL^64
+  double* op_pwL = nullptr;          // TL^(2^k)
+  double* op_lanepL = nullptr;       // TL^(l+1)
+  double* op_lanepUL = nullptr;      // UL^(l+1)
+  double* op_wdot = nullptr;         // [OPS_RUN][4]: end state of a run from zero state per unit sample at position k
+  bool op_plainL = false;
   unsigned* op_fault = nullptr;      // host memory, mapped: raised by a chunk whose look-back timed out
   unsigned* op_fault_dev = nullptr;  // ... its device address
 };
@@ -712,6 +1144,10 @@ int wfk_iir_plan_destroy(wfk_iir_plan* p) {
   (void)hipFree(p->op_pw1);
   (void)hipFree(p->op_lanep1);
   (void)hipFree(p->op_lanepU);
+  (void)hipFree(p->op_pwL);
+  (void)hipFree(p->op_lanepL);
+  (void)hipFree(p->op_lanepUL);
+  (void)hipFree(p->op_wdot);
   if (p->op_fault) (void)hipHostFree(p->op_fault);
   (void)hipFree(p->state);
   (void)hipFree(p->grp);
@@ -903,7 +1339,7 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
     // 256 x 1e7 11.7 / 11.5 vs 8.6 / 9.9, 64 x 1e7 3.0 / 3.2 vs 2.8 / 3.1, 64 x 1e5 0.39 / 0.46 vs
     // 0.04 / 0.05 (one launch instead of three).  WFK_IIR_ONEPASS=0 keeps the three-launch form.
     const char* on = getenv("WFK_IIR_ONEPASS");
-    // Between 8 and 64 LONG rows the three-launch form is still ahead (tools/attic/iir_depth.py, 2 biquads,
+    // Between 8 and 64 LONG rows the three-launch form is still ahead (round-2 depth probe, 2 biquads,
     // fp64, three-launch vs single pass: 8 x 1e7 0.61 vs 0.75 ms, 16 x 1e7 0.80 vs 1.22, 32 x 1e7 1.55 vs
     // 1.84, 48 x 1e7 2.29 vs 2.48; but 16 x 1e6 0.49 vs 0.12, 4 x 1e7 0.54 vs 0.38, 1 x 1e7 0.51 vs 0.15):
     // 2304 / rows chunks of a row are in flight there and every look-back reads all of them.
@@ -922,6 +1358,24 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
       std::vector<double> pw1, lanep1, pwU, lanepU;
       const std::vector<quad> U1 = tables(T1, pw1, lanep1);    // U1 = T1^64: one chunk
       tables(U1, pwU, lanepU);                                  // U1^(l+1), l < 64: the look-back window
+      std::vector<double> pwL, lanepL, pwUL, lanepUL;           // the same for the long runs of iir_sampled
+      {
+        std::vector<quad> TL = T1, nxt;
+        for (int k = 1; k < OPS_ROUNDS; ++k) { qmatmul(TL, T1, nxt, D); TL = nxt; }
+        const std::vector<quad> UL = tables(TL, pwL, lanepL);
+        tables(UL, pwUL, lanepUL);
+        double tm = 0.0;
+        for (size_t e = 0; e < lanepL.size(); e += 2) tm = std::max(tm, std::fabs(lanepL[e]));
+        const char* dde = getenv("WFK_IIR_DD");
+        p->op_plainL = tm < 16.0 && !(dde && dde[0] == '1');
+      }
+      std::vector<double> wdot((size_t)OPS_RUN * 4, 0.0);
+      for (int k = 0; k < OPS_RUN; ++k) {
+        quad z[IIR_MAXD];
+        for (int r = 0; r < IIR_MAXD; ++r) z[r] = 0;
+        for (int t = k; t < OPS_RUN; ++t) quad_step(c, t == k ? (quad)1 : (quad)0, z);
+        for (int r = 0; r < D && r < 4; ++r) wdot[(size_t)k * 4 + r] = (double)z[r];
+      }
       double tmax = 0.0;                                        // largest entry of T1^1 .. T1^64 (hi words)
       for (size_t e = 0; e < lanep1.size(); e += 2) tmax = std::max(tmax, std::fabs(lanep1[e]));
       const char* ddenv = getenv("WFK_IIR_DD");
@@ -933,7 +1387,8 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
                  hipMalloc(&p->op_ticket, (size_t)batch * 64) == hipSuccess &&
                  hipMalloc(&p->op_agg, slots * D * 8) == hipSuccess &&
                  hipMalloc(&p->op_pref, slots * D * 8) == hipSuccess && upload(&p->op_pw1, pw1) &&
-                 upload(&p->op_lanep1, lanep1) && upload(&p->op_lanepU, lanepU);
+                 upload(&p->op_lanep1, lanep1) && upload(&p->op_lanepU, lanepU) && upload(&p->op_pwL, pwL) &&
+                 upload(&p->op_lanepL, lanepL) && upload(&p->op_lanepUL, lanepUL) && upload(&p->op_wdot, wdot);
       ok1 = ok1 && hipHostMalloc((void**)&p->op_fault, 64, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&p->op_fault_dev, p->op_fault, 0) == hipSuccess;
       if (!ok1) {
@@ -984,11 +1439,14 @@ static void iir_launch(wfk_iir_plan* p, const void* in, int64_t is, void* out, i
 extern "C" {
 
 // y = F(x - pre) + post   (the public entry has pre == post == `initial`)
+// `src` != null: the first single-pass stage EVALUATES its input from the waveform program (iir_sampled) instead of
+// reading `in_dev`; the caller has checked that this stage is in the single-pass form.
 static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride, void* out_dev,
                           int64_t out_stride, const double* zi_dev, double* zf_dev, double initial,
-                          double post, void* hip_stream) {
+                          double post, void* hip_stream, const IirSampArgs* src = nullptr) {
   if (!p) return iir_fail(WFK_EINVAL, "null plan");
   if (p->n == 0) return WFK_OK;
+  if (src) { in_dev = out_dev; in_stride = out_stride; }     // (never read)
   if (!in_dev || !out_dev) return iir_fail(WFK_EINVAL, "null buffer");
   if (in_stride < p->n || out_stride < p->n) return iir_fail(WFK_EINVAL, "stride smaller than n");
   hipStream_t s = (hipStream_t)hip_stream;
@@ -1018,7 +1476,7 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
       const bool first = i == 0, last = i + 1 == p->parts.size();
       int rc = iir_apply_impl(q, first ? in_dev : out_dev, first ? in_stride : out_stride, out_dev,
                               out_stride, zi_dev ? p->zi_tmp : nullptr, zf_dev ? p->zf_tmp : nullptr,
-                              first ? initial : 0.0, last ? post : 0.0, hip_stream);
+                              first ? initial : 0.0, last ? post : 0.0, hip_stream, first ? src : nullptr);
       if (rc == WFK_ETIMEOUT)   // a part reported an earlier stall: no part of this plan may wait on a chain again
         for (wfk_iir_plan* r : p->parts) r->onepass = false;
       if (rc) return rc;
@@ -1037,6 +1495,7 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
     return iir_fail(WFK_ETIMEOUT, "IIR single pass: a look-back timed out in an EARLIER launch of this plan (a stalled or "
                                   "preempted predecessor chunk); its outputs hold NaN. The plan now runs in the three-launch form: launch again");
   }
+  if (src && !p->onepass) return iir_fail(WFK_EINVAL, "sampled source on a stage that is not in the single-pass form");
   if (p->onepass) {
     int spin_limit = OP_SPIN;
     if (const char* e = getenv("WFK_IIR_SPIN")) spin_limit = atoi(e);   // (tests: force the timeout)
@@ -1047,7 +1506,8 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
     // Few long rows: with one chunk per workgroup 2304 / rows chunks of a row are in flight, and a
     // look-back reads every one of them.  Below OP_DEPTH_ROWS rows the grid is op_depth persistent waves
     // per row instead (WFK_IIR_OP_DEPTH: experiments).
-    unsigned total = (unsigned)(p->op_chunks * p->batch);
+    const int64_t nchunks = src ? (p->n + OPS_CHUNK - 1) / OPS_CHUNK : p->op_chunks;   // (iir_sampled: long chunks)
+    unsigned total = (unsigned)(nchunks * p->batch);
     int persist = 0;
     {
       // from 64 rows on: about two waves per SIMD's worth of persistent waves (same box, 2 biquads, one
@@ -1060,22 +1520,29 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
         depth = depth < 4 ? 4 : (depth > 36 ? 36 : depth);
       }
       if (const char* e = getenv("WFK_IIR_OP_DEPTH")) depth = atoi(e);
-      if (depth > 0 && (int64_t)depth < p->op_chunks) {
+      if (depth > 0 && (int64_t)depth < nchunks) {
         total = (unsigned)(depth * p->batch);
         persist = 1;
       }
     }
-#define OP_LAUNCH(TT, NS, OR)                                                                                     \
-    if (p->op_plain)                                                                                          \
-    hipLaunchKernelGGL((iir_onepass<TT, NS, OR, true>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
-                       (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
-                       p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
+#define OP_LAUNCH_K(KERNEL, PL, FIRST, TABS, NCH, TT, NS, OR)                                                     \
+    if (PL)                                                                                                   \
+    hipLaunchKernelGGL((KERNEL<TT, NS, OR, true>), dim3(total), dim3(64), 0, s, p->c, FIRST,                   \
+                       (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket,              \
+                       TABS, zi_dev, zf_dev, p->n, NCH, (int)p->batch, epoch,                                     \
                        initial, post, persist, p->op_fault_dev, spin_limit);                                            \
     else                                                                                                       \
-    hipLaunchKernelGGL((iir_onepass<TT, NS, OR, false>), dim3(total), dim3(64), 0, s, p->c, (const TT*)in_dev, in_stride,   \
-                       (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket, p->op_pw1,    \
-                       p->op_lanep1, p->op_lanepU, zi_dev, zf_dev, p->n, p->op_chunks, (int)p->batch, epoch,      \
+    hipLaunchKernelGGL((KERNEL<TT, NS, OR, false>), dim3(total), dim3(64), 0, s, p->c, FIRST,                  \
+                       (TT*)out_dev, out_stride, p->op_status, p->op_agg, p->op_pref, p->op_ticket,              \
+                       TABS, zi_dev, zf_dev, p->n, NCH, (int)p->batch, epoch,                                     \
                        initial, post, persist, p->op_fault_dev, spin_limit)
+#define OP_COMMA ,
+#define OP_LAUNCH(TT, NS, OR)                                                                                     \
+    if (src) { OP_LAUNCH_K(iir_sampled, p->op_plainL, *src, p->op_pwL OP_COMMA p->op_lanepL OP_COMMA p->op_lanepUL OP_COMMA p->op_wdot, nchunks, TT, NS, OR); } \
+    else { OP_LAUNCH_K(iir_onepass, p->op_plain, (const TT*)in_dev OP_COMMA in_stride, p->op_pw1 OP_COMMA p->op_lanep1 OP_COMMA p->op_lanepU, p->op_chunks, TT, NS, OR); }
+#ifdef OPS_ONLY_22     /* A/B builds (tools/iirchain_ablate.sh): one shape, a third of the compile time */
+#define OP_SHAPES(TT)  do { OP_LAUNCH(TT, 2, 2); } while (0)
+#else
 #define OP_SHAPES(TT)                                                                              \
     do {                                                                                           \
       const int ns_ = p->c.nsec, or_ = p->c.ord[0];                                                \
@@ -1087,9 +1554,16 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
       else if (ns_ == 3) { OP_LAUNCH(TT, 3, 1); }                                                  \
       else { OP_LAUNCH(TT, 4, 1); }                                                                \
     } while (0)
+#endif
+#ifdef OPS_ONLY_22
+    OP_SHAPES(double);
+#else
     if (p->kind == WFK_OUT_F32) OP_SHAPES(float); else OP_SHAPES(double);
+#endif
 #undef OP_SHAPES
 #undef OP_LAUNCH
+#undef OP_LAUNCH_K
+#undef OP_COMMA
     if (hipGetLastError() != hipSuccess) return iir_fail(WFK_EHIP, "IIR kernel launch failed");
     return WFK_OK;
   }
@@ -1105,6 +1579,7 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
 extern "C" int wfk_iir_status(wfk_iir_plan* p, void* hip_stream) {
   if (!p) return iir_fail(WFK_EINVAL, "null plan");
   if (hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) return iir_fail(WFK_EHIP, "stream synchronisation failed");
+
   bool fault = false;
   auto look = [&](wfk_iir_plan* q) {
     if (q->op_fault && *(volatile unsigned*)q->op_fault != 0) {
@@ -1131,6 +1606,231 @@ extern "C" int wfk_iir_apply(wfk_iir_plan* p, const void* in_dev, int64_t in_str
                              double initial, void* hip_stream) {
   return iir_apply_impl(p, in_dev, in_stride, out_dev, out_stride, zi_dev, zf_dev, initial, initial,
                         hip_stream);
+}
+
+}  // extern "C"
+
+// ---- sampler -> IIR (-> FIR) chain --------------------------------------------------------------------------
+// Reference: Waveform.sample(filters=(sos, initial)) (waveforms/waveform.py:190-203,244-251) and
+// predistort(wav(t), filters, ker) (waveforms/distortion.py:298-337): sampler -> sosfilt / lfilter -> FIR.
+extern "C" void wfk_internal_plan_tables(const wfk_plan* p, const HostPlan** h, const double** d_params);
+
+struct wfk_chain_iir_plan {
+  wfk_plan* sampler = nullptr;     // the plain sampler plan: the unfused path, queries
+  wfk_iir_plan* iir = nullptr;
+  wfk_fir_plan* fir = nullptr;     // optional third stage
+  bool fused = false;
+  std::string why;                 // why the sampler does not run inside the IIR pass
+  int32_t kind = 0, n_channels = 0;
+  int64_t n = 0;
+  void* d_tables = nullptr;        // fused path: the plan compiled for the chunk geometry (a lane owns 32 consecutive samples)
+  IirSampArgs sa{};
+  int64_t table_bytes = 0;
+  void* workspace = nullptr;       // FIR stage: the filtered rows between the IIR pass and the FIR
+};
+
+static wfk_iir_plan* chain_first_stage(wfk_chain_iir_plan* p) {
+  return p->iir->parts.empty() ? p->iir : p->iir->parts[0];
+}
+
+extern "C" {
+
+int wfk_chain_iir_plan_destroy(wfk_chain_iir_plan* p) {
+  if (!p) return WFK_OK;
+  if (p->d_tables || p->workspace) (void)hipDeviceSynchronize();
+  (void)hipFree(p->d_tables);
+  (void)hipFree(p->workspace);
+  wfk_plan_destroy(p->sampler);
+  wfk_iir_plan_destroy(p->iir);
+  wfk_fir_plan_destroy(p->fir);
+  delete p;
+  return WFK_OK;
+}
+
+int wfk_chain_iir_plan_create(const wfk_program* prog, const wfk_grid* grid, int32_t n_sections,
+                              const int32_t* orders, const double* b, const double* a, const double* ker_host,
+                              int32_t K, int32_t ker_per_row, int kind, wfk_chain_iir_plan** out) {
+  if (!out) return iir_fail(WFK_EINVAL, "null out");
+  *out = nullptr;
+  if (!prog || !grid) return iir_fail(WFK_EINVAL, "null argument");
+  if (kind != WFK_OUT_F64 && kind != WFK_OUT_F32) return iir_fail(WFK_EINVAL, "chain kind must be F64 or F32");
+  if (ker_host && K < 1) return iir_fail(WFK_EINVAL, "empty FIR kernel");
+  wfk_chain_iir_plan* p = nullptr;
+  try {
+    p = new wfk_chain_iir_plan();
+    p->kind = kind;
+    p->n = grid->n;
+    p->n_channels = prog->n_channels;
+    int rc = wfk_plan_create_grid(prog, grid, &p->sampler);
+    if (!rc) rc = wfk_iir_plan_create(n_sections, orders, b, a, grid->n, std::max(1, prog->n_channels), kind, &p->iir);
+    if (!rc && ker_host)
+      rc = ker_per_row ? wfk_fir_plan_create_rows(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir)
+                       : wfk_fir_plan_create(ker_host, K, grid->n, std::max(1, prog->n_channels), kind, &p->fir);
+    if (rc) { wfk_chain_iir_plan_destroy(p); return rc; }
+    if (p->n == 0 || p->n_channels == 0) { *out = p; return WFK_OK; }
+    const size_t es = kind == WFK_OUT_F32 ? 4 : 8;
+    if (p->fir && hipMalloc(&p->workspace, (size_t)p->n_channels * (size_t)p->n * es) != hipSuccess) {
+      wfk_chain_iir_plan_destroy(p);
+      return iir_fail(WFK_ENOMEM, "chain workspace allocation failed");
+    }
+    // ---- can the sampler run inside the first IIR pass? ----------------------------------------------
+    wfk_iir_plan* first = chain_first_stage(p);
+    const char* off = getenv("WFK_CHAIN_UNFUSED");
+    HostPlan H;
+    std::string err;
+    const int par_cap = OPS_PAR;     // doubles of LDS the kernel stages a piece's parameter block in
+    if (off && off[0] == '1') p->why = "disabled by WFK_CHAIN_UNFUSED";
+    else if (!first->onepass) p->why = "the first IIR pass is not in the single-pass form (state dimension > 4, mixed orders, a short or a mid-sized batch of long rows)";
+    else if (p->n < 4 * (int64_t)OPS_CHUNK) p->why = "rows shorter than four chunks of the fused scan";
+    else if (wfk_compile_geom(prog, grid, 1, OP_LB, H, err) != WFK_OK) p->why = "geometry compile: " + err;
+    else if (!H.lean) p->why = "plan is not fully fused (generic / direct terms, closing multipliers, or too many ops per piece)";
+    else {
+      for (const DevChannel& c : H.channels)
+        if (c.do_clip) p->why = "clip (min/max) on a channel";
+      for (uint8_t cx_ : H.channel_complex)
+        if (cx_) p->why = "complex-valued channel";
+    }
+    // The kernel stages the pieces a chunk overlaps in LDS (descriptors + the blocks of the live ones) and lets every
+    // lane read the record of its own piece: the blocks must fit, a chunk may overlap <= OPS_PMAX pieces, live pieces
+    // are >= 32 samples long (a lane's 32-sample segment then meets at most two), and the live pieces of a CHUNK have
+    // the same op shapes (op count, packed op words: the usual pulse train).  Anything else stays on sampler -> IIR.
+    const int64_t nch = (p->n + OPS_CHUNK - 1) / OPS_CHUNK;
+    std::vector<int32_t> chunk_first;
+    auto same_shape = [&](const DevPiece& x, const DevPiece& y) {
+      const double* bx = H.params.data() + x.par_off;
+      const double* by = H.params.data() + y.par_off;
+      bool same = bx[1] == by[1];
+      for (int op = 0; same && op < (int)bx[1]; ++op)
+        same = std::memcmp(bx + WFK_BLK_HDR + op * WFK_FCE_REC + WFK_FCE_DEG, by + WFK_BLK_HDR + op * WFK_FCE_REC + WFK_FCE_DEG,
+                           sizeof(double)) == 0;
+      return same;
+    };
+    if (p->why.empty())
+      for (const DevPiece& pc : H.pieces) {
+        if (pc.n_blk == 0) continue;
+        if (pc.stop - pc.start < OP_LB) { p->why = "a piece shorter than 32 samples"; break; }
+        if (pc.n_blk != 1) { p->why = "a piece of several parameter blocks"; break; }
+      }
+    if (p->why.empty()) {
+      chunk_first.resize((size_t)nch * p->n_channels);
+      for (int32_t c = 0; c < p->n_channels && p->why.empty(); ++c) {
+        int32_t q = H.channels[c].piece_begin;
+        for (int64_t k = 0; k < nch; ++k) {
+          const int64_t s1 = k * OPS_CHUNK, s2 = s1 + OPS_CHUNK;
+          while (q < H.channels[c].piece_end - 1 && H.pieces[q].stop <= s1) ++q;
+          chunk_first[(size_t)c * nch + k] = q;
+          int64_t need = 0, cnt = 0;
+          int32_t first_live = -1;
+          for (int32_t j = q; j < H.channels[c].piece_end && H.pieces[j].start < s2; ++j) {
+            ++cnt;
+            if (H.pieces[j].n_blk == 0) continue;
+            need += (H.pieces[j].first_len + 1) & ~1;
+            if (first_live < 0) first_live = j;
+            else if (!same_shape(H.pieces[first_live], H.pieces[j]))
+              p->why = "pieces of different op shapes in one chunk (the fused scan reads every lane's own piece record with one op loop)";
+          }
+          if (!p->why.empty()) break;
+          if (need > par_cap) { p->why = "the parameter blocks of the pieces of one chunk do not fit its LDS buffer"; break; }
+          if (cnt > OPS_PMAX) { p->why = "more than 16 pieces in one chunk of the fused scan (8192 samples)"; break; }
+        }
+      }
+    }
+    if (p->why.empty()) {
+      auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+      const size_t b_ch = H.channels.size() * sizeof(DevChannel), b_pc = H.pieces.size() * sizeof(DevPiece),
+                   b_pa = H.params.size() * sizeof(double), b_cf = chunk_first.size() * sizeof(int32_t);
+      const size_t o_pc = al(b_ch), o_pa = al(o_pc + b_pc), o_cf = al(o_pa + b_pa), total = al(o_cf + b_cf) + 256;
+      std::vector<char> stage(total, 0);
+      std::memcpy(stage.data(), H.channels.data(), b_ch);
+      std::memcpy(stage.data() + o_pc, H.pieces.data(), b_pc);
+      std::memcpy(stage.data() + o_pa, H.params.data(), b_pa);
+      std::memcpy(stage.data() + o_cf, chunk_first.data(), b_cf);
+      if (hipMalloc(&p->d_tables, total) != hipSuccess ||
+          hipMemcpy(p->d_tables, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        wfk_chain_iir_plan_destroy(p);
+        return iir_fail(WFK_ENOMEM, "chain table allocation failed");
+      }
+      char* base = static_cast<char*>(p->d_tables);
+      IirSampArgs& sa = p->sa;
+      sa.channels = reinterpret_cast<const DevChannel*>(base);
+      sa.pieces = reinterpret_cast<const DevPiece*>(base + o_pc);
+      sa.params = reinterpret_cast<const double*>(base + o_pa);
+      sa.chunk_first = reinterpret_cast<const int32_t*>(base + o_cf);
+      sa.nchunks = nch;
+      sa.t0 = grid->t0; sa.step = grid->step; sa.last = grid->last; sa.has_last = grid->has_last;
+      sa.n = grid->n; sa.i0 = grid->i0;
+      p->table_bytes = (int64_t)total;
+      p->fused = true;
+    }
+    *out = p;
+    return WFK_OK;
+  } catch (const std::bad_alloc&) {
+    if (p) wfk_chain_iir_plan_destroy(p);
+    return iir_fail(WFK_ENOMEM, "out of host memory while building the chain plan");
+  }
+}
+
+/* 1 while the next launch evaluates the samples inside the IIR pass (a look-back timeout switches the plan to the
+ * unfused path for good) */
+int wfk_chain_iir_is_fused(const wfk_chain_iir_plan* p) {
+  return p && p->fused && chain_first_stage(const_cast<wfk_chain_iir_plan*>(p))->onepass ? 1 : 0;
+}
+
+const char* wfk_chain_iir_unfused_reason(const wfk_chain_iir_plan* p) {
+  if (!p) return "";
+  if (p->fused && !chain_first_stage(const_cast<wfk_chain_iir_plan*>(p))->onepass)
+    return "a look-back of the single pass timed out earlier: the plan runs sampler -> IIR in three launches now";
+  return p->why.c_str();
+}
+
+int wfk_chain_iir_state_dim(const wfk_chain_iir_plan* p) { return p ? wfk_iir_state_dim(p->iir) : WFK_EINVAL; }
+
+int64_t wfk_chain_iir_table_bytes(const wfk_chain_iir_plan* p) {
+  if (!p) return iir_fail(WFK_EINVAL, "null plan");
+  return p->fused ? p->table_bytes : wfk_plan_table_bytes(p->sampler);
+}
+
+const char* wfk_chain_iir_kernel_name(const wfk_chain_iir_plan* p) {
+  if (!p) return "";
+  static thread_local std::string name;
+  const char* T = p->kind == WFK_OUT_F32 ? "float" : "double";
+  if (wfk_chain_iir_is_fused(p)) {
+    const wfk_iir_plan* f = chain_first_stage(const_cast<wfk_chain_iir_plan*>(p));
+    name = std::string("iir_sampled<") + T + "," + std::to_string(f->c.nsec) + "," + std::to_string(f->c.ord[0]) + "," +
+           (f->op_plain ? "true" : "false") + ">";
+    if (!p->iir->parts.empty() && p->iir->parts.size() > 1) name += " + IIR passes";
+  } else {
+    name = std::string(wfk_plan_kernel_name(p->sampler, p->kind)) + " + IIR";
+  }
+  if (p->fir) name += " + FIR";
+  return name.c_str();
+}
+
+int wfk_chain_iir_launch(wfk_chain_iir_plan* p, void* out_dev, int64_t out_stride, const double* zi_dev,
+                         double* zf_dev, double initial, void* hip_stream) {
+  if (!p) return iir_fail(WFK_EINVAL, "null plan");
+  if (p->n == 0 || p->n_channels == 0) return WFK_OK;
+  if (!out_dev) return iir_fail(WFK_EINVAL, "null output");
+  if (out_stride < p->n) return iir_fail(WFK_EINVAL, "out_stride smaller than n");
+  void* mid = p->fir ? p->workspace : out_dev;
+  const int64_t mid_stride = p->fir ? p->n : out_stride;
+  int rc;
+  if (wfk_chain_iir_is_fused(p)) {
+    rc = iir_apply_impl(p->iir, nullptr, 0, mid, mid_stride, zi_dev, zf_dev, initial, initial, hip_stream, &p->sa);
+  } else {
+    rc = wfk_plan_launch(p->sampler, mid, mid_stride, p->kind, 0, hip_stream);
+    if (!rc) rc = iir_apply_impl(p->iir, mid, mid_stride, mid, mid_stride, zi_dev, zf_dev, initial, initial, hip_stream);
+  }
+  if (rc) return rc;
+  if (p->fir) return wfk_fir_apply(p->fir, p->workspace, p->n, out_dev, out_stride, hip_stream);
+  return WFK_OK;
+}
+
+/* as wfk_iir_status: synchronises, WFK_ETIMEOUT if a look-back of a launch since the last check timed out (outputs
+ * hold NaN); launching again then takes the three-launch form behind the plain sampler */
+int wfk_chain_iir_status(wfk_chain_iir_plan* p, void* hip_stream) {
+  if (!p) return iir_fail(WFK_EINVAL, "null plan");
+  return wfk_iir_status(p->iir, hip_stream);
 }
 
 }  // extern "C"

@@ -95,6 +95,94 @@ class SampledFir:
         self.plan.close()
 
 
+class SampledIir:
+    """`sosfilt(sos, wav(t) - initial, zi) + initial` (Waveform.sample(filters=), reference waveform.py:190-203,
+    244-251) -- or any cascade of (b, a) sections, optionally followed by the FIR of `predistort(., filters, ker)`
+    (distortion.py:298-337) -- for many channels on one uniform grid, device-resident.  When the channels are fully
+    fused and the cascade's first pass carries <= 4 state values, the wave that owns a chunk of the IIR scan evaluates
+    its input itself (`fused`, `plan.kernel_name()` == 'iir_sampled<...>'): the unfiltered samples never touch HBM.
+
+        si = SampledIir(channels, ('linspace', 0.0, 3e-6, 10**7, False), sos)        # sos (n_sections, 6) or [(b, a), ...]
+        si.launch_torch(out, initial=0.0)     # (n_channels, >= n) device tensor of the plan dtype; -> final state or None
+    """
+
+    def __init__(self, channels, grid, sections, ker=None, dtype=np.float64, function_lib=None, tile=1):
+        """`tile` > 1 repeats the channel list that many times (synthetic batches, as BatchSampler's)"""
+        from . import _flatten
+        if not isinstance(grid, _flatten.wfk_grid):
+            grid = _flatten.grid_from_desc(grid)
+        try:
+            sec = np.asarray(sections, dtype=np.float64)
+        except (ValueError, TypeError):
+            sec = None
+        if sec is not None and sec.ndim == 2 and sec.shape[1] == 6:
+            sections = [(r[:3], r[3:]) for r in sec]              # an SOS matrix (scipy.signal.sosfilt)
+        self.prog = _flatten.tile_program(_flatten.flatten(list(channels), grid, function_lib), tile)
+        self.plan = _engine.ChainIirPlan(self.prog, grid, sections, ker, dtype)
+        self.n, self.n_channels, self.dtype = self.plan.n, self.plan.n_channels, np.dtype(dtype)
+        self.state_dim = self.plan.state_dim
+        self.why_not = self.plan.why_not
+
+    @property
+    def fused(self):
+        return self.plan.fused
+
+    def launch(self, out_ptr, out_stride=None, zi_ptr=None, zf_ptr=None, initial=0.0, stream=0):
+        """-> False if the library refused the launch after an earlier look-back timeout (launch again)"""
+        return self.plan.launch(out_ptr, self.n if out_stride is None else out_stride, zi_ptr, zf_ptr, initial, stream)
+
+    def launch_torch(self, out, initial=0.0, zi=None, zf=None):
+        """zi / zf: optional (n_channels, state_dim) float64 device tensors (initial state in / final state out)"""
+        import torch
+        want = torch.float64 if self.dtype == np.float64 else torch.float32
+        if (not out.is_cuda or out.dtype != want or out.dim() != 2 or out.shape[0] != self.n_channels
+                or out.shape[1] < self.n or out.stride(1) != 1):
+            raise ValueError('out must be a (n_channels, >=n) row-contiguous device tensor of the plan dtype')
+        for z in (zi, zf):
+            if z is not None and (not z.is_cuda or z.dtype != torch.float64 or not z.is_contiguous()
+                                  or tuple(z.shape) != (self.n_channels, self.state_dim)):
+                raise ValueError('zi / zf must be contiguous (n_channels, state_dim) float64 device tensors')
+        s = torch.cuda.current_stream(out.device).cuda_stream
+        for attempt in range(2):
+            ok = self.launch(out.data_ptr(), out.stride(0), None if zi is None else zi.data_ptr(),
+                             None if zf is None else zf.data_ptr(), initial, s)
+            if ok:
+                return out
+        raise _engine.EngineError('IIR chain refused twice')
+
+    def to_host(self, initial=0.0, zi=None, return_zf=False):
+        """NumPy result (n_channels, n); a look-back timeout (outputs NaN) is retried once in the unfused form"""
+        D = max(self.state_dim, 1)
+        buf = _engine.DeviceBuffer(max(self.n_channels * self.n, 1) * self.dtype.itemsize)
+        dzi = _engine.DeviceBuffer(self.n_channels * D * 8) if zi is not None else None
+        dzf = _engine.DeviceBuffer(self.n_channels * D * 8) if return_zf else None
+        try:
+            if zi is not None:
+                z = np.broadcast_to(np.asarray(zi, dtype=np.float64).reshape(-1, self.state_dim)
+                                    if np.ndim(zi) > 1 else np.asarray(zi, dtype=np.float64),
+                                    (self.n_channels, self.state_dim))
+                dzi.upload(np.ascontiguousarray(z))
+            for attempt in range(2):
+                ok = self.launch(buf.ptr, None, None if dzi is None else dzi.ptr, None if dzf is None else dzf.ptr, initial)
+                if self.plan.status() and ok:
+                    break
+                if attempt == 1:
+                    raise _engine.EngineError('IIR chain failed twice')
+            out = buf.download((self.n_channels, self.n), self.dtype)
+            if return_zf:
+                return out, dzf.download((self.n_channels, D), np.float64)[:, :self.state_dim]
+            return out
+        finally:
+            buf.close()
+            if dzi is not None:
+                dzi.close()
+            if dzf is not None:
+                dzf.close()
+
+    def close(self):
+        self.plan.close()
+
+
 def fir_host(sig: np.ndarray, ker: np.ndarray) -> np.ndarray:
     """NumPy in, NumPy out: upload, overlap-save FIR on the device, download.  Complex signals and / or
     kernels (the reference's `fftconvolve` takes both, distortion.py:329-337) run as real convolutions of
