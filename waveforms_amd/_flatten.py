@@ -167,11 +167,63 @@ class _HostFactors:
         return np.ascontiguousarray(np.broadcast_to(v.astype(dt, copy=False), (stop - start, )))
 
 
+try:                                   # the native walk of the hot case (csrc/wfk_pyflatten.c, built by the Makefile)
+    from . import _cflatten
+except ImportError:                    # pragma: no cover  (host-side serialisation only: the Python walk below does the same)
+    _cflatten = None
+_native_argc = (None, None)            # (registry generation, {type id: argc}) of the default function library
+
+
+def _flatten_native(channels):
+    """The whole call through the C walk when every channel uses the registry's device primitives as they are;
+    None when anything needs the Python walk (callables, remapped ids, variable-arity primitives, complex powers)."""
+    global _native_argc
+    from . import waveform as _w
+    if _native_argc[0] != _w._registry_generation:
+        _native_argc = (_w._registry_generation,
+                        {tid: _SIMPLE_ARGC[tid] for tid, fn in _w._baseFunc.items()
+                         if isinstance(fn, _w.BuiltinPrimitive) and fn.type_id == tid and tid in _SIMPLE_ARGC})
+    members, ch_member_off, ch = [], [0], []
+    for w in channels:
+        if getattr(w, 'function_lib', None) is not None:
+            return None
+        mem, offset, tshift, lo, hi = channel_members(w)
+        members.extend(mem)
+        ch_member_off.append(len(members))
+        ch.append((offset, tshift, lo, hi))
+    r = _cflatten.flatten_members(members, _native_argc[1])
+    if r is None:
+        return None
+    mb, bound, pt, are, aim, tf, ft, fp, fs, fa, pool, any_complex = r
+
+    def arr(b, dt):
+        a = np.frombuffer(b, dtype=dt)
+        return a if a.size else np.zeros(1, dtype=dt)      # keep a valid pointer
+    cols = np.asarray(ch, dtype=np.float64).reshape(-1, 4)
+    arrays = dict(
+        ch_member_off=np.asarray(ch_member_off, dtype=np.int32), ch_offset=np.ascontiguousarray(cols[:, 0]) if len(ch) else np.zeros(1),
+        ch_tshift=np.ascontiguousarray(cols[:, 1]) if len(ch) else np.zeros(1),
+        ch_clip_lo=np.ascontiguousarray(cols[:, 2]) if len(ch) else np.zeros(1),
+        ch_clip_hi=np.ascontiguousarray(cols[:, 3]) if len(ch) else np.zeros(1),
+        mb_piece_off=arr(mb, np.int32), pc_bound=arr(bound, np.float64), pc_term_off=arr(pt, np.int32),
+        tm_amp_re=arr(are, np.float64), tm_amp_im=arr(aim, np.float64), tm_factor_off=arr(tf, np.int32),
+        fc_type=arr(ft, np.int32), fc_power=arr(fp, np.float64), fc_shift=arr(fs, np.float64),
+        fc_arg_off=arr(fa, np.int64), pool=arr(pool, np.float64))
+    counts = dict(n_channels=len(ch), n_members=len(members), n_pieces=len(bound) // 8, n_terms=len(are) // 8,
+                  n_factors=len(ft) // 4, n_pool=len(pool) // 8)
+    return Program(arrays, counts, bool(any_complex), False)
+
+
 def flatten(channels, axis=None, function_lib=None) -> Program:
     """channels -> wfk_program.  `axis` (a wfk_grid or the sorted time array) and
     `function_lib` matter only for primitives that are Python callables: those are evaluated
     here, on the exact sample times (see _HostFactors)."""
     from .waveform import BuiltinPrimitive, _baseFunc
+    if _cflatten is not None and function_lib is None:
+        channels = list(channels)
+        prog = _flatten_native(channels)
+        if prog is not None:
+            return prog
     ch_member_off = [0]
     ch_offset, ch_tshift, ch_lo, ch_hi = [], [], [], []
     mb_piece_off = [0]

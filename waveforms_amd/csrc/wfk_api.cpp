@@ -235,9 +235,16 @@ static int plan_create_impl(const wfk_program* prog, const wfk_grid* grid, const
   wfk_plan* p = new (std::nothrow) wfk_plan();
   if (!p) return fail(WFK_ENOMEM, "out of host memory");
   std::string err;
-  int rc;
+  int rc = WFK_RETRY_STD;
   try {
-    rc = wfk_compile(prog, grid, tlist, n, p->h, err);
+    // big grid batches (a fresh AWG sequence: thousands of rows x thousands of pulses): channel blocks on host threads
+    if (grid && prog && prog->n_channels >= 32 && prog->n_pieces >= 8192) {
+      int nt = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+      if (const char* e = std::getenv("WFK_COMPILE_THREADS")) nt = std::atoi(e);
+      nt = std::min(nt, prog->n_channels / 8);
+      if (nt > 1) rc = wfk_compile_blocks(prog, grid, nt, p->h, err);
+    }
+    if (rc == WFK_RETRY_STD) rc = wfk_compile(prog, grid, tlist, n, p->h, err);
   } catch (...) {
     delete p;
     throw;

@@ -13,7 +13,9 @@
 //
 // Compiled with -ffp-contract=off: the grid formula must round twice.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
@@ -135,6 +137,10 @@ static thread_local bool g_no_chirp = false;   // second compile of a plan that 
 static thread_local bool g_keep_mixed_short = false;   // the FIR chain's sampler plan: fir_short fuses the short pieces, the rest is copied in
 void wfk_internal_keep_mixed_short(bool on) { g_keep_mixed_short = on; }
 static thread_local int g_tlist_ns = 0;        // samples per lane of this thread's next time-list compiles (0: by size)
+// wfk_compile_blocks: this thread compiles a BLOCK of the channels of a bigger job -- the program's channel arrays are
+// views into the job's (ch_member_off does not start at 0), the job was validated once by the caller, and the
+// launch geometry (tiles per chunk) is decided on the job's channel count, so that the blocks' tables concatenate
+static thread_local int32_t g_block_total_channels = 0;
 void wfk_internal_tlist_ns(int ns) { g_tlist_ns = ns; }
 // the sample times of a grid, as NumPy forms them (this file is built -ffp-contract=off)
 void wfk_internal_grid_times(const wfk_grid* g, double* out) {
@@ -144,7 +150,42 @@ void wfk_internal_grid_times(const wfk_grid* g, double* out) {
 
 // want_short: -1 = decide from the mean live piece length (grid plans), 0 = never.  Returns
 // WFK_RETRY_STD when the short geometry was chosen but some piece cannot run in it.
-#define WFK_RETRY_STD 1
+// a vector of at most N elements on the stack (the fusion pass runs per term: heap traffic there was a third of a compile)
+template <class T, int N>
+struct SmallVec {
+  alignas(T) unsigned char raw[N * sizeof(T)];     // (no element is constructed until it is pushed)
+  int n = 0;
+  SmallVec() {}
+  SmallVec(const SmallVec& o) : n(o.n) { std::memcpy(raw, o.raw, (size_t)o.n * sizeof(T)); }
+  SmallVec& operator=(const SmallVec& o) { n = o.n; std::memcpy(raw, o.raw, (size_t)o.n * sizeof(T)); return *this; }
+  T* data() { return reinterpret_cast<T*>(raw); }
+  const T* data() const { return reinterpret_cast<const T*>(raw); }
+  bool push_back(const T& x) { if (n >= N) return false; data()[n++] = x; return true; }
+  size_t size() const { return (size_t)n; }
+  bool empty() const { return n == 0; }
+  T* begin() { return data(); }
+  T* end() { return data() + n; }
+  const T* begin() const { return data(); }
+  const T* end() const { return data() + n; }
+  T& operator[](size_t i) { return data()[i]; }
+  const T& operator[](size_t i) const { return data()[i]; }
+  void swap(SmallVec& o) { SmallVec t(*this); *this = o; o = t; }
+};
+
+// WFK_TIMING=1: where a compile spends its time, phase by phase, on stderr (tools/plan_build_bench.py)
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  PhaseTimer() : on(std::getenv("WFK_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "wfk_compile %-14s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+  ~PhaseTimer() { mark("rest"); }
+};
+
 static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
                         int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr,
                         int lane_stride = 64, int ns_override = 0, int want_short = 0);
@@ -207,6 +248,7 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
 static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double* tlist,
                         int64_t n_tlist, HostPlan& H, std::string& err, bool allow_corr,
                         int lane_stride, int ns_override, int want_short) {
+  PhaseTimer ptimer;
   if (!P || (!grid && !tlist && n_tlist != 0)) { err = "null program or time axis"; return WFK_EINVAL; }
   if (P->n_channels < 0 || P->n_members < 0) { err = "negative counts"; return WFK_EINVAL; }
   TimeAxis ax{grid, tlist, grid ? grid->n : n_tlist};
@@ -228,10 +270,23 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   bool shortm = false;          // the plan is compiled for the short tier (decided after the piece search)
   bool cur_short = false;       // ... and the piece being built uses its contiguous-lane geometry
   const int lean_par_cap = ns_override > 0 ? WFK_CHAIN_PAR : WFK_LEAN_PAR;
+  // (experiment switches, read once per compile: a getenv per piece is a scan of the environment per piece)
+  const bool env_no_sinc_tab = std::getenv("WFK_NO_SINC_TAB") != nullptr;
+  const bool env_no_moll_rec = std::getenv("WFK_NO_MOLL_REC") != nullptr;
+  const bool env_no_interp_grid = std::getenv("WFK_NO_INTERP_GRID") != nullptr;
+  const bool env_no_interp_lin = std::getenv("WFK_NO_INTERP_LIN") != nullptr;
+  const bool env_no_short_cmul = std::getenv("WFK_NO_SHORT_CMUL") != nullptr;
+  const bool env_no_short_chirp = std::getenv("WFK_NO_SHORT_CHIRP") != nullptr;
+  const bool env_no_short_multi = std::getenv("WFK_NO_SHORT_MULTI") != nullptr;
+  const bool env_no_lean_multi = std::getenv("WFK_NO_LEAN_MULTI") != nullptr;
+  const bool env_no_short_envmul = std::getenv("WFK_NO_SHORT_ENVMUL") != nullptr;
+  const bool env_no_bank = std::getenv("WFK_NO_BANK") != nullptr;
+  const char* const env_tlsmall_limit = std::getenv("WFK_TLSMALL_LIMIT");
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
   const bool nofast = nofast_env && nofast_env[0] == '1';
 
+  if (g_block_total_channels == 0) {
   // ---- validate structure ----------------------------------------------------
   auto offsets_ok = [](const auto* off, int64_t count, int64_t total) {
     if (off[0] != 0 || off[count] != total) return false;
@@ -296,6 +351,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     }
   }
 
+  }
+  ptimer.mark("validate");
   // ---- searchsorted per member ----------------------------------------------
   H.member_idx.resize(P->n_members);
   for (int32_t c = 0; c < P->n_channels; ++c)
@@ -305,6 +362,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         idx.push_back(ax.search_left(P->ch_tshift[c], P->pc_bound[p]));
     }
 
+  ptimer.mark("searchsorted");
   // ---- geometry: short tier? ---------------------------------------------------------------------
   // Mean length of the live member pieces (samples).  Below WFK_SH_MAXLEN the plan is compiled for
   // the contiguous-lane geometry: lane stride = one sample, WFK_SH_R samples per lane.
@@ -457,7 +515,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           fast = true;
         }
       } else if (type == WFK_SINC && std::isfinite(a[0]) && a[0] != 0.0 && rate_safe(3.141592653589793 * a[0], s0, s1) &&
-                 !std::getenv("WFK_NO_SINC_TAB")) {
+                 !env_no_sinc_tab) {
         // sin(pi b u) from the phasor table, the argument pi b u advanced by the very same phase step (so the two
         // stay consistent where the argument passes through zero), one reciprocal per sample instead of libm's
         // sin + a division (reference _waveform.pyx:303-305: np.sinc)
@@ -465,7 +523,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         rec[0] = WFK_M_SINC_TAB; rec[3] = a[0]; rec[4] = dphase; fast = true;
         table = table_for(B, dphase);
       } else if (type == WFK_MOLLIFIER && a[1] == 0.0 && std::isfinite(a[0]) && a[0] > 0.0 && rate_safe(4.0 / a[0], s0, s1) &&
-                 !std::getenv("WFK_NO_MOLL_REC")) {
+                 !env_no_moll_rec) {
         // exp(1 / (x^2 - 1) + 1), x = u / r (reference _waveform.pyx:359-363): the exponent is <= 0 inside the
         // support; Newton reciprocal + inline exponential instead of an IEEE division and libm's exp
         rec[0] = WFK_M_MOLL_REC; rec[3] = a[0]; rec[4] = dstride; fast = true;
@@ -508,7 +566,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             H.pool.push_back(0.0);
             // grid mode: same arithmetic, but the knot/slope loads (L2 latency) of four samples
             // are in flight together instead of one dependent load pair per sample
-            if (!H.tlist && !nofast && pw == 1.0 && m < (int64_t(1) << 31) && !std::getenv("WFK_NO_INTERP_GRID")) {
+            if (!H.tlist && !nofast && pw == 1.0 && m < (int64_t(1) << 31) && !env_no_interp_grid) {
               rec[0] = WFK_M_INTERP_GRID;
               // A finite table is a CONTINUOUS piecewise-linear function: next to a knot the two adjoining
               // segments agree to rounding, so the knot index may come straight from the O(1) guess, without
@@ -524,7 +582,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
                 finite = std::isfinite(sl);
                 smax = std::max(smax, std::fabs(sl));
               }
-              if (finite && s1 > s0 && rate_safe(4.0 * smax, s0, s1) && !std::getenv("WFK_NO_INTERP_LIN")) {
+              if (finite && s1 > s0 && rate_safe(4.0 * smax, s0, s1) && !env_no_interp_lin) {
                 rec[0] = WFK_M_INTERP_LIN;
                 interp_lin = true;
               }
@@ -628,6 +686,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   bool piece_fmul_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
   bool plan_has_bank = false;  // some piece holds a run of bare carriers (tone loop): longer chunks pay there
 
+  std::vector<FceGroup> fuse_staged;
   auto fuse_term = [&](std::vector<FceGroup>& groups, int32_t k, double tshift, int64_t s0,
                        int64_t s1, int32_t skip = -1) -> bool {   // skip: a factor handled by the caller
     // a complex amplitude a + ib contributes a * (...) to the real part and b * (...) to the
@@ -652,19 +711,20 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     double first_cos_shift = 0;
     struct Car { long double c, W, Psi, K = 0.0L; };   // c * cos(K t'^2 + W t' - Psi),  t' = t - tshift
     struct ExpV { long double c, a, b; };    // c * exp(a t' + b): EXP factors, COSH / SINH as two of them
-    std::vector<ExpV> evs = {{1.0L, 0.0L, 0.0L}};
+    SmallVec<ExpV, 8> evs;
+    evs.push_back({1.0L, 0.0L, 0.0L});
     bool has_expf = false;
     struct CosF { double w, sh, thmax; };    // reference COS factors of the term (|w|, shift, largest |phase|)
-    std::vector<CosF> cosf;
+    SmallVec<CosF, 40> cosf;
     bool has_drag = false;
     const long double PI = 3.141592653589793238462643383279502884L;
-    std::vector<Car> cars;                   // empty: no carrier factor seen yet
+    SmallVec<Car, 32> cars;                  // empty: no carrier factor seen yet
     // multiply the running carrier sum by another sum of carriers:
     //   cos a cos b = (cos(a+b) + cos(a-b)) / 2
-    auto times = [&](const std::vector<Car>& f) -> bool {
-      if (cars.empty()) { cars = f; return true; }
+    auto times = [&](std::initializer_list<Car> f) -> bool {
+      if (cars.empty()) { for (const Car& r : f) cars.push_back(r); return true; }
       if (cars.size() * f.size() * 2 > 32) return false;
-      std::vector<Car> nx;
+      SmallVec<Car, 32> nx;
       for (const Car& q : cars)
         for (const Car& r : f) {
           nx.push_back({q.c * r.c / 2, q.W + r.W, q.Psi + r.Psi, q.K + r.K});
@@ -750,7 +810,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // (e^{w u} +- e^{-w u}) / 2
           if (!expfuse || pw != 1.0 || !std::isfinite(a[0]) || !std::isfinite(sh) || evs.size() > 2) return false;
           const long double sgn = P->fc_type[f] == WFK_COSH ? 1.0L : -1.0L;
-          std::vector<ExpV> nx;
+          SmallVec<ExpV, 8> nx;
           for (const ExpV& e : evs) {
             nx.push_back({e.c / 2, e.a + a[0], e.b - (long double)a[0] * sh});
             nx.push_back({sgn * e.c / 2, e.a - a[0], e.b + (long double)a[0] * sh});
@@ -805,7 +865,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (cars.empty()) cars.push_back({1.0L, 0.0L, 0.0L});
     const double cs[1] = {first_cos_shift};
     // stage the contributions; commit only if every carrier finds/creates a group
-    std::vector<FceGroup> staged = groups;
+    std::vector<FceGroup>& staged = fuse_staged;       // (scratch kept across terms: no allocation here)
+    staged = groups;
     bool any_corr = false;
     const double tpa = ax.at(s0) - tshift, tpb = ax.at(s1 - 1) - tshift;   // the piece on the channel's own axis
     for (const Car& q : cars) {
@@ -842,7 +903,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // alone they are an envelope of their own, exp(a (t' - ref)) with the reference time in the piece
     // (state g = exp(a (x - ref)), constant ratio exp(a D): the Gaussian recurrence with q = 1).
     struct EnvV { long double amp; bool has_env, env32, has_exp; double sigma, sg; };
-    std::vector<EnvV> envs;
+    SmallVec<EnvV, 8> envs;
     for (const ExpV& e : evs) {
       EnvV v{e.c, has_env, env32, false, sigma, sg};
       if (has_expf && e.a != 0.0L) {
@@ -923,11 +984,16 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       }
       if (has_env && !env32) G->env32 = false;
       long double ca, cb;
-      if (W == 0.0 && !is_chirp) { ca = q.c * cosl(q.Psi); cb = 0.0L; }
+      if (W == 0.0 && !is_chirp) { ca = q.Psi == 0.0L ? q.c : q.c * cosl(q.Psi); cb = 0.0L; }
       else {
         const long double delta = G->psi_ref - q.Psi;   // cos(th_ref + delta)
-        ca = q.c * cosl(delta);
-        cb = -q.c * sinl(delta);
+        if (delta == 0.0L) { ca = q.c; cb = 0.0L; }     // (the term that founded the group)
+        else {
+          long double sd, cd;
+          sincosl(delta, &sd, &cd);
+          ca = q.c * cd;
+          cb = -q.c * sd;
+        }
       }
       // multiply by u_term^p with u_term = u_group + d
       long double d = 0.0L;
@@ -944,10 +1010,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         d = (long double)G->slin - slin;
       }
       static const int binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+      const long double dpow[4] = {1.0L, d, d * d, d * d * d};
       for (int m = 0; m <= p; ++m) {           // every monomial tp[m] (u_group + d)^m of the term's polynomial
         if (tp[m] == 0.0L) continue;
         for (int i = 0; i <= m; ++i) {
-          long double f = tp[m] * binom[m][i] * powl(d, m - i);
+          long double f = tp[m] * binom[m][i] * dpow[m - i];
           G->A[i] += ca * f;
           G->B[i] += cb * f;
         }
@@ -1118,7 +1185,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       //  by a multiplication, one rounding off the reference's division: 2 v^2 ulp <= 1.5e-13 relative at |v| = 26)
       if (G.has_env && !G.has_exp) rec[WFK_FCE_H] = 1.0 / G.sigma;
       double lim = 1.6e6;       // (tests: WFK_TLSMALL_LIMIT=0 sends every carrier through the two-term 1/pi reduction)
-      if (const char* e = std::getenv("WFK_TLSMALL_LIMIT")) lim = std::atof(e);
+      if (env_tlsmall_limit) lim = std::atof(env_tlsmall_limit);
       if (G.tl_thmax <= lim) rec[WFK_FCE_DEG] += (double)WFK_FCE_TLSMALL;
     }
     if (G.chirp) {
@@ -1165,7 +1232,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // 12-double record: the op adds envelope x carrier itself (word bit 7; bit 8: mollifier) instead of a carrier
     // op followed by the closing multiplier in a record of its own (a dependent load per piece)
     const bool one = groups.size() >= 2 && groups[1].fmul && groups[0].deg == 0 && !groups[0].has_env && !groups[0].has_exp &&
-                     !groups[0].erfmul && !groups[0].envmul && !groups[0].chirp && !groups[0].fmul && !std::getenv("WFK_NO_SHORT_CMUL");
+                     !groups[0].erfmul && !groups[0].envmul && !groups[0].chirp && !groups[0].fmul && !env_no_short_cmul;
     // (several envelopes in one piece: the host marked every (group, multiplier) pair -- FceGroup::fmul_own)
     auto own_pair = [&](size_t gi) { return gi + 1 < groups.size() && groups[gi + 1].fmul && (groups[gi + 1].fmul_own || (one && gi == 0)); };
     int32_t rec_len = 0;
@@ -1275,9 +1342,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         const long double u0 = G.has_lin ? x0 - (long double)G.slin : 0.0L;
         static const int binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
         long double Ar[4] = {0, 0, 0, 0}, Br[4] = {0, 0, 0, 0};
+        const long double upow[4] = {1.0L, u0, u0 * u0, u0 * u0 * u0};
         for (int m = 0; m <= 3; ++m)
           for (int i = 0; i <= m; ++i) {
-            const long double f = binom[m][i] * powl(u0, m - i);
+            const long double f = binom[m][i] * upow[m - i];
             Ar[i] += G.A[m] * f;
             Br[i] += G.B[m] * f;
           }
@@ -1322,6 +1390,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     return rec_len;
   };
 
+  ptimer.mark("setup");
   // ---- merge members into disjoint device pieces -----------------------------
   bool lean_ok = can_fuse;
   int64_t n_lean_pieces = 0, n_short_pieces = 0, n_foreign_pieces = 0, n_short_samples = 0, n_foreign_samples = 0;
@@ -1341,11 +1410,15 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     std::sort(cuts.begin(), cuts.end());
     cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
     std::vector<int32_t> cur(m1 - m0, 0);  // per member: current piece (relative)
+    // (scratch of the piece loop, kept across pieces: a 2 GS/s channel is thousands of pieces, and their heap traffic
+    //  was a third of a compile)
+    std::vector<int32_t> live, generic, order;
+    std::vector<FceGroup> groups, mgroups;
     for (size_t ci = 0; ci + 1 < cuts.size(); ++ci) {
       const int64_t s0 = cuts[ci], s1 = cuts[ci + 1];
       if (s0 < 0 || s1 > ax.n || s0 >= s1) continue;
       // collect live member pieces
-      std::vector<int32_t> live;
+      live.clear();
       for (int32_t m = m0; m < m1; ++m) {
         const auto& idx = H.member_idx[m];
         int32_t& k = cur[m - m0];
@@ -1367,7 +1440,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       for (int attempt = 0; attempt < 2 && !live.empty(); ++attempt) {
         const int32_t corr_before = H.n_corr;
         // (a short plan: in its short pieces only -- the pieces that tier hands on run on the general kernel, which has no chirp op)
-        chirp_ok = chirp_base && piece_chirp_ok && can_fuse && (!shortm || (cur_short && !g_no_short_fmul && !std::getenv("WFK_NO_SHORT_CHIRP")));
+        chirp_ok = chirp_base && piece_chirp_ok && can_fuse && (!shortm || (cur_short && !g_no_short_fmul && !env_no_short_chirp));
         D.flags |= WFK_PF_HAS_TERMS;
         BlockBuilder B;
         auto room_for = [&](size_t need) -> int {
@@ -1380,9 +1453,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           return 0;
         };
         // pass 1: fuse eligible terms into carrier-envelope groups
-        std::vector<FceGroup> groups;
-        std::vector<int32_t> generic;
-        std::vector<int32_t> order;
+        groups.clear();
+        generic.clear();
+        order.clear();
         for (int32_t p : live)
           for (int32_t k = P->pc_term_off[p]; k < P->pc_term_off[p + 1]; ++k) order.push_back(k);
         if (can_fuse && corr_enabled) {
@@ -1410,7 +1483,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // whose other factors fuse: the rest goes into a second group list, and a closing op multiplies
         // what those groups accumulated by the erf (advanced by its own Taylor step, see emit_group);
         // the unmodulated groups follow it.  One erf (sigma, shift) per piece.
-        std::vector<FceGroup> mgroups;
+        mgroups.clear();
         bool mod_on = false;
         double mod_sigma = 0, mod_shift = 0;
         int mod_kind = 0;             // 1: erf edge, 2: INTERP table, 3: mollifier (the closing multiplier of this piece)
@@ -1422,7 +1495,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // as long as each stands over one plain carrier: every such term is an own-term op, acc += F (A cos + B sin).
         struct XMod { int kind; int32_t f; std::vector<FceGroup> g; };
         std::vector<XMod> xmods;      // the envelopes after the first one
-        const bool multi_ok = !std::getenv(cur_short ? "WFK_NO_SHORT_MULTI" : "WFK_NO_LEAN_MULTI");
+        const bool multi_ok = !(cur_short ? env_no_short_multi : env_no_lean_multi);
         auto same_mod = [&](int32_t a_, int32_t b_) {
           const int64_t na = P->fc_arg_off[a_ + 1] - P->fc_arg_off[a_];
           if (P->fc_type[a_] != P->fc_type[b_] || P->fc_shift[a_] != P->fc_shift[b_] || na != P->fc_arg_off[b_ + 1] - P->fc_arg_off[b_]) return false;
@@ -1621,7 +1694,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // (From four carriers on: the extra op costs a pair of pieces what it saves them.)
         // (short pieces too: a tone costs a phasor seed and 7 instructions per sample there instead of the seeds of its own
         //  Gaussian and 13; not for the FIR chain's sampler plan, whose fir_short does not know the closing op)
-        if (groups.size() >= 4 && !mod_on && (!cur_short || (!g_no_short_fmul && !std::getenv("WFK_NO_SHORT_ENVMUL")))) {
+        if (groups.size() >= 4 && !mod_on && (!cur_short || (!g_no_short_fmul && !env_no_short_envmul))) {
           bool shared = true, e32 = true;
           for (const FceGroup& g : groups) {
             shared = shared && g.has_env && !g.has_exp && g.sigma == groups[0].sigma && g.sg == groups[0].sg;
@@ -1638,7 +1711,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         // tones): marked for the lean kernel's compact tone loop -- per tone and tile two state reads, the products
         // with the amplitude, the phasor advance; no per-op dispatch (wfk_kernels.hip: fce_bank)
         bool piece_has_bank = false;
-        if (!cur_short && !H.tlist && ns_override == 0 && !std::getenv("WFK_NO_BANK")) {
+        if (!cur_short && !H.tlist && ns_override == 0 && !env_no_bank) {
           auto bare = [](const FceGroup& g) {
             return g.W != 0.0 && !g.chirp && g.deg == 0 && !g.has_env && !g.has_exp && !g.envmul && !g.erfmul && !g.fmul && !g.corr;
           };
@@ -1776,6 +1849,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     C.piece_end = (int32_t)H.pieces.size();
   }
 
+  ptimer.mark("pieces+fusion");
   // ---- workgroup chunking ------------------------------------------------------
   // general kernel: workgroup = 4 waves, tile = 256*NS samples, chunk = tiles_per_chunk tiles
   // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
@@ -1799,7 +1873,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // lean kernel   : workgroup = 1 wave,  tile = 64*NS samples (a wave owns a contiguous span)
     tile = (lean_geom ? 64 : WFK_WG) * H.ns;
     const int64_t tiles_per_ch = (ax.n + tile - 1) / tile;
-    const int64_t total_tiles = tiles_per_ch * P->n_channels;
+    const int64_t total_tiles = tiles_per_ch * (g_block_total_channels > 0 ? g_block_total_channels : P->n_channels);
     // lean: one wave per workgroup; ~2-3k workgroups already fill 256 CUs x 12 waves.  Longer
     // chunks amortise the exact seeds, shorter ones keep the set of regions being written at
     // any moment compact, which is what the HBM write rate depends on:
@@ -1828,6 +1902,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       }
     }
   };
+  ptimer.mark("chunking");
   // ---- short tier: wave units and lane slots ------------------------------------
   if (shortm) {
     // Mostly pieces the short tier cannot take (e.g. carriers that need the lean kernel's grid-rounding
@@ -1920,6 +1995,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       if (v >= 1 && v <= 64) H.s_units_per_chunk = v;
     }
     H.chunks_per_ch = 0;
+    H.pool_real = !H.pool.empty();
     if (H.pool.empty()) H.pool.push_back(0.0);
     H.params.resize(H.params.size() + 16, 0.0);   // (the kernel reads one op record past the last real one)
     if (H.mixed) {
@@ -1949,11 +2025,120 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       H.f32_tiles_per_chunk = 0;
     }
   }
+  H.pool_real = !H.pool.empty();
   if (H.pool.empty()) H.pool.push_back(0.0);
   if (H.params.empty()) H.params.push_back(0.0);
   return WFK_OK;
 }
 
+
+// ---- big batches: channel blocks compiled on host threads ---------------------------------------
+// The compile is O(#pieces) of scalar work with long-double seeds per op (2 us per piece): a fresh AWG sequence of
+// 2048 rows x 1668 pulses is 7 s on one core.  Channels are independent (reference: one Waveform per channel,
+// waveforms/waveform.py:529-563), so the job is cut into contiguous channel blocks, every block is compiled by
+// wfk_compile on its own thread into its own HostPlan, and the plans are concatenated (indices rebased).  Taken for the
+// two bulk shapes -- pure short-tier and pure lean plans without pool tables; anything else (mixed tiers, INTERP /
+// mollifier / SAMPLED tables, blocks that chose different tiers) returns WFK_RETRY_STD and the caller compiles in one piece.
+int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads, HostPlan& H, std::string& err) {
+  if (!P || !grid || nthreads < 2 || P->n_channels < 2 * nthreads) return WFK_RETRY_STD;
+  {
+    // validate the whole program once, here (a block skips it): a grid of zero points is enough for that
+    HostPlan V;
+    wfk_grid g0 = *grid;
+    g0.n = 0; g0.has_last = 0;
+    const int rc = compile_impl(P, &g0, nullptr, 0, V, err, true);
+    if (rc != WFK_OK && rc != WFK_RETRY_STD) return rc;
+  }
+  const int K = nthreads;
+  std::vector<HostPlan> parts((size_t)K);
+  std::vector<std::string> errs((size_t)K);
+  std::vector<int> rcs((size_t)K, WFK_OK);
+  std::vector<int32_t> first((size_t)K + 1);
+  for (int k = 0; k <= K; ++k) first[k] = (int32_t)((int64_t)P->n_channels * k / K);
+  const bool t_fmul = g_no_short_fmul, t_mixed = g_keep_mixed_short, t_chirp = g_no_chirp;
+  auto work = [&](int k) {
+    g_no_short_fmul = t_fmul; g_keep_mixed_short = t_mixed; g_no_chirp = t_chirp;
+    g_block_total_channels = P->n_channels;
+    wfk_program Q = *P;
+    const int32_t a = first[k];
+    Q.n_channels = first[k + 1] - a;
+    Q.ch_member_off += a; Q.ch_offset += a; Q.ch_tshift += a; Q.ch_clip_lo += a; Q.ch_clip_hi += a;
+    try {
+      rcs[k] = wfk_compile(&Q, grid, nullptr, 0, parts[k], errs[k]);
+    } catch (...) {
+      rcs[k] = WFK_ENOMEM;
+      errs[k] = "out of host memory while compiling a channel block";
+    }
+    g_block_total_channels = 0;
+  };
+  {
+    std::vector<std::thread> th;
+    int started = 1;
+    try {
+      for (; started < K; ++started) th.emplace_back(work, started);
+    } catch (...) {
+    }
+    work(0);
+    for (auto& t : th) t.join();
+    for (int k = started; k < K; ++k) work(k);               // (threads that could not be had)
+  }
+  for (int k = 0; k < K; ++k)
+    if (rcs[k] != WFK_OK) { err = errs[k]; return rcs[k] == WFK_ENOMEM ? WFK_ENOMEM : WFK_RETRY_STD; }
+  const HostPlan& A = parts[0];
+  if (A.tlist || A.mixed || A.grid_as_tlist || !(A.shortp || A.lean)) return WFK_RETRY_STD;
+  for (const HostPlan& B : parts)
+    if (B.shortp != A.shortp || B.lean != A.lean || B.mixed || B.pool_real || B.short_gave_up || B.ns != A.ns || B.tile != A.tile ||
+        B.tiles_per_chunk != A.tiles_per_chunk || B.chunks_per_ch != A.chunks_per_ch ||
+        B.f32_tiles_per_chunk != A.f32_tiles_per_chunk || B.f32_chunks_per_ch != A.f32_chunks_per_ch ||
+        (B.n_corr > 0) != (A.n_corr > 0))
+      return WFK_RETRY_STD;
+  H = HostPlan();
+  H.tlist = false; H.n_channels = P->n_channels; H.n = A.n;
+  H.t0 = A.t0; H.step = A.step; H.last = A.last; H.has_last = A.has_last; H.i0 = A.i0;
+  H.ns = A.ns; H.tile = A.tile; H.tiles_per_chunk = A.tiles_per_chunk; H.chunks_per_ch = A.chunks_per_ch;
+  H.lean = A.lean; H.shortp = A.shortp; H.mixed = false;
+  H.f32_tiles_per_chunk = A.f32_tiles_per_chunk; H.f32_chunks_per_ch = A.f32_chunks_per_ch;
+  H.lean_tile = A.lean_tile; H.lean_tiles_per_chunk = A.lean_tiles_per_chunk; H.lean_chunks_per_ch = A.lean_chunks_per_ch;
+  H.member_idx.resize((size_t)P->n_members);
+  double len_sum = 0.0, frac_sum = 0.0;
+  for (int k = 0; k < K; ++k) {
+    HostPlan& B = parts[k];
+    if (H.params.size() & 1) H.params.push_back(0.0);
+    const int64_t po = (int64_t)H.params.size();             // even: records keep their 16-byte alignment
+    const int32_t pc = (int32_t)H.pieces.size(), so = (int32_t)H.s_slots.size();
+    for (DevChannel c : B.channels) { c.piece_begin += pc; c.piece_end += pc; H.channels.push_back(c); }
+    for (DevPiece d : B.pieces) { if (d.n_blk > 0) d.par_off += po; else d.par_off = po; H.pieces.push_back(d); }
+    H.params.insert(H.params.end(), B.params.begin(), B.params.end());
+    for (int32_t v : B.chunk_first) H.chunk_first.push_back(v + pc);
+    for (int32_t v : B.f32_chunk_first) H.f32_chunk_first.push_back(v + pc);
+    H.channel_complex.insert(H.channel_complex.end(), B.channel_complex.begin(), B.channel_complex.end());
+    for (ShortUnit u : B.s_units) { u.ch += first[k]; u.slot0 += so; u.rec0 += po / 2; H.s_units.push_back(u); }
+    H.s_slots.insert(H.s_slots.end(), B.s_slots.begin(), B.s_slots.end());
+    for (size_t m = 0; m < B.member_idx.size(); ++m)
+      if (!B.member_idx[m].empty()) H.member_idx[m] = std::move(B.member_idx[m]);
+    H.n_fast += B.n_fast; H.n_direct += B.n_direct; H.n_fused += B.n_fused; H.n_generic += B.n_generic; H.n_corr += B.n_corr;
+    H.lean_fam = std::max(H.lean_fam, B.lean_fam);
+    H.lean_par = std::max(H.lean_par, B.lean_par); H.lean_ops = std::max(H.lean_ops, B.lean_ops);
+    H.max_block_len = std::max(H.max_block_len, B.max_block_len);
+    H.s_lds_samples = std::max(H.s_lds_samples, B.s_lds_samples);
+    H.short_has_fmul = H.short_has_fmul || B.short_has_fmul;
+    H.short_needs_corr = H.short_needs_corr || B.short_needs_corr;
+    len_sum += B.mean_piece_len * (double)B.n_channels; frac_sum += B.foreign_frac * (double)B.n_channels;
+  }
+  H.mean_piece_len = len_sum / (double)P->n_channels;
+  H.foreign_frac = frac_sum / (double)P->n_channels;
+  H.pool.assign(1, 0.0);
+  if (H.shortp) {
+    const int64_t nu = (int64_t)H.s_units.size();
+    H.s_units_per_chunk = (int32_t)std::min<int64_t>(6, std::max<int64_t>(1, nu / 8192));
+    if (const char* e = std::getenv("WFK_SH_UPC")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 64) H.s_units_per_chunk = v;
+    }
+    if (H.s_slots.empty()) H.s_slots.push_back(0);
+  }
+  return WFK_OK;
+}
 
 // ---- uniform-grid detection -----------------------------------------------------------------
 // Waveform.__call__(x) takes any sorted array (reference waveform.py:529-563), but scripts

@@ -294,6 +294,7 @@ struct HostPlan {
   bool grid_as_tlist = false;      // ... and the plan was therefore compiled on the grid's sample times as a time list (wfk_api.cpp)
   bool short_has_fmul = false;     // some short piece holds an op wfk_sample_short evaluates and fir_short does not (table / mollifier multipliers, chirps)
   bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
+  bool pool_real = false;          // `pool` holds tables the parameter blocks point into (INTERP / mollifier / SAMPLED)
   std::vector<ShortUnit> s_units;
   std::vector<uint32_t> s_slots;
   int32_t s_lds_samples = 0, s_units_per_chunk = 1;
@@ -306,6 +307,10 @@ int wfk_compile(const wfk_program* prog, const wfk_grid* grid, const double* tli
 
 int wfk_compile_geom(const wfk_program* prog, const wfk_grid* grid, int lane_stride, int ns,
                      HostPlan& out, std::string& err);
+#define WFK_RETRY_STD 1      // (not an error: compile again another way)
+// big batches: contiguous channel blocks compiled on `nthreads` host threads, plans concatenated; WFK_RETRY_STD when
+// the plan is not of a shape this takes (compile it in one piece then)
+int wfk_compile_blocks(const wfk_program* prog, const wfk_grid* grid, int nthreads, HostPlan& out, std::string& err);
 
 // Sampler fused into the FIR transform at AWG rates (fir_short, wfk_fir_sampled.hip): the pieces of a pure
 // short plan cut into per-half-window entry lists.  Window pair `pr` of a row starts at sample
