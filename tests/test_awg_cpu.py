@@ -81,7 +81,7 @@ def test_long_pieces_keep_the_lean_tier_and_env_overrides():
     # a linear chirp is an op of the short tier too (quadratic-phase recurrence) ...
     w = wl.awg_channel(wf, 0, 20000, 2e9) + (wf.chirp(1e8, 2e8, 30e-9) >> 5e-6)
     p3 = _engine.Plan(_flatten.flatten([w]), grid=g2)
-    assert p3.kernel_name() == 'wfk_sample_short<double,false,false,16>' and p3.info.n_generic == 0
+    assert p3.kernel_name() == 'wfk_sample_short<double,false,false,16,1>' and p3.info.n_generic == 0
     # ... pieces the tier cannot take (an exponential chirp: device libm) go to the general kernel in a second launch;
     # the rest of the plan keeps the short tier
     w = wl.awg_channel(wf, 0, 20000, 2e9) + (wf.chirp(1e8, 2e8, 30e-9, type='exponential') >> 5e-6)

@@ -193,7 +193,7 @@ def test_flat_top_pulses_with_erf_edges_stay_in_the_short_tier():
         g = _flatten.grid_arange(0.0, 3.4e-6, 1 / rate)
         prog = _flatten.flatten([w])
         plan = _engine.Plan(prog, grid=g)
-        assert plan.kernel_name() == 'wfk_sample_short<double,false,false,16>', plan.kernel_name()
+        assert plan.kernel_name() == 'wfk_sample_short<double,false,false,16,1>', plan.kernel_name()
         assert plan.info.n_direct == 0 and plan.info.n_generic == 0
         ora = c_oracle.eval_grid(prog, g)[0]
         got = plan.run_host(np.float64)[0]
@@ -304,7 +304,7 @@ def test_linear_chirps_at_awg_rates_run_on_the_short_tier(monkeypatch):
     prog = _flatten.flatten(chans)
     g = _flatten.grid_from_desc(grid)
     plan = _engine.Plan(prog, grid=g)
-    assert plan.kernel_name(np.complex128) == 'wfk_sample_short<double,true,false,16>' and plan.info.n_generic == 0
+    assert plan.kernel_name(np.complex128) == 'wfk_sample_short<double,true,false,16,1>' and plan.info.n_generic == 0
     ref = c_oracle.eval_grid(prog, g, True)
     pk = float(np.abs(ref).max())
     got = plan.run_host(np.complex128)
@@ -313,5 +313,5 @@ def test_linear_chirps_at_awg_rates_run_on_the_short_tier(monkeypatch):
     assert np.max(np.abs(plan.run_host(np.complex64) - ref)) <= FP32_TOL * pk
     monkeypatch.setenv('WFK_NO_SHORT_CHIRP', '1')
     off = _engine.Plan(prog, grid=g)
-    assert not off.kernel_name(np.complex128).startswith('wfk_sample_short<double,true,false,16>') or ' + ' in off.kernel_name(np.complex128)
+    assert not off.kernel_name(np.complex128).startswith('wfk_sample_short<double,true,false,16,1>') or ' + ' in off.kernel_name(np.complex128)
     assert np.max(np.abs(off.run_host(np.complex128) - ref)) <= 1e-9 * pk

@@ -151,7 +151,7 @@ AWG_TOL = 5e-11        # of peak, as tests/test_gpu_awg.py: grid jitter x carrie
 def test_optimised_pulses_at_awg_rates_run_on_the_short_tier():
     chans = [wl.awg_interp_channel(wf, c) for c in range(3)]
     got, name, info = run(chans, AWG)
-    assert name == 'wfk_sample_short<double,false,false,16>' and info.n_generic == 0 and info.n_fused > 0, name
+    assert name == 'wfk_sample_short<double,false,false,16,2>' and info.n_generic == 0 and info.n_fused > 0, name
     ref = oracle(chans, AWG)
     assert np.max(np.abs(got - ref)) <= AWG_TOL * np.abs(ref).max()
     # one copy per distinct table: 3 channels x 8 shapes x 302 entries of 16 B (+ the op records), not one per pulse
@@ -161,7 +161,7 @@ def test_optimised_pulses_at_awg_rates_run_on_the_short_tier():
     assert name_off.startswith('wfk_sample<') and info_off.n_generic > 0
     assert np.max(np.abs(off - ref)) <= AWG_TOL * np.abs(ref).max()
     f32, name32, _ = run(chans, AWG, np.float32)
-    assert name32 == 'wfk_sample_short<float,false,false,16>'
+    assert name32 == 'wfk_sample_short<float,false,false,16,2>'
     assert np.max(np.abs(f32 - ref)) <= FP32_TOL * np.abs(ref).max()
 
 
@@ -225,7 +225,7 @@ def test_overlapping_envelopes_in_short_pieces():
              own[2] + 0.05 * own[0] + (wf.gaussian(20e-9) * wf.cos(1e9) >> 5.01e-6)]
     grid = wl.awg_grid(40_000, 2e9)
     got, name, info = run(chans, grid)
-    assert name == 'wfk_sample_short<double,false,false,16>' and info.n_generic == 0, (name, info.n_generic)
+    assert name == 'wfk_sample_short<double,false,false,16,2>' and info.n_generic == 0, (name, info.n_generic)
     ref = oracle(chans, grid)
     assert np.max(np.abs(got - ref)) <= AWG_TOL * np.abs(ref).max()
     off, name_off, info_off = run(chans, grid, env={'WFK_NO_SHORT_MULTI': '1'})

@@ -1273,6 +1273,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             o[6] = (double)((long double)grid->step / (long double)fa[0]);
           }
           H.short_has_fmul = true;
+          H.short_fam = std::max(H.short_fam, 2);
           o += WFK_SH_OP3;
           continue;
         }
@@ -1286,6 +1287,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           o[6] = (double)Hh;
           o[7] = (double)expl(-2.0L * Hh * Hh);
           H.short_has_fmul = true;      // (an op fir_short does not evaluate)
+          H.short_fam = std::max(H.short_fam, 1);
           o += WFK_SH_OP1;
           continue;
         }
@@ -1296,6 +1298,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           o[5] = (double)((x0 - (long double)G.sg) / G.sigma);
           o[6] = (double)((long double)grid->step / G.sigma);
           o[8] = G.m0; o[9] = G.m1;
+          H.short_fam = std::max(H.short_fam, 1);
           o += WFK_SH_OP1;
           continue;
         }
@@ -1318,6 +1321,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           o[3] = (double)cosl(2 * d2);
           o[4] = (double)sinl(2 * d2);
           H.short_has_fmul = true;      // (an op fir_short does not evaluate: the chain's sampler plan keeps such pieces off the short tier)
+          H.short_fam = std::max(H.short_fam, 1);
         } else if (G.W != 0.0) {
           const long double th0 = (long double)G.W * x0 - G.psi_ref;
           o[1] = (double)remainderl(th0 / PIl, 2.0L);
@@ -1374,6 +1378,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             o[6] = (double)((long double)grid->step / (long double)fa[0]);
           }
           H.short_has_fmul = true;
+          H.short_fam = std::max(H.short_fam, 2);
           o += WFK_SH_OP1;
           continue;
         }
@@ -2122,6 +2127,7 @@ int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads,
     H.max_block_len = std::max(H.max_block_len, B.max_block_len);
     H.s_lds_samples = std::max(H.s_lds_samples, B.s_lds_samples);
     H.short_has_fmul = H.short_has_fmul || B.short_has_fmul;
+    H.short_fam = std::max(H.short_fam, B.short_fam);
     H.short_needs_corr = H.short_needs_corr || B.short_needs_corr;
     len_sum += B.mean_piece_len * (double)B.n_channels; frac_sum += B.foreign_frac * (double)B.n_channels;
   }

@@ -215,7 +215,7 @@ struct SArgs {                // short-tier launch (wfk_short.hip)
   int32_t units_per_chunk;
   int32_t accumulate;
   int32_t lds_samples;        // largest n_samples of a unit with slots
-  int32_t pad;
+  int32_t fam;                // op family (HostPlan::short_fam): the smallest instantiation that holds the plan's ops
   double step;
   const double* pool;         // INTERP tables of the closing multipliers ((value, difference) pairs)
 };
@@ -293,6 +293,8 @@ struct HostPlan {
   bool short_gave_up = false;      // grid plan: the pieces are of AWG-rate length but the short tier could not take most of them
   bool grid_as_tlist = false;      // ... and the plan was therefore compiled on the grid's sample times as a time list (wfk_api.cpp)
   bool short_has_fmul = false;     // some short piece holds an op wfk_sample_short evaluates and fir_short does not (table / mollifier multipliers, chirps)
+  int32_t short_fam = 0;           // instantiation of wfk_sample_short the plan needs: 0 carrier-envelope ops only, 1 + erf edges, chirps and
+                                   // shared Gaussians, 2 + table / mollifier envelopes (closing multipliers, own-term ops)
   bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
   bool pool_real = false;          // `pool` holds tables the parameter blocks point into (INTERP / mollifier / SAMPLED)
   std::vector<ShortUnit> s_units;

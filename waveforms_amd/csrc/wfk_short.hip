@@ -137,7 +137,12 @@ constexpr int kStage = 68 * 16 + 16;
 //     sees to that): with a variable row loop the compiler cannot count the stores behind a load and
 //     falls back to vmcnt(0) at the loop's back edge -- every wave then idles until its own stores
 //     have been acknowledged (measured: 6 us per unit).
-template <typename T, bool CPLX, bool ACC, int R>
+// FAM: the op family the plan needs (HostPlan::short_fam) -- 0: carrier-envelope ops and nothing else (the plain pulse train:
+// the body of round 3); 1: + the closing ops of flat-top edges (erf) and multi-tone pieces (shared Gaussian), linear chirps,
+// envelope seeds skipped where no lane has an envelope; 2: + table / mollifier envelopes (closing multipliers, own-term ops).  Separate instantiations, so that a shape added to one family cannot move the code generation of the others (the
+// chirp / cmul / shared-envelope ops of round 4, inlined into the one body, cost the plain pulse train 23 % more VALU
+// instructions and 113-120 spilled SGPRs).
+template <typename T, bool CPLX, bool ACC, int R, int FAM>
 __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(const SArgs a) {
   using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
   __shared__ __attribute__((aligned(16))) E s_out[kStage];
@@ -215,32 +220,41 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         const int w = op_word(rc);
         const bool closing = ((w >> 4) & 3) == 3;       // closing multiplier (erf edge, table, mollifier)
         const bool mine = lv && !closing && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
-        const bool chirp = (w & 512) != 0;              // quadratic phase (16-double record, polynomials of degree <= 1)
+        const bool chirp = FAM >= 1 && (w & 512) != 0;  // quadratic phase (16-double record, polynomials of degree <= 1)
         const bool cubic = __any(mine && !chirp && (w & 3) > 1);
-        if (__any(mine && chirp)) {
-          if (mine && chirp) short_chirp<R, CPLX>(rc, opp, w, kf, a.step, acc, acci);
+        if constexpr (FAM >= 1) {
+          if (__any(mine && chirp)) {
+            if (mine && chirp) short_chirp<R, CPLX>(rc, opp, w, kf, a.step, acc, acci);
+          }
         }
         if (mine && !chirp) {
-          if (cubic) short_op<R, true, CPLX, true>(rc, opp, w, kf, a.step, acc, acci);
-          else short_op<R, false, CPLX, true>(rc, opp, w, kf, a.step, acc, acci);
+          if (cubic) short_op<R, true, CPLX, (FAM >= 1)>(rc, opp, w, kf, a.step, acc, acci);
+          else short_op<R, false, CPLX, (FAM >= 1)>(rc, opp, w, kf, a.step, acc, acci);
         }
+        if constexpr (FAM >= 1)
         if (__any(lv && closing)) {
-          const bool own = (w & 128) != 0;      // envelope x carrier in one op: adds its own term
-          if (__any(lv && closing && own)) {
-            if (lv && closing && own && (CPLX || !(w & 8))) short_cmul<R, CPLX>(rc, a.pool, w, kf, acc, acci);
+          const bool own = FAM >= 2 && (w & 128) != 0;      // envelope x carrier in one op: adds its own term
+          if constexpr (FAM >= 2) {
+            if (__any(lv && closing && own)) {
+              if (lv && closing && own && (CPLX || !(w & 8))) short_cmul<R, CPLX>(rc, a.pool, w, kf, acc, acci);
+            }
           }
           const int kind = own ? -1 : (w & 3);      // 0: erf edge; 1: shared Gaussian; 2: INTERP table, 3: mollifier (stateless multipliers)
-          if (__any(lv && closing && kind == 1)) {
-            if (lv && closing && kind == 1) short_envmul<R, CPLX>(rc, kf, acc, acci);
+          if constexpr (FAM >= 1) {
+            if (__any(lv && closing && kind == 1)) {
+              if (lv && closing && kind == 1) short_envmul<R, CPLX>(rc, kf, acc, acci);
+            }
           }
           if (__any(lv && closing && kind == 0)) {
             if (lv && closing && kind == 0) short_erfmul_run<R, CPLX>(rc, kf, seg.len, acc, acci);
           }
-          if (__any(lv && closing && kind == 2)) {
-            if (lv && closing && kind == 2) short_tabmul<R, CPLX>(rc, a.pool, kf, acc, acci);
-          }
-          if (__any(lv && closing && kind == 3)) {
-            if (lv && closing && kind == 3) short_mollmul<R, CPLX>(rc, kf, acc, acci);
+          if constexpr (FAM >= 2) {
+            if (__any(lv && closing && kind == 2)) {
+              if (lv && closing && kind == 2) short_tabmul<R, CPLX>(rc, a.pool, kf, acc, acci);
+            }
+            if (__any(lv && closing && kind == 3)) {
+              if (lv && closing && kind == 3) short_mollmul<R, CPLX>(rc, kf, acc, acci);
+            }
           }
         }
         return lv && !(w & WFK_SH_LAST);
@@ -339,10 +353,13 @@ int launch_short(const SArgs& a, hipStream_t s) {
   if (blocks == 0) return 0;
   if (blocks > 0x7fffffffLL) return -2;
   if (a.lds_samples > WFK_SH_LCAP) return -3;
-  if (a.accumulate)
-    hipLaunchKernelGGL((wfk_sample_short<T, CPLX, true, WFK_SH_R>), dim3((unsigned)blocks), dim3(64), 0, s, a);
-  else
-    hipLaunchKernelGGL((wfk_sample_short<T, CPLX, false, WFK_SH_R>), dim3((unsigned)blocks), dim3(64), 0, s, a);
+#define SH_LAUNCH(ACCV, FAMV) hipLaunchKernelGGL((wfk_sample_short<T, CPLX, ACCV, WFK_SH_R, FAMV>), dim3((unsigned)blocks), dim3(64), 0, s, a)
+  if (a.accumulate) {
+    if (a.fam <= 0) SH_LAUNCH(true, 0); else if (a.fam == 1) SH_LAUNCH(true, 1); else SH_LAUNCH(true, 2);
+  } else {
+    if (a.fam <= 0) SH_LAUNCH(false, 0); else if (a.fam == 1) SH_LAUNCH(false, 1); else SH_LAUNCH(false, 2);
+  }
+#undef SH_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
