@@ -394,7 +394,8 @@ const char* wfk_plan_kernel_name(const wfk_plan* p, int out_kind) {
     return f32 && (tl || g || d) ? "wfk_sample_wide<" + tail : std::string("wfk_sample<") + T + "," + tail;
   };
   if (h.shortp) {
-    name = std::string("wfk_sample_short<") + T + "," + cplx + ",false," + std::to_string(WFK_SH_R) + "," + std::to_string(h.short_fam) + ">";
+    name = std::string("wfk_sample_short<") + T + "," + cplx + ",false," + std::to_string(WFK_SH_R) + "," +
+           std::to_string(h.short_fam == 0 && out_kind == WFK_OUT_F32 && !(std::getenv("WFK_SH_NO_PK") && std::getenv("WFK_SH_NO_PK")[0] == '1') ? 3 : h.short_fam) + ">";
     if (h.mixed)      // pieces the short tier cannot take: a second launch of the general kernel
       name += " + " + general(false, h.n_direct > 0 || h.n_generic > 0, h.n_direct > 0, h.ns);
     return name.c_str();
@@ -447,6 +448,7 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
     sa.accumulate = (flags & WFK_ACCUMULATE) ? 1 : 0;
     sa.lds_samples = p->h.s_lds_samples;
     sa.fam = p->h.short_fam;
+    { const char* e = std::getenv("WFK_SH_NO_PK"); sa.pk = (e && e[0] == '1') ? 0 : 1; }
     sa.step = p->h.step;
     sa.pool = p->d_pool;
     if (s_lo && nparts > 1) {

@@ -218,6 +218,7 @@ struct SArgs {                // short-tier launch (wfk_short.hip)
   int32_t fam;                // op family (HostPlan::short_fam): the smallest instantiation that holds the plan's ops
   double step;
   const double* pool;         // INTERP tables of the closing multipliers ((value, difference) pairs)
+  int32_t pk, pad2;           // real float launches of family 0: the packed-fp32 build (WFK_SH_NO_PK=1: the double-arithmetic one)
 };
 
 struct KArgs {

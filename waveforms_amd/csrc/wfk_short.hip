@@ -145,6 +145,9 @@ constexpr int kStage = 68 * 16 + 16;
 template <typename T, bool CPLX, bool ACC, int R, int FAM>
 __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(const SArgs a) {
   using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
+  // float launches of the plain pulse train (family 3 = family 0 in packed fp32 arithmetic, wfk_short_dev.h: short_op_pk)
+  constexpr bool PK = FAM == 3;
+  static_assert(!PK || (std::is_same<T, float>::value && !CPLX), "packed arithmetic: real float launches only");
   __shared__ __attribute__((aligned(16))) E s_out[kStage];
   const int lane = threadIdx.x;
   // XCD-aware chunk map (workgroup b runs on XCD b % 8): XCD x walks the x-th contiguous eighth
@@ -199,9 +202,11 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
     const int rs = sw ? 68 : 64;
     const int s0 = sw ? l0 + (l0 >> 4) : l0;    // (arithmetic shift: exact for the negative l0 of row 0 too)
 
-    double acc[R], acci[CPLX ? R : 1];
-    SH_EACH(R, k) acc[k] = 0.0; SH_END
+    double acc[PK ? 1 : R], acci[CPLX ? R : 1];
+    f32x2 accp[PK ? R / 2 : 1];
+    SH_EACH(PK ? 1 : R, k) acc[k] = 0.0; SH_END
     SH_EACH(CPLX ? R : 1, k) acci[k] = 0.0; SH_END
+    SH_EACH(PK ? R / 2 : 1, k) accp[k] = 0.0f; SH_END
 
     if (cur.nslots != 0) {
       const double kf = (double)(seg.j - op_ref(first));   // samples from the record's reference sample
@@ -220,18 +225,28 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         const int w = op_word(rc);
         const bool closing = ((w >> 4) & 3) == 3;       // closing multiplier (erf edge, table, mollifier)
         const bool mine = lv && !closing && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
-        const bool chirp = FAM >= 1 && (w & 512) != 0;  // quadratic phase (16-double record, polynomials of degree <= 1)
+        const bool chirp = FAM >= 1 && FAM <= 2 && (w & 512) != 0;  // quadratic phase (16-double record, polynomials of degree <= 1)
         const bool cubic = __any(mine && !chirp && (w & 3) > 1);
-        if constexpr (FAM >= 1) {
+        if constexpr (PK) {
+          if (mine) {
+            if (cubic) short_op_pk<R, true>(rc, opp, w, kf, a.step, accp);
+            else short_op_pk<R, false>(rc, opp, w, kf, a.step, accp);
+          }
+          return lv && !(w & WFK_SH_LAST);
+        } else {
+        if constexpr (FAM >= 1 && FAM <= 2) {
           if (__any(mine && chirp)) {
             if (mine && chirp) short_chirp<R, CPLX>(rc, opp, w, kf, a.step, acc, acci);
           }
         }
         if (mine && !chirp) {
-          if (cubic) short_op<R, true, CPLX, (FAM >= 1)>(rc, opp, w, kf, a.step, acc, acci);
-          else short_op<R, false, CPLX, (FAM >= 1)>(rc, opp, w, kf, a.step, acc, acci);
+#ifndef WFK_SH_SKIP0
+#define WFK_SH_SKIP0 0
+#endif
+          if (cubic) short_op<R, true, CPLX, (FAM >= 1 || WFK_SH_SKIP0)>(rc, opp, w, kf, a.step, acc, acci);
+          else short_op<R, false, CPLX, (FAM >= 1 || WFK_SH_SKIP0)>(rc, opp, w, kf, a.step, acc, acci);
         }
-        if constexpr (FAM >= 1)
+        if constexpr (FAM >= 1 && FAM <= 2)
         if (__any(lv && closing)) {
           const bool own = FAM >= 2 && (w & 128) != 0;      // envelope x carrier in one op: adds its own term
           if constexpr (FAM >= 2) {
@@ -258,6 +273,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
           }
         }
         return lv && !(w & WFK_SH_LAST);
+        }
       };
       live = eval(rec, op, live);
       while (__any(live)) {
@@ -288,6 +304,15 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
             if (acc[k] < cur.clip_lo || (acc[k] == cur.clip_lo && acci[k] < 0.0)) { acc[k] = cur.clip_lo; acci[k] = 0.0; }
             if (acc[k] > cur.clip_hi || (acc[k] == cur.clip_hi && acci[k] > 0.0)) { acc[k] = cur.clip_hi; acci[k] = 0.0; }
           SH_END
+        } else if constexpr (PK) {
+          // (the double path clips the fp64 sum and rounds once; here the float sum is clipped against the bounds --
+          //  np.clip semantics, NaN propagates)
+          SH_EACH(R, k)
+            float v = accp[k / 2][k % 2];
+            v = v < (float)cur.clip_lo ? (float)cur.clip_lo : v;
+            v = v > (float)cur.clip_hi ? (float)cur.clip_hi : v;
+            accp[k / 2][k % 2] = v;
+          SH_END
         } else {
           SH_EACH(R, k) acc[k] = clip_np(acc[k], cur.clip_lo, cur.clip_hi); SH_END
         }
@@ -300,7 +325,9 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         SH_EACH(R, k)
           if (k < len) {                      // (a masked LDS write needs no wait: the branch is cheap)
             E* const at = (k >= t ? b0 + 1 : b0) + k;
-            const double v = acc[k] + cur.offset;
+            double v;
+            if constexpr (PK) v = (double)(accp[k / 2][k % 2] + (float)cur.offset);
+            else v = acc[k] + cur.offset;
             if constexpr (CPLX) {
               E e;
               e.x = (T)v;
@@ -354,10 +381,14 @@ int launch_short(const SArgs& a, hipStream_t s) {
   if (blocks > 0x7fffffffLL) return -2;
   if (a.lds_samples > WFK_SH_LCAP) return -3;
 #define SH_LAUNCH(ACCV, FAMV) hipLaunchKernelGGL((wfk_sample_short<T, CPLX, ACCV, WFK_SH_R, FAMV>), dim3((unsigned)blocks), dim3(64), 0, s, a)
+  // (real float launches of family 0 run its packed-fp32 build, "family 3")
+  constexpr bool kPk = std::is_same<T, float>::value && !CPLX;
   if (a.accumulate) {
-    if (a.fam <= 0) SH_LAUNCH(true, 0); else if (a.fam == 1) SH_LAUNCH(true, 1); else SH_LAUNCH(true, 2);
+    if (a.fam <= 0) { if constexpr (kPk) { if (a.pk) SH_LAUNCH(true, 3); else SH_LAUNCH(true, 0); } else SH_LAUNCH(true, 0); }
+    else if (a.fam == 1) SH_LAUNCH(true, 1); else SH_LAUNCH(true, 2);
   } else {
-    if (a.fam <= 0) SH_LAUNCH(false, 0); else if (a.fam == 1) SH_LAUNCH(false, 1); else SH_LAUNCH(false, 2);
+    if (a.fam <= 0) { if constexpr (kPk) { if (a.pk) SH_LAUNCH(false, 3); else SH_LAUNCH(false, 0); } else SH_LAUNCH(false, 0); }
+    else if (a.fam == 1) SH_LAUNCH(false, 1); else SH_LAUNCH(false, 2);
   }
 #undef SH_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -408,4 +408,99 @@ __device__ __forceinline__ void short_erfmul_run(const OpRec& o, double kf, int 
   SH_END
 }
 
+// ---- float launches of the plain pulse train: packed fp32 arithmetic ------------------------------------------------
+// Unpacked fp32 issues at the fp64 rate on this part, so the float launch of the short tier was issue-bound on the same
+// ~37 fp64 instructions per sample as the double launch (0.31-0.35 of the 4 B/sample roof).  v_pk_fma_f32 / v_pk_mul_f32
+// work on two floats per lane and instruction: a lane's run is evaluated as PAIRS of neighbouring samples (k, k + 1),
+// the recurrences stepping by two samples -- rotation by (C2, S2) = (C1^2 - S1^2, 2 C1 S1), Gaussian pair
+// g <- g R, R <- R q^4 with R_k = r_k r_(k+1) -- and the seeds (one sincospi, two exponentials per op and lane) are
+// float too: the phase is reduced in fp64 (kf W dt + th0 to half-turns in [-1/2, 1/2]), the rest is a degree-9 / 8
+// float polynomial and v_exp_f32.  Error budget: seeds 2e-7, eight recurrence steps 1e-6 -- against the 1e-3 contract of
+// float outputs (tests: FP32_TOL = 5e-5 of peak).  6.5 packed instructions per op and sample instead of 14.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void sincospi_f32(float r, float* sn, float* cs) {   // |r| <= 1/2
+  const float a = fabsf(r);
+  const bool swap = a > 0.25f;
+  const float z = swap ? 0.5f - a : a;                      // exact
+  const float t = z * 3.14159265358979f;
+  const float t2 = t * t;
+  float ps = 2.7557319e-06f;                                //  1/9!
+  ps = fmaf(ps, t2, -1.9841270e-04f);
+  ps = fmaf(ps, t2, 8.3333333e-03f);
+  ps = fmaf(ps, t2, -1.6666667e-01f);
+  const float s = fmaf(t * t2, ps, t);
+  float pc = 2.4801587e-05f;                                //  1/8!
+  pc = fmaf(pc, t2, -1.3888889e-03f);
+  pc = fmaf(pc, t2, 4.1666667e-02f);
+  pc = fmaf(pc, t2, -0.5f);
+  const float c = fmaf(t2, pc, 1.0f);
+  const float ss = swap ? c : s, cc = swap ? s : c;
+  *sn = r < 0.0f ? -ss : ss;
+  *cs = cc;
+}
+
+template <int R, bool CUBIC>
+__device__ __forceinline__ void short_op_pk(const OpRec& o, const double* op, int w, double kf, double step,
+                                            f32x2 (&acc)[R / 2]) {
+  static_assert(R % 2 == 0, "pairs of samples");
+  const int env = (w >> 4) & 3;
+  const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.x, q = o.d.y;
+  const f32x2 A0 = (float)o.e.x, A1 = (float)o.e.y, B0 = (float)o.f.x, B1 = (float)o.f.y;
+  f32x2 A2 = 0.0f, A3 = 0.0f, B2 = 0.0f, B3 = 0.0f;
+  if constexpr (CUBIC) {
+    if ((w & 3) > 1) { A2 = (float)op[12]; A3 = (float)op[13]; B2 = (float)op[14]; B3 = (float)op[15]; }
+  }
+  // seeds at the lane's first sample (phase reduced in fp64) and at the one behind it
+  f32x2 c, s;
+  {
+    const double x = fma(kf, o.b.x, o.a.y);       // phase / pi
+    const double n = rint(x);
+    float s0, c0;
+    sincospi_f32((float)(x - n), &s0, &c0);
+    if (((int)n) & 1) { c0 = -c0; s0 = -s0; }
+    const float c1 = (float)C1, s1 = (float)S1;
+    c = f32x2{c0, c0 * c1 - s0 * s1};
+    s = f32x2{s0, s0 * c1 + c0 * s1};
+  }
+  const f32x2 C2 = (float)(C1 * C1 - S1 * S1), S2 = (float)(2.0 * C1 * S1);
+  f32x2 g = 1.0f, rr = 1.0f;
+  f32x2 q4 = 1.0f;
+  if (env != 0) {
+    const double vv = fma(kf, Hh, o.c.y);
+    const double ea = env == 1 ? -(vv * vv) : vv;
+    const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : Hh;
+    const float g0 = __builtin_amdgcn_exp2f((float)(ea * 1.4426950408889634));
+    const float r0 = __builtin_amdgcn_exp2f((float)(eb * 1.4426950408889634));
+    const float qf = (float)q, r1 = r0 * qf;
+    g = f32x2{g0, g0 * r0};
+    rr = f32x2{r0 * r0 * qf, r1 * r1 * qf};
+    const float q2 = qf * qf;
+    q4 = q2 * q2;
+  }
+  const float u0 = (float)(kf * step), dt = (float)step;
+  f32x2 u = f32x2{u0, u0 + dt};
+  const f32x2 du = 2.0f * dt;
+  SH_EACH(R / 2, k)
+    f32x2 pa, pb;
+    if constexpr (CUBIC) {
+      pa = ((A3 * u + A2) * u + A1) * u + A0;
+      pb = ((B3 * u + B2) * u + B1) * u + B0;
+    } else {
+      pa = A1 * u + A0;
+      pb = B1 * u + B0;
+    }
+    const f32x2 val = pa * c + pb * s;
+    acc[k] = val * g + acc[k];
+    if constexpr (k + 1 < R / 2) {
+      g = g * rr;
+      rr = rr * q4;
+      const f32x2 cn = c * C2 - s * S2;
+      s = s * C2 + c * S2;
+      c = cn;
+      u = u + du;
+    }
+  SH_END
+}
+
 }  // namespace shdev
