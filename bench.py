@@ -710,6 +710,14 @@ def run_rank(args):
             also['c4']['roofline_valu'] = rv
         chn.close()
         fst.close()
+        if dtype == np.float64:      # the same chain into a float buffer (4 B/sample)
+            chn32 = SampledFir([make_channel(c) for c in range(sh.start, sh.stop)], grid, wl.c4_kernel(), np.float32)
+            o32c = torch.empty((bs.n_channels, bs.n), device='cuda', dtype=torch.float32)
+            ms32 = timed(lambda: chn32.launch_torch(o32c), 5, 2)
+            also['c4']['f32'] = {'kernel': chn32.plan.kernel_name(), 'fused': chn32.fused, 'step_ms': ms32,
+                                 'frac': algo_bytes / 2 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            chn32.close()
+            del o32c
         # IIR stages of sample(filters=) / predistort(filters=) on the same 256 x 1e7 block (SURVEY 8(f)
         # N1): a two-biquad sosfilt cascade and four first-order (exponential-correction) sections;
         # 16 B/sample algorithmic (read + write), kernel time by HIP events

@@ -13,6 +13,11 @@ ws = [((0.5 + 0.3j) * wf.chirp(1e8, 3e8, 1.2 * wl.W, type='exponential') * (wf.s
 w = wl._tree_sum(ws)
 n = 2 * 10**6
 grid = ('linspace', 0.0, 3e-6, n, False)
+# `slice` as first argument: the same samples as the second half of a grid twice as long (wfk_grid.i0 != 0: the *_slice builds)
+SLICE = len(sys.argv) > 1 and sys.argv[1] == 'slice'
+if SLICE:
+    full = _flatten.grid_from_desc(('linspace', -3e-6, 3e-6, 2 * n, False))
+    grid = _flatten.grid_slice(full, n, 2 * n)
 for dt, tdt in ((np.complex128, torch.complex128), (np.complex64, torch.complex64), (np.float64, torch.float64)):
     bs = BatchSampler([w] * 32, grid)
     out = torch.empty((32, n), dtype=tdt, device='cuda')
@@ -23,7 +28,7 @@ for dt, tdt in ((np.complex128, torch.complex128), (np.complex64, torch.complex6
     for _ in range(5): bs.launch_torch(out)
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
-    ref = c_oracle.eval_grid(_flatten.flatten([w]), _flatten.grid_from_desc(('linspace', 0.0, 3e-6, n, False)), True)[0][:200000]
+    ref = c_oracle.eval_grid(_flatten.flatten([w]), grid if SLICE else _flatten.grid_from_desc(('linspace', 0.0, 3e-6, n, False)), True)[0][:200000]
     got = out[0, :200000].cpu().numpy()
     err = np.max(np.abs(got - (ref if np.iscomplexobj(got) else ref.real)))
     print(f'{np.dtype(dt).name}: {ms:.3f} ms  {bs.plan.kernel_name(dt)}  max err {err:.2e}  lib={os.environ.get("WFK_LIB", "tree")}', flush=True)

@@ -94,7 +94,9 @@ __device__ __forceinline__ double grid_time(const KArgs& a, int64_t j) {
   // (int64 -> double is a multi-instruction sequence on this ISA, uint32 -> double is one: the
   //  per-sample callers of the direct tier feel it; both conversions are exact)
   double dj;
-  if constexpr (SLICE) dj = (double)(j + a.i0);
+  // (slices: j and i0 are exact doubles and so is their sum (< 2^53): one conversion of a 32-bit index + one add,
+  //  instead of a 64-bit add and the multi-instruction int64 conversion)
+  if constexpr (SLICE) dj = a.n <= 0xffffffffLL ? (double)(uint32_t)j + (double)a.i0 : (double)(j + a.i0);
   else dj = a.n <= 0xffffffffLL ? (double)(uint32_t)j : (double)j;
   double m = dj * a.step;
   double t = m + a.t0;
@@ -1830,8 +1832,15 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENER
   wfk_sample_body<T, T, CPLX, TLIST, GENERIC, DIRECT, NS, false>(a);
 }
 // the same for a plan that is a time slice of a longer grid (wfk_grid.i0 != 0; grid plans only: a time list carries its times)
+// (the complex builds with the direct tier sit on the 256-register edge and the slice offset pushed them over it -- 848 / 734
+//  VGPRs in scratch: they run ONE workgroup per CU instead, i.e. one wave per SIMD with 512 registers per lane, and the
+//  allocator's overflow lands in AGPRs, not in memory)
+#ifndef WFK_SLICE_CPLX_WGS
+#define WFK_SLICE_CPLX_WGS 1
+#endif
+#define WFK_SLICE_WGS(CPLX, GENERIC, DIRECT) ((CPLX) && (DIRECT) ? WFK_SLICE_CPLX_WGS : ((DIRECT) || (GENERIC)) ? 2 : 1)
 template <typename T, bool CPLX, bool GENERIC, bool DIRECT, int NS>
-__global__ void __launch_bounds__(WFK_WG, (DIRECT || GENERIC) ? 2 : 1) wfk_sample_slice(const KArgs a) {
+__global__ void __launch_bounds__(WFK_WG, WFK_SLICE_WGS(CPLX, GENERIC, DIRECT)) wfk_sample_slice(const KArgs a) {
   wfk_sample_body<T, T, CPLX, false, GENERIC, DIRECT, NS, true>(a);
 }
 
@@ -1844,7 +1853,7 @@ __global__ void __launch_bounds__(WFK_WG, TLIST ? WFK_TL_WGS : ((DIRECT || GENER
   wfk_sample_body<double, float, CPLX, TLIST, GENERIC, DIRECT, NS, false>(a);
 }
 template <bool CPLX, bool GENERIC, bool DIRECT, int NS>
-__global__ void __launch_bounds__(WFK_WG, (DIRECT || GENERIC) ? 2 : 1) wfk_sample_wide_slice(const KArgs a) {
+__global__ void __launch_bounds__(WFK_WG, WFK_SLICE_WGS(CPLX, GENERIC, DIRECT)) wfk_sample_wide_slice(const KArgs a) {
   wfk_sample_body<double, float, CPLX, false, GENERIC, DIRECT, NS, true>(a);
 }
 
