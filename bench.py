@@ -751,6 +751,10 @@ def run_rank(args):
                              'msamples_per_s': bs.n_channels * bs.n / (ms * 1e-3) / 1e6,
                              'frac': algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              'unfused_ms': kern_ms + also['iir'].get(sname, {}).get('ms', float('nan'))}
+                rvi = valu_roofline('iir_chain' if sname == 'two_biquads' else 'iir_chain4', ms, bs.n_channels * bs.n) if sc.fused else None
+                if rvi is not None:
+                    ic[sname]['valu_frac'] = rvi['valu_frac']
+                    ic[sname]['valu_instr_per_sample'] = rvi['valu_instr_per_sample']
                 sc.close()
             also['iir_chain'] = ic
         except Exception as e:
