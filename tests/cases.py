@@ -20,6 +20,20 @@ LIN = ('linspace', -10.0, 10.0, 1001, True)
 # envelope recurrences of the fused tiers (worst observed over the soaks: 3.03e-5, chain_soak seed 29703).
 FP32_TOL = 5e-5
 
+# THE fp64 bounds, one per tier, as fractions of max(1, peak) of the fp64 oracle (north_star's contract: < 1e-9 absolute
+# on O(1) waveforms).  Tests and soaks (tools/*_soak.py) hold THESE numbers; a test may assert something tighter for a
+# case it knows (the README pulses sit at 1e-12), never something looser.
+#   grid tiers (lean, short, general, the FIR / IIR chains' samplers): a fused group is admitted only while
+#       |rate| x (rounding of NumPy's grid time) <= 2.5e-10, closing multipliers add up to 1e-10 (worst soak: 3.5e-10)
+#   time lists, fused groups evaluated pointwise: the same 2.5e-10 admission on 2.4e-16 |t| rate, + the inline
+#       sincos / exp (2 ulp) -- worst of 16 000 soak scripts 1.9e-11
+#   time lists, libm tier (one device-libm call per factor on the caller's own times): 1e-11
+#   IIR stages (blocked scan against SciPy's sequential recurrence, any of the three execution forms): 1e-10
+FP64_GRID_TOL = 1e-9
+FP64_TLIST_FUSED_TOL = 5e-10
+FP64_TLIST_LIBM_TOL = 1e-11
+FP64_IIR_TOL = 1e-10
+
 
 def _ref_tolist_case(ns):          # reference tests/test_waveform.py:38-48
     p = ns.gaussian(10) >> 5

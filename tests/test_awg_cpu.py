@@ -82,9 +82,13 @@ def test_long_pieces_keep_the_lean_tier_and_env_overrides():
     w = wl.awg_channel(wf, 0, 20000, 2e9) + (wf.chirp(1e8, 2e8, 30e-9) >> 5e-6)
     p3 = _engine.Plan(_flatten.flatten([w]), grid=g2)
     assert p3.kernel_name() == 'wfk_sample_short<double,false,false,16,1>' and p3.info.n_generic == 0
-    # ... pieces the tier cannot take (an exponential chirp: device libm) go to the general kernel in a second launch;
-    # the rest of the plan keeps the short tier
+    # ... and so is an exponential chirp (a closing multiplier of family 4: one exponential step + one sine per sample)
     w = wl.awg_channel(wf, 0, 20000, 2e9) + (wf.chirp(1e8, 2e8, 30e-9, type='exponential') >> 5e-6)
+    p3 = _engine.Plan(_flatten.flatten([w]), grid=g2)
+    assert p3.kernel_name() == 'wfk_sample_short<double,false,false,16,4>' and p3.info.n_generic == 0
+    # ... pieces the tier cannot take (a sinc pulse: device libm) go to the general kernel in a second launch;
+    # the rest of the plan keeps the short tier
+    w = wl.awg_channel(wf, 0, 20000, 2e9) + ((wf.sinc(2e8) * wf.square(30e-9)) >> 5e-6)
     p3 = _engine.Plan(_flatten.flatten([w]), grid=g2)
     assert p3.kernel_name().startswith('wfk_sample_short<') and ' + wfk_sample<' in p3.kernel_name()
     assert p3.info.n_generic > 0 and p3.info.n_fused > 0

@@ -122,3 +122,31 @@ def test_reference_chirp_cases_and_goldens():
     got = wf.chirp(1, 2, 10, 4, 'linear')(t)
     want = np.where((t >= 0) & (t < 10), np.sin(4 + 2 * np.pi * ((2 - 1) / (2 * 10) * t**2 + 1 * t)), 0.0)
     assert np.max(np.abs(got - want)) <= 1e-9
+
+
+def test_exponential_and_hyperbolic_chirps_at_awg_rates_are_short_tier_multipliers(monkeypatch):
+    """chirp(type='exponential' | 'hyperbolic') pulses of 30-60 samples at 2 GS/s: the phase has no recurrence form, but as
+    the closing MULTIPLIER of what the pulse's other factors fuse to they stay on the short tier (family 4: one inline
+    exponential step / one log + one sine per sample) instead of the term interpreter with device libm
+    (reference EXPONENTIALCHIRP / HYPERBOLICCHIRP, _waveform.pyx:326-332)."""
+    rate, n = 2e9, 40_000
+    grid = ('arange', 0.0, n / rate, 1.0 / rate)
+    rng = np.random.default_rng(5)
+    for kind in ('exponential', 'hyperbolic'):
+        ws = []
+        for k in range(int(n / rate / wl.SPAN)):
+            body = wf.chirp(rng.uniform(5e7, 1e8), rng.uniform(1.5e8, 3e8), wl.SPAN, rng.uniform(0, 6), type=kind)
+            env = wf.cosPulse(wl.SPAN) if k % 3 else (wf.gaussian(wl.W) >> (wl.SPAN / 2))
+            ws.append(rng.uniform(0.2, 1) * body * env >> (k * wl.SPAN))
+        w = wl._tree_sum(ws)
+        plan, err = _check([w, 0.5 * w + 0.1], grid, tol=1e-9, want_kernel='wfk_sample_short<double,false,false,16,4>')
+        assert plan.info.n_generic == 0 and plan.info.n_direct == 0
+        assert err <= 5e-11, err                      # (measured; the bound of the grid tiers is 1e-9)
+    # complex amplitudes, and the switch that sends such pieces back to the term interpreter
+    wc = (0.7 - 0.2j) * w
+    _check(wc, grid, want_kernel='wfk_sample_short<double,false,false,16,4>', cplx=True)
+    monkeypatch.setenv('WFK_NO_SHORT_XCHIRP', '1')
+    off = _engine.Plan(_flatten.flatten([w]), grid=_flatten.grid_from_desc(grid))
+    assert '16,4>' not in off.kernel_name()
+    ora = c_oracle.eval_grid(_flatten.flatten([w]), _flatten.grid_from_desc(grid))
+    assert np.max(np.abs(off.run_host(np.float64) - ora)) <= 1e-9

@@ -11,7 +11,7 @@ from scipy.signal import butter, lfilter, sosfilt, tf2sos
 
 import cases
 import golden_io
-from cases import FP32_TOL
+from cases import FP32_TOL, FP64_IIR_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten, workloads as wl
@@ -19,7 +19,7 @@ from waveforms_amd.distortion import SampledIir, exp_decay_filter
 
 pytestmark = pytest.mark.gpu
 IIR = golden_io.npz("iir.npz")
-TOL = 1e-10      # fp64 bound of the IIR stages (as tests/test_gpu_iir.py): a blocked scan against SciPy's sequential recurrence; contract 1e-9
+TOL = FP64_IIR_TOL      # a blocked scan against SciPy's sequential recurrence (tests/cases.py); contract 1e-9
 
 
 def _samples(chans, grid):

@@ -5,6 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
+from cases import FP64_GRID_TOL
 import cases
 import waveforms_amd as wf
 from oracle import np_oracle
@@ -34,7 +35,7 @@ for it in range(count):
         want = np_oracle.call(ch, x)
         got = ch(x)
         pk = max(1.0, float(np.abs(want).max())) if want.size else 1.0
-        tol = 1e-9 * pk
+        tol = FP64_GRID_TOL * pk
         if got.shape != want.shape or got.dtype != want.dtype or np.max(np.abs(got - want), initial=0.0) > tol:
             bad.append((it, 'call', got.shape, want.shape, got.dtype, want.dtype)); print('FAIL', bad[-1], flush=True); continue
         if len(x):

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import cases
-from cases import FP32_TOL
+from cases import FP32_TOL, FP64_GRID_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _flatten
@@ -32,7 +32,7 @@ for seed in range(first, first + count):
         y = c_oracle.eval_grid(prog, g)
         want = np.stack([c_oracle.fir(r, ker) for r in y])
         pk = max(1.0, float(np.abs(y).max(initial=0.0)))
-        for dt, tol in ((np.float64, 1e-9), (np.float32, FP32_TOL)):      # (fp32: fuzz_soak's bound for the sampler alone)
+        for dt, tol in ((np.float64, FP64_GRID_TOL), (np.float32, FP32_TOL)):      # (fp32: fuzz_soak's bound for the sampler alone)
             sf = SampledFir(chans, grid, ker, dt)
             kn = sf.plan.kernel_name()
             kn = 'hybrid fir_short' if (' + fir_short' in kn) else kn.split('<')[0].split(' ')[0] + (' + FIR' if '+ FIR' in kn else '')

@@ -3,7 +3,9 @@ multipliers (family 3) against the C oracle.     python tools/fmul_soak.py [n_ca
 Prints one line per failure and a summary; exit code 1 on any failure."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+from cases import FP64_GRID_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -76,7 +78,7 @@ for case in range(n_cases):
     pk = max(1.0, float(np.abs(ref).max()))
     err = float(np.max(np.abs(got - ref))) / pk
     worst = max(worst, err)
-    if not err <= 1e-9:
+    if not err <= FP64_GRID_TOL:
         fails += 1
         print(f'FAIL case {seed0 + case}: err {err:.3e} of peak {pk:.3g}  n {n} span {span:.3g} t0 {t0:.3g}  {name}', flush=True)
     if case % 50 == 49:

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import cases
-from cases import FP32_TOL
+from cases import FP32_TOL, FP64_GRID_TOL, FP64_TLIST_FUSED_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -32,7 +32,7 @@ for seed in range(first, first + count):
             ora = c_oracle.eval_grid(prog, g, True)[0]
             got = plan.run_host(np.complex128)[0]
             e = float(np.max(np.abs(got - ora), initial=0.0))
-            if not e <= 1e-9 * max(1.0, float(np.max(np.abs(ora), initial=0.0))):
+            if not e <= FP64_GRID_TOL * max(1.0, float(np.max(np.abs(ora), initial=0.0))):
                 bad.append((seed, 'complex', e))
                 print('FAIL', bad[-1], flush=True)
             continue
@@ -42,7 +42,7 @@ for seed in range(first, first + count):
         e32 = float(np.max(np.abs(got32 - ora), initial=0.0))
         tl = _engine.Plan(prog, t=c_oracle.grid_values(g)).run_host(np.float64)[0]
         etl = float(np.max(np.abs(tl - ora), initial=0.0))
-        if not (e64 <= 1e-9 * pk and e32 <= FP32_TOL * pk and etl <= 5e-10 * pk) or \
+        if not (e64 <= FP64_GRID_TOL * pk and e32 <= FP32_TOL * pk and etl <= FP64_TLIST_FUSED_TOL * pk) or \
                 (np.all(np.isfinite(ora)) and not np.all(np.isfinite(got))):
             bad.append((seed, e64 / pk, e32 / pk, etl / pk))
             print('FAIL', bad[-1], flush=True)

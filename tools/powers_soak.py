@@ -2,7 +2,9 @@
 from t = 0, on fine grids, AWG-rate grids and time lists, against the C oracle.   python tools/powers_soak.py [n] [seed0]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+from cases import FP64_GRID_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _engine, _flatten
@@ -57,7 +59,7 @@ for case in range(n_cases):
         tl = _engine.Plan(prog, t=t).run_host(dt)
         err = max(err, float(np.max(np.abs(tl - c_oracle.eval_tlist(prog, t, want_complex=cplx)))) / pk)
     worst = max(worst, err)
-    if not err <= 1e-9:
+    if not err <= FP64_GRID_TOL:
         fails += 1
         print(f'FAIL case {seed0 + case}: err {err:.3e} of peak {pk:.3g}  {grid[0]} n {n} t0 {t0:.3g}  {plan.kernel_name(dt)}', flush=True)
     if case % 100 == 99:

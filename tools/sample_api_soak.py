@@ -6,6 +6,7 @@ import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
+from cases import FP64_GRID_TOL
 from scipy import signal
 import cases
 import waveforms_amd as wf
@@ -70,7 +71,7 @@ for it in range(count):
             bad.append((it, mode, 'shape', got.shape, want.shape)); print('FAIL', bad[-1], flush=True); continue
         pk = max(1.0, float(np.abs(want).max())) if want.size else 1.0
         e = float(np.max(np.abs(got - want), initial=0.0)) / pk
-        if not e <= 1e-9:
+        if not e <= FP64_GRID_TOL:
             bad.append((it, mode, e)); print('FAIL', bad[-1], flush=True)
     except NotImplementedError:
         skipped += 1

@@ -138,7 +138,8 @@ __device__ __forceinline__ ChSeeds chain_seeds(double theta, double ea, double e
 // (iir_sampled: a lane's run continues in the next round).
 // SEL (with MASK): the mask as a per-sample select on the value instead of a branch around the sample's arithmetic (which
 // the compiler turns into 32 precomputed exec masks in SGPR pairs: iir_sampled has no SGPRs to spare).
-template <typename T, int CL, int KC, bool MASK, bool DEG1, bool SEL = false>
+// INIT: the op's values are STORED into acc (the first op of a round whose every lane runs it), not added.
+template <typename T, int CL, int KC, bool MASK, bool DEG1, bool SEL = false, bool INIT = false>
 __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, const ChSeeds& sd, double u0,
                                            double q, T (&acc)[CL], int klo, int khi, ChSeeds& nx) {
   const T c0 = (T)sd.c, s0 = (T)sd.s;
@@ -186,7 +187,8 @@ __device__ __forceinline__ void chain_loop(const double2* tab, const double* r, 
       }
       g *= rr;
       rr *= q;
-      if constexpr (MASK && SEL) acc[k] += (k >= klo && k < khi) ? val : (T)0;
+      if constexpr (INIT) acc[k] = val;
+      else if constexpr (MASK && SEL) acc[k] += (k >= klo && k < khi) ? val : (T)0;
       else if (!MASK || (k >= klo && k < khi)) acc[k] += val;
     CH_END
     __builtin_amdgcn_sched_barrier(0);

@@ -282,6 +282,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool env_no_short_envmul = std::getenv("WFK_NO_SHORT_ENVMUL") != nullptr;
   const bool env_no_bank = std::getenv("WFK_NO_BANK") != nullptr;
   const char* const env_tlsmall_limit = std::getenv("WFK_TLSMALL_LIMIT");
+  const bool env_no_short_xchirp = std::getenv("WFK_NO_SHORT_XCHIRP") != nullptr;
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
   const bool nofast = nofast_env && nofast_env[0] == '1';
@@ -1231,7 +1232,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     // ONE carrier (or none) under a table / mollifier envelope -- a pulse as mixing() makes it -- is a single
     // 12-double record: the op adds envelope x carrier itself (word bit 7; bit 8: mollifier) instead of a carrier
     // op followed by the closing multiplier in a record of its own (a dependent load per piece)
-    const bool one = groups.size() >= 2 && groups[1].fmul && groups[0].deg == 0 && !groups[0].has_env && !groups[0].has_exp &&
+    const bool one = groups.size() >= 2 && (groups[1].fmul == 2 || groups[1].fmul == 3) && groups[0].deg == 0 && !groups[0].has_env && !groups[0].has_exp &&
                      !groups[0].erfmul && !groups[0].envmul && !groups[0].chirp && !groups[0].fmul && !env_no_short_cmul;
     // (several envelopes in one piece: the host marked every (group, multiplier) pair -- FceGroup::fmul_own)
     auto own_pair = [&](size_t gi) { return gi + 1 < groups.size() && groups[gi + 1].fmul && (groups[gi + 1].fmul_own || (one && gi == 0)); };
@@ -1258,10 +1259,25 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // table: [8] m - 1, [9] the table's first entry in the pool (16-byte entries)
           const int32_t f = G.fmul_f;
           const double* fa = P->pool + P->fc_arg_off[f];
-          const uint64_t word = (uint64_t)(uint32_t)(G.fmul | (3 << 4) | (&G == &groups.back() ? WFK_SH_LAST : 0)) | ((uint64_t)(uint32_t)r0 << 32);
+          // (chirp multipliers: degree field 2 | 3 as well -- the record is stepped over as a 16-double one -- and bit 10)
+          const uint64_t word = (uint64_t)(uint32_t)((G.fmul >= 4 ? (G.fmul - 2) | 1024 : G.fmul) | (3 << 4) | (&G == &groups.back() ? WFK_SH_LAST : 0)) | ((uint64_t)(uint32_t)r0 << 32);
           std::memcpy(&o[0], &word, sizeof word);
           const long double u0 = x0 - (long double)P->fc_shift[f];
-          if (G.fmul == 2) {
+          if (G.fmul == 4) {
+            // phase / pi = ph0 + scale exp(a_k),  a_k = alpha u0 + (koff + k) alpha dt
+            const long double al = fa[1];
+            o[5] = (double)(al * u0);
+            o[6] = (double)(al * (long double)grid->step);
+            o[8] = (double)(2.0L * (long double)fa[0] / al);
+            o[9] = (double)remainderl(((long double)fa[2] - 2.0L * PIl * (long double)fa[0] / al) / PIl, 2.0L);
+          } else if (G.fmul == 5) {
+            // phase / pi = ph0 + scale log(l_k),  l_k = 1 + k u0 + (koff + k) k dt
+            const long double kk = fa[1];
+            o[5] = (double)(1.0L + kk * u0);
+            o[6] = (double)(kk * (long double)grid->step);
+            o[8] = (double)(2.0L * (long double)fa[0] / kk);
+            o[9] = (double)remainderl((long double)fa[2] / PIl, 2.0L);
+          } else if (G.fmul == 2) {
             const int64_t m = P->fc_arg_off[f + 1] - P->fc_arg_off[f] - 2;
             const long double inv = (long double)(m - 1) / ((long double)fa[1] - (long double)fa[0]);
             o[5] = (double)((u0 - (long double)fa[0]) * inv);
@@ -1273,7 +1289,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
             o[6] = (double)((long double)grid->step / (long double)fa[0]);
           }
           H.short_has_fmul = true;
-          H.short_fam = std::max(H.short_fam, 2);
+          H.short_fam = std::max(H.short_fam, G.fmul >= 4 ? 4 : 2);
           o += WFK_SH_OP3;
           continue;
         }
@@ -1513,7 +1529,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           fslot = 0;
           int32_t at = -1;
           for (int32_t f = P->tm_factor_off[k]; f < P->tm_factor_off[k + 1]; ++f)
-            if (P->fc_type[f] == WFK_INTERP || P->fc_type[f] == WFK_MOLLIFIER) {
+            if (P->fc_type[f] == WFK_INTERP || P->fc_type[f] == WFK_MOLLIFIER ||
+                (cur_short && !env_no_short_xchirp && (P->fc_type[f] == WFK_EXPONENTIALCHIRP || P->fc_type[f] == WFK_HYPERBOLICCHIRP))) {
               if (at >= 0 || P->fc_power[f] != 1.0) return -1;
               at = f;
             } else if (P->fc_type[f] == WFK_ERF) return -1;
@@ -1522,7 +1539,34 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           const int64_t na = P->fc_arg_off[at + 1] - P->fc_arg_off[at];
           const double sh = P->fc_shift[at];
           if (!std::isfinite(sh)) return -1;
-          const int kind = P->fc_type[at] == WFK_INTERP ? 2 : 3;
+          const int kind = P->fc_type[at] == WFK_INTERP ? 2 : (P->fc_type[at] == WFK_MOLLIFIER ? 3 :
+                           (P->fc_type[at] == WFK_EXPONENTIALCHIRP ? 4 : 5));
+          if (kind >= 4) {
+            // Exponential / hyperbolic chirps at AWG rates (short pieces only): sin(phi0 + 2 pi f0 (exp(alpha u) - 1) / alpha) and
+            // sin(phi0 + 2 pi f0 / k log(1 + k u)) (reference _waveform.pyx:326-332) have no recurrence form -- the phase does not
+            // advance by a constant -- but as a MULTIPLIER of what the piece's other factors fuse to they cost one inline
+            // exp step + one sine per sample (wfk_short_dev.h: short_xchirpmul) instead of a trip through the term interpreter
+            // with device libm (one sample per lane: 10.6 ms for 2048 x 1e5 at 2 GS/s).  One such factor per piece.
+            if (mod_f >= 0) { if (same_mod(at, mod_f)) { kind_out = kind; return at; } return -1; }
+            for (int i = 0; i < 3; ++i)
+              if (!std::isfinite(fa[i])) return -1;
+            const double ua = (ax.at(s0) - C.tshift) - sh, ub = (ax.at(s1 - 1) - C.tshift) - sh;
+            double wmax;
+            if (kind == 4) {
+              if (fa[1] == 0.0 || !(std::fabs(fa[1]) * std::max(std::fabs(ua), std::fabs(ub)) <= 600.0)) return -1;
+              wmax = 6.283185307179586 * std::fabs(fa[0]) * std::exp(std::max(fa[1] * ua, fa[1] * ub));
+            } else {
+              const double la = 1.0 + fa[1] * ua, lb = 1.0 + fa[1] * ub;
+              if (fa[1] == 0.0 || !(la > 1e-6) || !(lb > 1e-6)) return -1;
+              wmax = 6.283185307179586 * std::fabs(fa[0]) / std::min(la, lb);
+            }
+            // (the phase itself is evaluated in double: its size times 2^-52 must stay inside the budget too)
+            const double phmax = kind == 4 ? 6.283185307179586 * std::fabs(fa[0] / fa[1]) * (1.0 + std::exp(std::max(fa[1] * ua, fa[1] * ub)))
+                                           : 6.283185307179586 * std::fabs(fa[0] / fa[1]) * std::max(std::fabs(std::log(1.0 + fa[1] * ua)), std::fabs(std::log(1.0 + fa[1] * ub)));
+            if (!std::isfinite(wmax) || !rate_safe(wmax, s0, s1) || !(4.5e-16 * (phmax + std::fabs(fa[2])) <= WFK_JITTER_TOL)) return -1;
+            kind_out = kind;
+            return at;
+          }
           if (mod_f >= 0) {
             // one multiplier per piece: the same primitive, arguments and shift as the first term's
             if (same_mod(at, mod_f)) { kind_out = kind; return at; }

@@ -685,7 +685,6 @@ __device__ __forceinline__ void ops_round(const IirSampArgs& a, const DevChannel
                                           T (&acc)[OP_LB]) {
   constexpr int CL = OP_LB;
   const double2* const unit_tab = reinterpret_cast<const double2*>(s_par + OPS_PAR);
-  CH_EACH(CL, k) acc[k] = (T)0; CH_END
   double x;
   {
 #pragma clang fp contract(off)
@@ -710,6 +709,7 @@ __device__ __forceinline__ void ops_round(const IirSampArgs& a, const DevChannel
   const bool keep = !first_round && main_on && prev_p == p0;   // the carried state continues this lane's run in this piece
   prev_p = main_on ? p0 : -1;
   const bool any_main = __any(main_on), any_fresh = __any(main_on && !keep), any_part = __any(!inside);
+  CH_EACH(CL, k) acc[k] = (T)0; CH_END
   for (int op = 0; op < nops; ++op) {
     const int fl = cuni(WFK_FCE_WORD(s_par + shape_off + WFK_BLK_HDR + op * WFK_FCE_REC));   // the same in every live piece
     const int env = (fl >> 4) & 3, carrier = (fl >> 2) & 1;
@@ -766,12 +766,7 @@ __device__ __forceinline__ void ops_round(const IirSampArgs& a, const DevChannel
       }
     }
   }
-  const T base = (T)C.offset;
-  if (js + CL <= a.n) {
-    CH_EACH(CL, k) acc[k] += base; CH_END
-  } else {
-    CH_EACH(CL, k) acc[k] = js + k < a.n ? acc[k] + base : (T)0; CH_END
-  }
+  // (the channel offset is added by the caller, folded with the filter's `- initial`: one add per sample)
 }
 
 template <typename T, int NSEC, int ORD, bool PLAIN>
@@ -799,6 +794,7 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
   }
   const int row = (int)(blockIdx.x % (unsigned)rows);
   const DevChannel C = sa.channels[row];
+  const double xoff = C.offset - pre_sub;                      // sample + channel offset - initial: what the filter sees
   if (lane <= OP_LB) reinterpret_cast<double2*>(s_par + OPS_PAR)[lane] = make_double2(1.0, 0.0);   // phasor table of ops without a carrier
   for (;;) {
   unsigned t = 0;
@@ -861,17 +857,17 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
       const double* w = s_w + r * OP_LB * 4;
 #pragma unroll
       for (int i = 0; i < OP_LB; ++i) {
-        const double xv = (double)acc[i] - pre_sub;
+        const double xv = (double)acc[i] + xoff;
 #pragma unroll
         for (int j = 0; j < DD; ++j) z[j] = fma(w[i * 4 + j], xv, z[j]);
       }
     } else if (rest >= OP_LB) {
 #pragma unroll
-      for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z);
+      for (int i = 0; i < OP_LB; ++i) (void)iir_step_t<NSEC, ORD>(c, (double)acc[i] + xoff, z);
     } else {
 #pragma unroll
       for (int i = 0; i < OP_LB; ++i)
-        if (i < rest) (void)iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z);
+        if (i < rest) (void)iir_step_t<NSEC, ORD>(c, (double)acc[i] + xoff, z);
     }
   }
   // (a run past the end of the row leaves its state alone; the scan still multiplies by TL per run, which only matters
@@ -1008,11 +1004,11 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
     const int64_t rest = n - js;                               // samples of the row from this lane's segment on
     if (rest >= OP_LB) {
 #pragma unroll
-      for (int i = 0; i < OP_LB; ++i) acc[i] = (T)(iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z) + post_add + bad);
+      for (int i = 0; i < OP_LB; ++i) acc[i] = (T)(iir_step_t<NSEC, ORD>(c, (double)acc[i] + xoff, z) + post_add + bad);
     } else {
 #pragma unroll
       for (int i = 0; i < OP_LB; ++i)
-        if (i < rest) acc[i] = (T)(iir_step_t<NSEC, ORD>(c, (double)acc[i] - pre_sub, z) + post_add + bad);
+        if (i < rest) acc[i] = (T)(iir_step_t<NSEC, ORD>(c, (double)acc[i] + xoff, z) + post_add + bad);
     }
     // final state of the row: the segment that holds its last sample
     if (zf && rest > 0 && rest <= OP_LB)

@@ -295,7 +295,8 @@ struct HostPlan {
   bool grid_as_tlist = false;      // ... and the plan was therefore compiled on the grid's sample times as a time list (wfk_api.cpp)
   bool short_has_fmul = false;     // some short piece holds an op wfk_sample_short evaluates and fir_short does not (table / mollifier multipliers, chirps)
   int32_t short_fam = 0;           // instantiation of wfk_sample_short the plan needs: 0 carrier-envelope ops only, 1 + erf edges, chirps and
-                                   // shared Gaussians, 2 + table / mollifier envelopes (closing multipliers, own-term ops)
+                                   // shared Gaussians, 2 + table / mollifier envelopes (closing multipliers, own-term ops), 4 + exponential / hyperbolic chirp
+                                   // multipliers (3 is family 0 in packed fp32, picked at launch)
   bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
   bool pool_real = false;          // `pool` holds tables the parameter blocks point into (INTERP / mollifier / SAMPLED)
   std::vector<ShortUnit> s_units;

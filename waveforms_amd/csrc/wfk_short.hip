@@ -147,6 +147,10 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
   using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
   // float launches of the plain pulse train (family 3 = family 0 in packed fp32 arithmetic, wfk_short_dev.h: short_op_pk)
   constexpr bool PK = FAM == 3;
+  // what a family holds beside the carrier-envelope ops: F1 closing ops of flat tops / multi-tone pieces and linear chirps,
+  // F2 table / mollifier envelopes, F4 exponential / hyperbolic chirp multipliers (libm log behind a call: a family of
+  // its own, so that the table envelopes keep their register allocation)
+  constexpr bool F1 = FAM == 1 || FAM == 2 || FAM == 4, F2 = FAM == 2 || FAM == 4, F4 = FAM == 4;
   static_assert(!PK || (std::is_same<T, float>::value && !CPLX), "packed arithmetic: real float launches only");
   __shared__ __attribute__((aligned(16))) E s_out[kStage];
   const int lane = threadIdx.x;
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         const int w = op_word(rc);
         const bool closing = ((w >> 4) & 3) == 3;       // closing multiplier (erf edge, table, mollifier)
         const bool mine = lv && !closing && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
-        const bool chirp = FAM >= 1 && FAM <= 2 && (w & 512) != 0;  // quadratic phase (16-double record, polynomials of degree <= 1)
+        const bool chirp = F1 && (w & 512) != 0;  // quadratic phase (16-double record, polynomials of degree <= 1)
         const bool cubic = __any(mine && !chirp && (w & 3) > 1);
         if constexpr (PK) {
           if (mine) {
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
           }
           return lv && !(w & WFK_SH_LAST);
         } else {
-        if constexpr (FAM >= 1 && FAM <= 2) {
+        if constexpr (F1) {
           if (__any(mine && chirp)) {
             if (mine && chirp) short_chirp<R, CPLX>(rc, opp, w, kf, a.step, acc, acci);
           }
@@ -243,19 +247,25 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
 #ifndef WFK_SH_SKIP0
 #define WFK_SH_SKIP0 0
 #endif
-          if (cubic) short_op<R, true, CPLX, (FAM >= 1 || WFK_SH_SKIP0)>(rc, opp, w, kf, a.step, acc, acci);
-          else short_op<R, false, CPLX, (FAM >= 1 || WFK_SH_SKIP0)>(rc, opp, w, kf, a.step, acc, acci);
+          if (cubic) short_op<R, true, CPLX, (F1 || WFK_SH_SKIP0)>(rc, opp, w, kf, a.step, acc, acci);
+          else short_op<R, false, CPLX, (F1 || WFK_SH_SKIP0)>(rc, opp, w, kf, a.step, acc, acci);
         }
-        if constexpr (FAM >= 1 && FAM <= 2)
+        if constexpr (F1)
         if (__any(lv && closing)) {
-          const bool own = FAM >= 2 && (w & 128) != 0;      // envelope x carrier in one op: adds its own term
-          if constexpr (FAM >= 2) {
+          const bool own = F2 && (w & 128) != 0;      // envelope x carrier in one op: adds its own term
+          if constexpr (F2) {
             if (__any(lv && closing && own)) {
               if (lv && closing && own && (CPLX || !(w & 8))) short_cmul<R, CPLX>(rc, a.pool, w, kf, acc, acci);
             }
           }
-          const int kind = own ? -1 : (w & 3);      // 0: erf edge; 1: shared Gaussian; 2: INTERP table, 3: mollifier (stateless multipliers)
-          if constexpr (FAM >= 1) {
+          const bool xch = F4 && (w & 1024) != 0;    // chirp multiplier (exponential / hyperbolic)
+          if constexpr (F4) {
+            if (__any(lv && closing && xch)) {
+              if (lv && closing && xch) short_xchirpmul<R, CPLX>(rc, w, kf, acc, acci);
+            }
+          }
+          const int kind = (own || xch) ? -1 : (w & 3);      // 0: erf edge; 1: shared Gaussian; 2: INTERP table, 3: mollifier (stateless multipliers)
+          if constexpr (F1) {
             if (__any(lv && closing && kind == 1)) {
               if (lv && closing && kind == 1) short_envmul<R, CPLX>(rc, kf, acc, acci);
             }
@@ -263,7 +273,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
           if (__any(lv && closing && kind == 0)) {
             if (lv && closing && kind == 0) short_erfmul_run<R, CPLX>(rc, kf, seg.len, acc, acci);
           }
-          if constexpr (FAM >= 2) {
+          if constexpr (F2) {
             if (__any(lv && closing && kind == 2)) {
               if (lv && closing && kind == 2) short_tabmul<R, CPLX>(rc, a.pool, kf, acc, acci);
             }
@@ -385,10 +395,10 @@ int launch_short(const SArgs& a, hipStream_t s) {
   constexpr bool kPk = std::is_same<T, float>::value && !CPLX;
   if (a.accumulate) {
     if (a.fam <= 0) { if constexpr (kPk) { if (a.pk) SH_LAUNCH(true, 3); else SH_LAUNCH(true, 0); } else SH_LAUNCH(true, 0); }
-    else if (a.fam == 1) SH_LAUNCH(true, 1); else SH_LAUNCH(true, 2);
+    else if (a.fam == 1) SH_LAUNCH(true, 1); else if (a.fam == 2) SH_LAUNCH(true, 2); else SH_LAUNCH(true, 4);
   } else {
     if (a.fam <= 0) { if constexpr (kPk) { if (a.pk) SH_LAUNCH(false, 3); else SH_LAUNCH(false, 0); } else SH_LAUNCH(false, 0); }
-    else if (a.fam == 1) SH_LAUNCH(false, 1); else SH_LAUNCH(false, 2);
+    else if (a.fam == 1) SH_LAUNCH(false, 1); else if (a.fam == 2) SH_LAUNCH(false, 2); else SH_LAUNCH(false, 4);
   }
 #undef SH_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;

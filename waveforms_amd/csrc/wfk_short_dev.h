@@ -313,6 +313,35 @@ __device__ __forceinline__ void short_mollmul(const OpRec& o, double kf, double 
   SH_END
 }
 
+// libm log behind a call (the hyperbolic chirp multiplier: rare)
+static __device__ __attribute__((noinline, unused)) double log_call(double x) { return log(x); }
+
+// Chirp multipliers (closing kind with word bit 10; degree field 2: exponential, 3: hyperbolic; 16-double records): what
+// the piece's ops accumulated is multiplied by sin(pi (ph0 + scale E_k)) with E_k = exp(a0 + (koff + k) da) -- advanced by
+// its constant ratio from one exact seed per lane -- or E_k = log(l0 + (koff + k) dl).  Reference: EXPONENTIALCHIRP /
+// HYPERBOLICCHIRP, waveforms/_waveform.pyx:326-332.  The phase is reduced per sample (rint) and the sine is the
+// straight-line sincospi kernel: ~60 instructions per sample against ~2000 on the pointwise tier's term interpreter.
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_xchirpmul(const OpRec& o, int w, double kf, double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+  const double d = o.d.x, scale = o.e.x, ph0 = o.e.y;
+  const bool hyp = (w & 1) != 0;
+  double a = fma(kf, d, o.c.y);
+  double e = hyp ? 0.0 : exp_small(a), rho = hyp ? 0.0 : exp_small(d);
+  SH_EACH(R, k)
+    double ev = e;
+    if (hyp) ev = log_call(a > 1e-300 ? a : 1.0);
+    const double x = fma(scale, ev, ph0);
+    const double n = rint(x);
+    double sn, cs;
+    sincospi_small(x - n, &sn, &cs);
+    const double m = (((int)n) & 1) ? -sn : sn;
+    acc[k] *= m;
+    if constexpr (CPLX) acci[k] *= m;
+    e *= rho;
+    a += d;
+  SH_END
+}
+
 // Envelope x carrier in ONE op (word bit 7; bit 8: the envelope is a mollifier, else a table): acc[k] += F_k (A0 c_k + B0 s_k)
 // -- a pulse as mixing(A * samplingPoints(...), freq, phase) makes it, in a record of 12 doubles like a Gaussian pulse's.
 // The carrier's rotation of each batch runs while the batch's table gathers are in flight.
