@@ -666,7 +666,7 @@ struct IirSampArgs {
 // [start[i], start[i + 1]) of the row and has its parameter block at s_par + off[i] (off < 0: a zero piece).
 #define OPS_PMAX 16
 struct OpsPieces {
-  int64_t start[OPS_PMAX + 1];
+  int32_t start[OPS_PMAX + 1];      // relative to the chunk's first sample, clamped to +-2^30 (all index arithmetic of a round is 32-bit)
   int32_t off[OPS_PMAX];
 };
 
@@ -681,22 +681,25 @@ struct OpsPieces {
 template <typename T>
 __device__ __forceinline__ void ops_round(const IirSampArgs& a, const DevChannel& C, const double* s_par,
                                           const OpsPieces& pd, int m, int nops, int shape_off, bool deg1,
-                                          int64_t js, bool first_round, int& prev_p, ChSeeds (&car)[OPS_NCAR],
-                                          T (&acc)[OP_LB]) {
+                                          int js, double dbase, int nrel, bool first_round, int& prev_p,
+                                          ChSeeds (&car)[OPS_NCAR], T (&acc)[OP_LB]) {
+  // js: the segment's first sample RELATIVE to the chunk (32-bit); dbase = (double)(chunk's first sample + grid.i0), exact, so
+  // that dbase + js is the exact double of the full-grid index (one conversion + one add instead of the int64 sequence);
+  // nrel: samples of the row from the chunk's start (clamped)
   constexpr int CL = OP_LB;
   const double2* const unit_tab = reinterpret_cast<const double2*>(s_par + OPS_PAR);
   double x;
   {
 #pragma clang fp contract(off)
-    const double mm = (double)(js + a.i0) * a.step;
+    const double mm = (dbase + (double)js) * a.step;
     x = mm + a.t0;
-    if (a.has_last && js == a.n - 1) x = a.last;
+    if (a.has_last && js == nrel - 1) x = a.last;
   }
   if (C.tshift != 0.0) x = x - C.tshift;
   // the lane's piece at its first and at its last sample
   int p0 = 0, p1 = 0;
   for (int i = 1; i < m; ++i) {
-    const int64_t st = pd.start[i];
+    const int st = pd.start[i];
     p0 += st <= js ? 1 : 0;
     p1 += st <= js + (CL - 1) ? 1 : 0;
   }
@@ -741,8 +744,8 @@ __device__ __forceinline__ void ops_round(const IirSampArgs& a, const DevChannel
     }
     if (any_part) {
       // segments that straddle a piece edge: samples [0, e0) belong to piece p0, [e1, CL) to piece p1
-      const int64_t d0 = pd.start[p0 + 1] - js, d1 = pd.start[p1] - js;
-      const int e0 = d0 > CL ? CL : (int)d0, e1 = d1 < 0 ? 0 : (int)d1;
+      const int d0 = pd.start[p0 + 1] - js, d1 = pd.start[p1] - js;
+      const int e0 = d0 > CL ? CL : d0, e1 = d1 < 0 ? 0 : d1;
       ChSeeds nx;
       if (part0) {
         const double* rec = blk0 + WFK_BLK_HDR + op * WFK_FCE_REC;
@@ -803,7 +806,10 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
   const int64_t chunk = t;
   if (chunk >= nchunks) return;
   const int64_t base = chunk * OPS_CHUNK, chunk_end = base + OPS_CHUNK;
-  const int64_t jrun = base + (int64_t)lane * OPS_RUN;         // first sample of this lane's run
+  const int jrun = lane * OPS_RUN;                             // first sample of this lane's run, relative to the chunk
+  const int64_t left = n - base;
+  const int nrel = (int)(left > (1 << 30) ? (1 << 30) : left); // samples of the row from the chunk's start (clamped)
+  const double dbase = (double)(base + sa.i0);                 // exact (< 2^53)
   T* y = out + (int64_t)row * out_stride + base;
 
   // ---- stage the pieces the chunk overlaps: descriptors (zero pieces included) and the parameter blocks of the live
@@ -819,8 +825,9 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
       const DevPiece P = sa.pieces[q];
       if (P.start >= chunk_end) break;
       if (lane == 0) {
-        pd.start[m] = m == 0 ? INT64_MIN : P.start;
-        pd.start[m + 1] = INT64_MAX;
+        const int64_t rs = P.start - base;
+        pd.start[m] = m == 0 ? -(1 << 30) : (int32_t)(rs > (1 << 30) ? (1 << 30) : rs);
+        pd.start[m + 1] = 1 << 30;
         pd.off[m] = P.n_blk == 0 ? -1 : off;
       }
       ++m;
@@ -848,11 +855,11 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
   for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
 #pragma unroll 1
   for (int r = 0; r < OPS_ROUNDS; ++r) {
-    const int64_t js = jrun + r * OP_LB;
-    if (base + r * OP_LB >= n) break;                          // (wave-uniform: no lane has a sample in this round)
+    const int js = jrun + r * OP_LB;
+    if (r * OP_LB >= nrel) break;                          // (wave-uniform: no lane has a sample in this round)
     T acc[OP_LB];
-    ops_round<T>(sa, C, s_par, pd, m, nops, shape_off, deg1, js, r == 0, prev_p, car, acc);
-    const int64_t rest = n - js;
+    ops_round<T>(sa, C, s_par, pd, m, nops, shape_off, deg1, js, dbase, nrel, r == 0, prev_p, car, acc);
+    const int rest = nrel - js;
     if (PLAIN && chunk_end <= n) {                             // (wave-uniform: every run of the chunk is whole)
       const double* w = s_w + r * OP_LB * 4;
 #pragma unroll
@@ -997,11 +1004,11 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
   const double bad = poisoned ? __builtin_nan("") : 0.0;
 #pragma unroll 1
   for (int r = 0; r < OPS_ROUNDS; ++r) {
-    const int64_t js = jrun + r * OP_LB;
-    if (base + r * OP_LB >= n) break;                          // (wave-uniform)
+    const int js = jrun + r * OP_LB;
+    if (r * OP_LB >= nrel) break;                          // (wave-uniform)
     T acc[OP_LB];
-    ops_round<T>(sa, C, s_par, pd, m, nops, shape_off, deg1, js, r == 0, prev_p, car, acc);
-    const int64_t rest = n - js;                               // samples of the row from this lane's segment on
+    ops_round<T>(sa, C, s_par, pd, m, nops, shape_off, deg1, js, dbase, nrel, r == 0, prev_p, car, acc);
+    const int rest = nrel - js;                                // samples of the row from this lane's segment on
     if (rest >= OP_LB) {
 #pragma unroll
       for (int i = 0; i < OP_LB; ++i) acc[i] = (T)(iir_step_t<NSEC, ORD>(c, (double)acc[i] + xoff, z) + post_add + bad);
@@ -1033,7 +1040,7 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
       } else {
 #pragma unroll
         for (int i = 0; i < 64 / RPI; ++i)
-          if (base + (int64_t)(RPI * i + rsub) * OPS_RUN + r * OP_LB + h * HS + col < n) ys[(int64_t)i * RPI * OPS_RUN] = tp[i * RPI * (HS + 1)];
+          if ((RPI * i + rsub) * OPS_RUN + r * OP_LB + h * HS + col < nrel) ys[(int64_t)i * RPI * OPS_RUN] = tp[i * RPI * (HS + 1)];
       }
     CH_END
   }
