@@ -176,8 +176,9 @@ def test_random_awg_script(seed):
 
 def test_flat_top_pulses_with_erf_edges_stay_in_the_short_tier():
     """square(width, edge) at AWG rates: 0.5 +- 0.5 erf edges of a handful of samples (reference
-    waveform.py:1096-1112).  The short tier multiplies what the edge piece's ops accumulated by
-    m0 + m1 erf(v) per sample (libm erf); nothing goes to the general kernel."""
+    waveform.py:1096-1112).  An edge under ONE carrier (or none) is an own-term op over the edge's host-sampled
+    table (family 2); under several carriers the short tier multiplies what the edge piece's ops accumulated by
+    m0 + m1 erf(v) per sample (libm erf, family 1; WFK_NO_SHORT_ERFTAB=1: every edge); nothing goes to the general kernel."""
     for rate, edge, tones in ((2e9, 5e-9, 1), (1e9, 3e-9, 1), (2.4e9, 8e-9, 3), (5e9, 2e-9, 2)):
         w = wf.zero()
         for k in range(40):
@@ -193,12 +194,19 @@ def test_flat_top_pulses_with_erf_edges_stay_in_the_short_tier():
         g = _flatten.grid_arange(0.0, 3.4e-6, 1 / rate)
         prog = _flatten.flatten([w])
         plan = _engine.Plan(prog, grid=g)
-        assert plan.kernel_name() == 'wfk_sample_short<double,false,false,16,1>', plan.kernel_name()
+        assert plan.kernel_name() == 'wfk_sample_short<double,false,false,16,2>', plan.kernel_name()
         assert plan.info.n_direct == 0 and plan.info.n_generic == 0
         ora = c_oracle.eval_grid(prog, g)[0]
         got = plan.run_host(np.float64)[0]
         assert np.max(np.abs(got - ora)) <= 1e-10, rate
         assert np.max(np.abs(plan.run_host(np.float32)[0] - ora)) <= 2e-6
+        os.environ['WFK_NO_SHORT_ERFTAB'] = '1'       # the closing-op form of every edge
+        try:
+            plan = _engine.Plan(prog, grid=g)
+        finally:
+            del os.environ['WFK_NO_SHORT_ERFTAB']
+        assert plan.kernel_name() == 'wfk_sample_short<double,false,false,16,1>', plan.kernel_name()
+        assert np.max(np.abs(plan.run_host(np.float64)[0] - ora)) <= 1e-10, rate
     # complex amplitudes and clip on top
     w2 = (0.6 + 0.3j) * (wf.square(40e-9, edge=5e-9) >> 60e-9) * wf.cos(2 * np.pi * 70e6) + 0.2 * (wf.gaussian(20e-9) >> 160e-9)
     g = _flatten.grid_arange(0.0, 0.3e-6, 1 / 2e9)

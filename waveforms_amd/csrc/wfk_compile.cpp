@@ -283,6 +283,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const bool env_no_bank = std::getenv("WFK_NO_BANK") != nullptr;
   const char* const env_tlsmall_limit = std::getenv("WFK_TLSMALL_LIMIT");
   const bool env_no_short_xchirp = std::getenv("WFK_NO_SHORT_XCHIRP") != nullptr;
+  const bool env_no_short_erftab = std::getenv("WFK_NO_SHORT_ERFTAB") != nullptr;
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
   const bool nofast = nofast_env && nofast_env[0] == '1';
@@ -1221,6 +1222,44 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (G.W != 0.0 && !G.chirp && !H.tlist) B.table_refs.emplace_back(at + WFK_FCE_TAB, table_for(B, G.W * dstride));
   };
 
+  // Flat-top edges at AWG rates (short tier): m0 + m1 erf(v_k) sampled HERE, once per distinct edge, as a table of the
+  // pool in fmul_table's layout (value, step to the next) -- the envelope of an own-term op (short_cmul) that is read at
+  // whole knots.  A libm erf per sample on the device was two thirds of what a flat-top pulse train cost (150
+  // instructions behind a call, per sample of an edge), and the closing op a record of its own behind a dependent load.
+  // Two edges share a table when (sigma, m0, m1, length) agree and their v at the first sample differ by no more than
+  // the rounding noise of the reference's own t - shift (1.5 ulp of the edge's largest |t|, over sigma) and 2e-11:
+  // pulses that sit on the sample grid alike.  Every other edge gets a table of its own (16 B per sample).
+  struct ErfTab { double sigma, m0, m1; long double v0; int64_t len, at; double first, last; };
+  std::vector<ErfTab> erf_tabs;
+  auto erf_table = [&](const FceGroup& E, double tshift, int64_t s0, int64_t s1) -> int64_t {
+    const int64_t len = s1 - s0;
+    auto xat = [&](int64_t k) { double x = ax.at(k); if (tshift != 0.0) x = x - tshift; return x; };
+    const double xa = xat(s0), xb = xat(s1 - 1);
+    const long double v0 = ((long double)xa - (long double)E.sg) / (long double)E.sigma;
+    const double tmax = std::max(std::max(std::fabs(xa), std::fabs(xb)), std::fabs(E.sg));
+    const double tol = std::min(1.5 * (std::nextafter(tmax, INFINITY) - tmax) / std::fabs(E.sigma), 2e-11);
+    int scanned = 0;
+    for (auto it = erf_tabs.rbegin(); it != erf_tabs.rend() && scanned < 64; ++it, ++scanned) {
+      if (it->sigma != E.sigma || it->m0 != E.m0 || it->m1 != E.m1 || it->len != len || fabsl(it->v0 - v0) > (long double)tol) continue;
+      const size_t a2 = 2 * (size_t)it->at;
+      if (a2 + 2 * (size_t)len > H.pool.size()) continue;                   // (rolled back with its piece)
+      if (std::memcmp(&H.pool[a2], &it->first, 8) != 0 || std::memcmp(&H.pool[a2 + 2 * (size_t)(len - 1)], &it->last, 8) != 0) continue;
+      return it->at;
+    }
+    if (H.pool.size() & 1) H.pool.push_back(0.0);
+    const int64_t at = (int64_t)(H.pool.size() / 2);
+    double prev = 0.0;
+    for (int64_t k = s0; k < s1; ++k) {
+      const double val = (double)((long double)E.m0 + (long double)E.m1 * erfl(((long double)xat(k) - (long double)E.sg) / (long double)E.sigma));
+      if (k > s0) H.pool.push_back(val - prev);
+      H.pool.push_back(val);
+      prev = val;
+    }
+    H.pool.push_back(0.0);
+    erf_tabs.push_back(ErfTab{E.sigma, E.m0, E.m1, v0, len, at, H.pool[2 * (size_t)at], prev});
+    return at;
+  };
+
   // ---- short tier: compact op records (WFK_SH_*), referenced to the first sample of each stretch ----
   // The group stands for  E(t') (A(u) cos th + B(u) sin th),  th = W t' - psi_ref,  u = t' - s_lin.
   // Everything a lane needs to seed the op `koff` samples after the reference sample x_ref:
@@ -1240,6 +1279,43 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       if (gi > 0 && own_pair(gi - 1)) continue;
       rec_len += (groups[gi].deg > 1 || groups[gi].fmul || groups[gi].chirp) ? WFK_SH_OP3 : WFK_SH_OP1;
+    }
+    // one carrier (or a constant) under a flat-top edge of at most WFK_SH_ERFTAB samples: ONE own-term op over the edge's
+    // sampled table (erf_table above), read at whole knots -- position k, step 1 (not for the FIR chain's sampler plan:
+    // fir_short evaluates the erf closing op only)
+    if (groups.size() == 2 && groups[1].erfmul && s1 - s0 <= WFK_SH_ERFTAB && !g_no_short_fmul && !env_no_short_erftab &&
+        groups[0].deg == 0 && !groups[0].has_env && !groups[0].has_exp && !groups[0].erfmul && !groups[0].envmul && !groups[0].chirp &&
+        !groups[0].fmul && !groups[0].corr) {
+      const FceGroup& G = groups[0];
+      double x = ax.at(s0);
+      if (tshift != 0.0) x = x - tshift;
+      const long double x0 = x;
+      const size_t at = H.params.size();
+      H.params.resize(at + (size_t)WFK_SH_OP1, 0.0);
+      double* o = H.params.data() + at;
+      const uint64_t word = (uint64_t)(uint32_t)(((G.W != 0.0 ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (3 << 4) | WFK_SH_LAST | 128) |
+                            ((uint64_t)(uint32_t)s0 << 32);
+      std::memcpy(&o[0], &word, sizeof word);
+      if (G.W != 0.0) {
+        const long double th0 = (long double)G.W * x0 - G.psi_ref;
+        o[1] = (double)remainderl(th0 / PIl, 2.0L);
+        const long double dth = (long double)G.W * (long double)grid->step;
+        o[2] = (double)(dth / PIl);
+        o[3] = (double)cosl(dth);
+        o[4] = (double)sinl(dth);
+      } else {
+        o[3] = 1.0;
+      }
+      o[5] = 0.0;                      // knot of the reference sample
+      o[6] = 1.0;                      // knots per sample
+      o[7] = (double)(s1 - s0 - 1);
+      o[8] = (double)G.A[0];
+      o[9] = (double)erf_table(groups[1], tshift, s0, s1);       // (H.pool may move: o points into H.params)
+      o[10] = (double)G.B[0];
+      H.short_has_fmul = true;
+      H.short_fam = std::max(H.short_fam, 2);
+      n_rec = 1;
+      return WFK_SH_OP1;
     }
     n_rec = 0;
     for (int64_t r0 = s0; r0 < s1; r0 += WFK_SH_SUB, ++n_rec) {

@@ -164,6 +164,7 @@
                               // (the kernel stores a unit with a FIXED sequence of 16 masked row stores)
 #define WFK_SH_SUB 4096       // samples per record of a long piece (phase = th0 + koff dth: koff stays small)
 #define WFK_SH_FILL 1008      // samples per pure-fill unit (long zero stretches: no slots, no LDS; same 16 rows)
+#define WFK_SH_ERFTAB 512     // flat-top edges of at most this many samples carry their multiplier values behind the record's ops
 #define WFK_SH_OP1 12
 #define WFK_SH_OP3 16
 #define WFK_SH_LAST 64        // op word: last op of its record

@@ -243,7 +243,14 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
             if (mine && chirp) short_chirp<R, CPLX>(rc, opp, w, kf, a.step, acc, acci);
           }
         }
-        if (mine && !chirp) {
+        // bare carriers (degree 0, no envelope): the tones of a multi-tone piece, plateaus -- half the instructions per sample
+        const bool bare = F1 && !chirp && (w & 0x33) == 0 && (w & 4) != 0;
+        if constexpr (F1) {
+          if (__any(mine && bare)) {
+            if (mine && bare) short_op_bare<R, CPLX>(rc, w, kf, acc, acci);
+          }
+        }
+        if (mine && !chirp && !bare) {
 #ifndef WFK_SH_SKIP0
 #define WFK_SH_SKIP0 0
 #endif
