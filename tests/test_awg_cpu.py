@@ -117,3 +117,29 @@ def test_chain_oracle_matches_reference_at_awg_rates(name):
     z = c_oracle.fir(y, wl.c4_kernel())[cases.awg_c4_subset(n)]
     assert z.shape == want.shape
     assert np.max(np.abs(z - want)) <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_flat_top_edges_share_their_sampled_tables_when_they_sit_on_the_grid_alike():
+    """square(width, edge) x one carrier at AWG rates: every edge is an own-term op over a table of m0 + m1 erf(v_k)
+    sampled by the host (wfk_compile.cpp: erf_table).  Pulses whose edges fall on the sample grid alike share one table;
+    pulses at arbitrary times get a table each; WFK_NO_SHORT_ERFTAB=1 keeps the closing-op form (device libm erf)."""
+    rate, n = 2e9, 20000
+    g = _flatten.grid_from_desc(wl.awg_grid(n, rate))
+
+    def plan(jitter):
+        rng = np.random.default_rng(5)
+        w = wf.zero()
+        for k in range(150):
+            at = (k + 0.5) * 60e-9 + (rng.uniform(0, 0.5e-9) if jitter else 0.0)
+            w = w + ((wf.square(36e-9, edge=3e-9) * wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6))) >> at)
+        return _engine.Plan(_flatten.flatten([w]), grid=g)
+    aligned, jittered = plan(False), plan(True)
+    assert aligned.kernel_name() == jittered.kernel_name() == 'wfk_sample_short<double,false,false,16,2>'
+    assert aligned.info.n_generic == 0 and jittered.info.n_generic == 0
+    # 300 edges of 12 samples: 16 B per sample when nothing is shared
+    assert jittered.table_bytes() - aligned.table_bytes() >= 250 * 12 * 16
+    os.environ['WFK_NO_SHORT_ERFTAB'] = '1'
+    try:
+        assert plan(False).kernel_name() == 'wfk_sample_short<double,false,false,16,1>'
+    finally:
+        del os.environ['WFK_NO_SHORT_ERFTAB']

@@ -25,10 +25,13 @@ def _plan(prog, grid, threads):
         del os.environ['WFK_COMPILE_THREADS']
 
 
-@pytest.mark.parametrize('kind', ['awg', 'lean', 'mixed_shapes'])
+@pytest.mark.parametrize('kind', ['awg', 'awg_tables', 'lean', 'mixed_shapes'])
 def test_blocks_equal_the_single_compile(kind):
     if kind == 'awg':        # short tier: 40 rows x 300 pulses at 2 GS/s
         chans = [wl.awg_channel(wf, c, 18000, 2e9, c % 3 == 0) for c in range(40)]
+        grid = _flatten.grid_from_desc(wl.awg_grid(18000, 2e9))
+    elif kind == 'awg_tables':   # short tier with pool tables (samplingPoints envelopes, sampled flat-top edges): they move with their block
+        chans = [wl.awg_interp_channel(wf, c, 18000, 2e9) if c % 2 else wl.awg_shape_channel(wf, 'flat_top', c, 18000, 2e9) for c in range(40)]
         grid = _flatten.grid_from_desc(wl.awg_grid(18000, 2e9))
     elif kind == 'lean':     # lean tier: 36 rows x 240 pulses on a fine grid
         chans = [wl.sum_channel(wf, 240, 50 + c) for c in range(36)]

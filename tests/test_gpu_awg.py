@@ -216,6 +216,31 @@ def test_flat_top_pulses_with_erf_edges_stay_in_the_short_tier():
     assert np.max(np.abs(plan.run_host(np.complex128)[0] - c_oracle.eval_grid(prog, g, True)[0])) <= 1e-10
 
 
+@pytest.mark.parametrize('t0', [0.0, 1e-4])
+@pytest.mark.parametrize('jitter', [False, True])
+def test_flat_top_edges_as_own_term_ops_over_sampled_tables(t0, jitter):
+    """edges that share a table (pulses on the sample grid alike) and edges with a table each (arbitrary pulse times),
+    at t = 0 and 100 us from it (where the rounding noise of t - shift exceeds the 2e-11 cap on what two edges may
+    differ by and still share): real and complex launches against the C oracle."""
+    rate, n = 2e9, 30000
+    g = _flatten.grid_arange(t0, t0 + n / rate, 1 / rate)
+    rng = np.random.default_rng(11)
+    w = wf.zero()
+    for k in range(200):
+        at = t0 + (k + 0.5) * 70e-9 + (rng.uniform(0, 0.5e-9) if jitter else 0.0)
+        amp = rng.uniform(0.2, 1) if k % 3 else complex(rng.uniform(-1, 1), rng.uniform(-1, 1))
+        car = wf.cos(2 * np.pi * rng.uniform(-2e8, 2e8), rng.uniform(0, 6)) if k % 5 else 1.0
+        w = w + ((amp * wf.square(rng.choice([30e-9, 36e-9]), edge=rng.choice([2e-9, 3e-9])) * car) >> at)
+    prog = _flatten.flatten([w])
+    plan = _engine.Plan(prog, grid=g)
+    assert plan.info.n_generic == 0
+    if t0 == 0.0:
+        assert plan.kernel_name(np.complex128) == 'wfk_sample_short<double,true,false,16,2>'
+    ora = c_oracle.eval_grid(prog, g, True)[0]
+    assert np.max(np.abs(plan.run_host(np.complex128)[0] - ora)) <= 1e-10
+    assert np.max(np.abs(plan.run_host(np.float64)[0] - ora.real)) <= 1e-10
+
+
 @pytest.mark.parametrize('duty30', [False, True])
 def test_bench_shape_2048_rows_full_size(duty30):
     """the `awg` / `awg_duty30` bench workloads as bench.py launches them: 2048 rows x 1e5 points at 2 GS/s,

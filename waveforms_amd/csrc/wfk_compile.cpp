@@ -2162,8 +2162,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
 // 2048 rows x 1668 pulses is 7 s on one core.  Channels are independent (reference: one Waveform per channel,
 // waveforms/waveform.py:529-563), so the job is cut into contiguous channel blocks, every block is compiled by
 // wfk_compile on its own thread into its own HostPlan, and the plans are concatenated (indices rebased).  Taken for the
-// two bulk shapes -- pure short-tier and pure lean plans without pool tables; anything else (mixed tiers, INTERP /
-// mollifier / SAMPLED tables, blocks that chose different tiers) returns WFK_RETRY_STD and the caller compiles in one piece.
+// two bulk shapes -- pure short-tier plans (their tables move with them) and pure lean plans without pool tables; anything
+// else (mixed tiers, lean plans with INTERP / mollifier / SAMPLED tables, blocks that chose different tiers) returns WFK_RETRY_STD and the caller compiles in one piece.
 int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads, HostPlan& H, std::string& err) {
   if (!P || !grid || nthreads < 2 || P->n_channels < 2 * nthreads) return WFK_RETRY_STD;
   {
@@ -2212,7 +2212,7 @@ int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads,
   const HostPlan& A = parts[0];
   if (A.tlist || A.mixed || A.grid_as_tlist || !(A.shortp || A.lean)) return WFK_RETRY_STD;
   for (const HostPlan& B : parts)
-    if (B.shortp != A.shortp || B.lean != A.lean || B.mixed || B.pool_real || B.short_gave_up || B.ns != A.ns || B.tile != A.tile ||
+    if (B.shortp != A.shortp || B.lean != A.lean || B.mixed || (B.pool_real && !B.shortp) || B.short_gave_up || B.ns != A.ns || B.tile != A.tile ||
         B.tiles_per_chunk != A.tiles_per_chunk || B.chunks_per_ch != A.chunks_per_ch ||
         B.f32_tiles_per_chunk != A.f32_tiles_per_chunk || B.f32_chunks_per_ch != A.f32_chunks_per_ch ||
         (B.n_corr > 0) != (A.n_corr > 0))
@@ -2232,6 +2232,28 @@ int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads,
     const int64_t po = (int64_t)H.params.size();             // even: records keep their 16-byte alignment
     const int32_t pc = (int32_t)H.pieces.size(), so = (int32_t)H.s_slots.size();
     for (DevChannel c : B.channels) { c.piece_begin += pc; c.piece_end += pc; H.channels.push_back(c); }
+    if (B.pool_real) {
+      // short plans with tables (INTERP envelopes, sampled flat-top edges): the block's pool goes behind the others', and
+      // the ops that name a table -- own-term ops over a table, closing table multipliers: [9], in 16-byte entries -- move with it
+      if (H.pool.size() & 1) H.pool.push_back(0.0);
+      const double tb = (double)(H.pool.size() / 2);
+      H.pool.insert(H.pool.end(), B.pool.begin(), B.pool.end());
+      for (const DevPiece& d : B.pieces) {
+        if (d.n_blk <= 0 || !(d.flags & WFK_PF_SHORT)) continue;
+        for (int32_t r = 0; r < d.n_blk; ++r) {
+          double* o = B.params.data() + d.par_off + (int64_t)r * d.first_len;
+          double* const end = o + d.first_len;
+          while (o < end) {
+            uint64_t word;
+            std::memcpy(&word, o, sizeof word);
+            const uint32_t w = (uint32_t)word;
+            if (((w >> 4) & 3) == 3 && ((w & 128) ? !(w & 256) : (!(w & 1024) && (w & 3) == 2))) o[9] += tb;
+            if (w & WFK_SH_LAST) break;
+            o += (w & 3) > 1 ? WFK_SH_OP3 : WFK_SH_OP1;
+          }
+        }
+      }
+    }
     for (DevPiece d : B.pieces) { if (d.n_blk > 0) d.par_off += po; else d.par_off = po; H.pieces.push_back(d); }
     H.params.insert(H.params.end(), B.params.begin(), B.params.end());
     for (int32_t v : B.chunk_first) H.chunk_first.push_back(v + pc);
@@ -2253,7 +2275,8 @@ int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads,
   }
   H.mean_piece_len = len_sum / (double)P->n_channels;
   H.foreign_frac = frac_sum / (double)P->n_channels;
-  H.pool.assign(1, 0.0);
+  H.pool_real = !H.pool.empty();
+  if (H.pool.empty()) H.pool.assign(1, 0.0);
   if (H.shortp) {
     const int64_t nu = (int64_t)H.s_units.size();
     H.s_units_per_chunk = (int32_t)std::min<int64_t>(6, std::max<int64_t>(1, nu / 8192));
