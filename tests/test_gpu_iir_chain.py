@@ -54,7 +54,9 @@ def test_fused_chain_matches_oracle_and_scipy(shape):
     """every single-pass shape with the sampler inside: fp64 against the C oracle's samples through SciPy"""
     secs = SHAPES[shape]
     chans = [wl.sum_channel(wf, 6, 1000 + c) for c in range(3)]
-    grid = ('linspace', 0.0, 6 * wl.SPAN, 50001, False)
+    # (>= four chunks of the fused scan: 64 lanes x 128 samples in the dot-product form, x 256 in the sweep form that
+    #  filters with slow poles -- two_biquads here -- take)
+    grid = ('linspace', 0.0, 6 * wl.SPAN, 70001, False)
     si = SampledIir(chans, grid, secs)
     assert si.fused, si.why_not
     assert si.plan.kernel_name().startswith('iir_sampled<double,'), si.plan.kernel_name()
@@ -82,7 +84,7 @@ def test_initial_level_and_carried_state():
     sos = butter(4, 0.02, output='sos')
     secs = [(r[:3], r[3:]) for r in sos]
     chans = [0.3 + wl.sum_channel(wf, 9, 40 + c) for c in range(2)]
-    grid = ('linspace', 0.0, 9 * wl.SPAN, 90000, False)
+    grid = ('linspace', 0.0, 9 * wl.SPAN, 140000, False)
     x = _samples(chans, grid)
     zi = np.array([0.1, -0.2, 0.05, 0.0])
     si = SampledIir(chans, grid, sos)
@@ -96,7 +98,7 @@ def test_initial_level_and_carried_state():
     # two halves of the grid, the state handed on == the whole grid
     g = _flatten.grid_from_desc(grid)
     halves, state = [], None
-    for lo, hi in ((0, 45001), (45001, 90000)):
+    for lo, hi in ((0, 70001), (70001, 140000)):
         sh = SampledIir(chans, _flatten.grid_slice(g, lo, hi), sos)
         assert sh.fused, sh.why_not
         y, state = sh.to_host(initial=0.3, zi=zi if state is None else state, return_zf=True)
@@ -105,7 +107,7 @@ def test_initial_level_and_carried_state():
     assert np.max(np.abs(np.concatenate(halves, axis=1) - got)) <= TOL
 
 
-@pytest.mark.parametrize('n,endpoint', [(32768, False), (32769, True), (100003, False), (312345, True)])
+@pytest.mark.parametrize('n,endpoint', [(65536, False), (65537, True), (100003, False), (312345, True)])
 def test_ragged_rows_piece_edges_inside_chunks_offsets_and_shifts(n, endpoint):
     """pieces far shorter and far longer than a 2048-sample sub-tile, gaps (zero pieces), a constant offset, a vstack
     with a time shift; rows that end inside a chunk / a sub-tile / a lane's block; the overridden last sample of an
@@ -127,6 +129,26 @@ def test_ragged_rows_piece_edges_inside_chunks_offsets_and_shifts(n, endpoint):
     assert np.max(np.abs(got - want)) <= TOL
     assert np.max(np.abs(zf - np.stack([_cascade(secs, row, 0.1)[1] for row in x]))) <= TOL
     si.close()
+
+
+def test_run_length_follows_the_scan_form_and_short_rows_fall_back():
+    """the dot-product form (transition powers of order 1: butter(4, 0.1)) runs 128 samples per lane and fuses from 32768
+    samples on; the sweep form (slow poles: butter(4, 0.03)) runs 256 per lane and needs 65536 -- shorter rows take
+    sampler + IIR, same numbers"""
+    chans = [wl.sum_channel(wf, 6, 1000 + c) for c in range(2)]
+    grid = ('linspace', 0.0, 6 * wl.SPAN, 40000, False)
+    x = _samples(chans, grid)
+    for sos, fused in ((butter(4, 0.1, output='sos'), True), (butter(4, 0.03, output='sos'), False)):
+        secs = [(r[:3], r[3:]) for r in sos]
+        si = SampledIir(chans, grid, sos)
+        assert si.fused == fused, si.why_not
+        if not fused:
+            assert 'four chunks' in si.why_not
+        else:
+            assert si.plan.kernel_name() == 'iir_sampled<double,2,2,true>'
+        want = np.stack([_cascade(secs, row)[0] for row in x])
+        assert np.max(np.abs(si.to_host() - want)) <= TOL * max(1.0, np.abs(want).max())
+        si.close()
 
 
 def test_float_rows():

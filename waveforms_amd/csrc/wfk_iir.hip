@@ -643,8 +643,9 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 #ifndef OPS_RUN
 #define OPS_RUN 128
 #endif
-#define OPS_ROUNDS (OPS_RUN / OP_LB)
-#define OPS_CHUNK (64 * OPS_RUN)
+#ifndef OPS_RUN_SWEEP
+#define OPS_RUN_SWEEP 256     // ... of plans whose scan is the sweep / double-double form (iir_sampled<..., PLAIN = false>)
+#endif
 #ifndef OPS_WAVES
 #define OPS_WAVES 2
 #endif
@@ -655,7 +656,7 @@ struct IirSampArgs {
   const DevChannel* channels;
   const DevPiece* pieces;
   const double* params;
-  const int32_t* chunk_first;   // [rows * nchunks] first piece overlapping each chunk of OPS_CHUNK samples
+  const int32_t* chunk_first;   // [rows * nchunks] first piece overlapping each chunk of 64 * RUN samples
   int64_t nchunks;
   double t0, step, last;
   int32_t has_last, pad;
@@ -784,16 +785,20 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
                                                   double post_add, int persist, unsigned* __restrict__ fault,
                                                   int spin_limit) {
   constexpr int DD = NSEC * ORD;       // state dimension (<= 4)
+  // samples per lane run: the dot-product form (PLAIN) is best at 128 (its weights are LDS reads per sample); the sweep /
+  // double-double form amortises its scans and look-back over runs twice as long (four first-order sections, 256 x 1e7,
+  // same box: 7.87 ms at 128, 7.01 at 256, 6.9 at 512; two biquads 7.06 / 7.20 / 7.67)
+  constexpr int RUN = PLAIN ? OPS_RUN : OPS_RUN_SWEEP;
   __shared__ __attribute__((aligned(16))) double s_par[OPS_PAR + 2 * (OP_LB + 1) + 2];
   __shared__ T tile[64][OP_LB / 2 + 1];
   __shared__ OpsPieces pd;
   // PLAIN: the run's end state from zero state as a DOT PRODUCT, f = sum_k W[k] x_k with W[k] = TL-step response to a
   // unit sample at position k (host, quad precision): DD independent fmas per sample instead of the sweep's 5 per
   // section in one dependent chain.  (Only where the transition powers have entries of order 1: no cancellation.)
-  __shared__ __attribute__((aligned(16))) double s_w[PLAIN ? OPS_RUN * 4 : 4];
+  __shared__ __attribute__((aligned(16))) double s_w[PLAIN ? RUN * 4 : 4];
   const int lane = threadIdx.x;
   if (PLAIN) {
-    for (int i = lane; i < OPS_RUN * 4; i += 64) s_w[i] = wdot[i];
+    for (int i = lane; i < RUN * 4; i += 64) s_w[i] = wdot[i];
   }
   const int row = (int)(blockIdx.x % (unsigned)rows);
   const DevChannel C = sa.channels[row];
@@ -805,8 +810,8 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
   t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
   const int64_t chunk = t;
   if (chunk >= nchunks) return;
-  const int64_t base = chunk * OPS_CHUNK, chunk_end = base + OPS_CHUNK;
-  const int jrun = lane * OPS_RUN;                             // first sample of this lane's run, relative to the chunk
+  const int64_t base = chunk * (64 * RUN), chunk_end = base + (64 * RUN);
+  const int jrun = lane * RUN;                             // first sample of this lane's run, relative to the chunk
   const int64_t left = n - base;
   const int nrel = (int)(left > (1 << 30) ? (1 << 30) : left); // samples of the row from the chunk's start (clamped)
   const double dbase = (double)(base + sa.i0);                 // exact (< 2^53)
@@ -854,7 +859,7 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
 #pragma unroll
   for (int i = 0; i < IIR_MAXD; ++i) z[i] = 0.0;
 #pragma unroll 1
-  for (int r = 0; r < OPS_ROUNDS; ++r) {
+  for (int r = 0; r < (RUN / OP_LB); ++r) {
     const int js = jrun + r * OP_LB;
     if (r * OP_LB >= nrel) break;                          // (wave-uniform: no lane has a sample in this round)
     T acc[OP_LB];
@@ -1003,7 +1008,7 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
   }
   const double bad = poisoned ? __builtin_nan("") : 0.0;
 #pragma unroll 1
-  for (int r = 0; r < OPS_ROUNDS; ++r) {
+  for (int r = 0; r < (RUN / OP_LB); ++r) {
     const int js = jrun + r * OP_LB;
     if (r * OP_LB >= nrel) break;                          // (wave-uniform)
     T acc[OP_LB];
@@ -1021,7 +1026,7 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
     if (zf && rest > 0 && rest <= OP_LB)
       for (int i = 0; i < DD; ++i) zf[(int64_t)row * DD + i] = z[i];
     // Store, in two halves of 16 samples per lane through the LDS tile: tile row l then holds samples
-    // l * OPS_RUN + 32 r + 16 h + [0, 16) of the chunk -- one 128-byte line; a wave instruction stores four rows.
+    // l * RUN + 32 r + 16 h + [0, 16) of the chunk -- one 128-byte line; a wave instruction stores four rows.
     // (The store phase's view of the lane index is opaque: left to itself the compiler computes the LDS addresses and
     // global offsets of this phase once, above the chunk loop, and spills them.)
     int lt = lane;
@@ -1033,14 +1038,14 @@ __global__ void __launch_bounds__(64, OPS_WAVES) iir_sampled(const IirCoef c, co
       __syncthreads();                                         // the previous half's stores have read the tile
       CH_EACH(HS, i) tile[lane][i] = acc[h * HS + i]; CH_END
       __syncthreads();
-      T* ys = y + (int64_t)rsub * OPS_RUN + r * OP_LB + h * HS + col;
+      T* ys = y + (int64_t)rsub * RUN + r * OP_LB + h * HS + col;
       if (chunk_end <= n) {
 #pragma unroll
-        for (int i = 0; i < 64 / RPI; ++i) ys[(int64_t)i * RPI * OPS_RUN] = tp[i * RPI * (HS + 1)];
+        for (int i = 0; i < 64 / RPI; ++i) ys[(int64_t)i * RPI * RUN] = tp[i * RPI * (HS + 1)];
       } else {
 #pragma unroll
         for (int i = 0; i < 64 / RPI; ++i)
-          if ((RPI * i + rsub) * OPS_RUN + r * OP_LB + h * HS + col < nrel) ys[(int64_t)i * RPI * OPS_RUN] = tp[i * RPI * (HS + 1)];
+          if ((RPI * i + rsub) * RUN + r * OP_LB + h * HS + col < nrel) ys[(int64_t)i * RPI * RUN] = tp[i * RPI * (HS + 1)];
       }
     CH_END
   }
@@ -1123,11 +1128,12 @@ struct wfk_iir_plan {
   double* op_pw1 = nullptr;
   double* op_lanep1 = nullptr;
   double* op_lanepU = nullptr;
-  // iir_sampled: a lane owns a run of OPS_RUN samples: TL = T1^(OPS_RUN / OP_LB), UL = TL^64
+  // iir_sampled: a lane owns a run of op_run samples: TL = T1^(op_run / OP_LB), UL = TL^64
   double* op_pwL = nullptr;          // TL^(2^k)
   double* op_lanepL = nullptr;       // TL^(l+1)
   double* op_lanepUL = nullptr;      // UL^(l+1)
-  double* op_wdot = nullptr;         // [OPS_RUN][4]: end state of a run from zero state per unit sample at position k
+  double* op_wdot = nullptr;         // [op_run][4]: end state of a run from zero state per unit sample at position k (dot-product form)
+  int op_run = 0;                    // samples per lane run of iir_sampled: OPS_RUN (dot-product form) | OPS_RUN_SWEEP
   bool op_plainL = false;
   unsigned* op_fault = nullptr;      // host memory, mapped: raised by a chunk whose look-back timed out
   unsigned* op_fault_dev = nullptr;  // ... its device address
@@ -1362,21 +1368,26 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
       const std::vector<quad> U1 = tables(T1, pw1, lanep1);    // U1 = T1^64: one chunk
       tables(U1, pwU, lanepU);                                  // U1^(l+1), l < 64: the look-back window
       std::vector<double> pwL, lanepL, pwUL, lanepUL;           // the same for the long runs of iir_sampled
-      {
+      // (runs of OPS_RUN samples; where their transition powers rule out the dot-product form, of OPS_RUN_SWEEP)
+      p->op_run = OPS_RUN;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        pwL.clear(); lanepL.clear(); pwUL.clear(); lanepUL.clear();
         std::vector<quad> TL = T1, nxt;
-        for (int k = 1; k < OPS_ROUNDS; ++k) { qmatmul(TL, T1, nxt, D); TL = nxt; }
+        for (int k = 1; k < p->op_run / OP_LB; ++k) { qmatmul(TL, T1, nxt, D); TL = nxt; }
         const std::vector<quad> UL = tables(TL, pwL, lanepL);
         tables(UL, pwUL, lanepUL);
         double tm = 0.0;
         for (size_t e = 0; e < lanepL.size(); e += 2) tm = std::max(tm, std::fabs(lanepL[e]));
         const char* dde = getenv("WFK_IIR_DD");
-        p->op_plainL = tm < 16.0 && !(dde && dde[0] == '1');
+        p->op_plainL = attempt == 0 && tm < 16.0 && !(dde && dde[0] == '1');
+        if (p->op_plainL || p->op_run == OPS_RUN_SWEEP) break;
+        p->op_run = OPS_RUN_SWEEP;
       }
-      std::vector<double> wdot((size_t)OPS_RUN * 4, 0.0);
-      for (int k = 0; k < OPS_RUN; ++k) {
+      std::vector<double> wdot((size_t)p->op_run * 4, 0.0);
+      for (int k = 0; k < p->op_run && p->op_plainL; ++k) {
         quad z[IIR_MAXD];
         for (int r = 0; r < IIR_MAXD; ++r) z[r] = 0;
-        for (int t = k; t < OPS_RUN; ++t) quad_step(c, t == k ? (quad)1 : (quad)0, z);
+        for (int t = k; t < p->op_run; ++t) quad_step(c, t == k ? (quad)1 : (quad)0, z);
         for (int r = 0; r < D && r < 4; ++r) wdot[(size_t)k * 4 + r] = (double)z[r];
       }
       double tmax = 0.0;                                        // largest entry of T1^1 .. T1^64 (hi words)
@@ -1509,7 +1520,8 @@ static int iir_apply_impl(wfk_iir_plan* p, const void* in_dev, int64_t in_stride
     // Few long rows: with one chunk per workgroup 2304 / rows chunks of a row are in flight, and a
     // look-back reads every one of them.  Below OP_DEPTH_ROWS rows the grid is op_depth persistent waves
     // per row instead (WFK_IIR_OP_DEPTH: experiments).
-    const int64_t nchunks = src ? (p->n + OPS_CHUNK - 1) / OPS_CHUNK : p->op_chunks;   // (iir_sampled: long chunks)
+    const int64_t ops_chunk = 64 * (int64_t)p->op_run;
+    const int64_t nchunks = src ? (p->n + ops_chunk - 1) / ops_chunk : p->op_chunks;   // (iir_sampled: long chunks)
     unsigned total = (unsigned)(nchunks * p->batch);
     int persist = 0;
     {
@@ -1682,9 +1694,10 @@ int wfk_chain_iir_plan_create(const wfk_program* prog, const wfk_grid* grid, int
     HostPlan H;
     std::string err;
     const int par_cap = OPS_PAR;     // doubles of LDS the kernel stages a piece's parameter block in
+    const int64_t ops_chunk = 64 * (int64_t)(first->op_run > 0 ? first->op_run : OPS_RUN);      // samples per chunk of the fused scan
     if (off && off[0] == '1') p->why = "disabled by WFK_CHAIN_UNFUSED";
     else if (!first->onepass) p->why = "the first IIR pass is not in the single-pass form (state dimension > 4, mixed orders, a short or a mid-sized batch of long rows)";
-    else if (p->n < 4 * (int64_t)OPS_CHUNK) p->why = "rows shorter than four chunks of the fused scan";
+    else if (p->n < 4 * ops_chunk) p->why = "rows shorter than four chunks of the fused scan";
     else if (wfk_compile_geom(prog, grid, 1, OP_LB, H, err) != WFK_OK) p->why = "geometry compile: " + err;
     else if (!H.lean) p->why = "plan is not fully fused (generic / direct terms, closing multipliers, or too many ops per piece)";
     else {
@@ -1697,7 +1710,7 @@ int wfk_chain_iir_plan_create(const wfk_program* prog, const wfk_grid* grid, int
     // lane read the record of its own piece: the blocks must fit, a chunk may overlap <= OPS_PMAX pieces, live pieces
     // are >= 32 samples long (a lane's 32-sample segment then meets at most two), and the live pieces of a CHUNK have
     // the same op shapes (op count, packed op words: the usual pulse train).  Anything else stays on sampler -> IIR.
-    const int64_t nch = (p->n + OPS_CHUNK - 1) / OPS_CHUNK;
+    const int64_t nch = (p->n + ops_chunk - 1) / ops_chunk;
     std::vector<int32_t> chunk_first;
     auto same_shape = [&](const DevPiece& x, const DevPiece& y) {
       const double* bx = H.params.data() + x.par_off;
@@ -1719,7 +1732,7 @@ int wfk_chain_iir_plan_create(const wfk_program* prog, const wfk_grid* grid, int
       for (int32_t c = 0; c < p->n_channels && p->why.empty(); ++c) {
         int32_t q = H.channels[c].piece_begin;
         for (int64_t k = 0; k < nch; ++k) {
-          const int64_t s1 = k * OPS_CHUNK, s2 = s1 + OPS_CHUNK;
+          const int64_t s1 = k * ops_chunk, s2 = s1 + ops_chunk;
           while (q < H.channels[c].piece_end - 1 && H.pieces[q].stop <= s1) ++q;
           chunk_first[(size_t)c * nch + k] = q;
           int64_t need = 0, cnt = 0;
@@ -1734,7 +1747,7 @@ int wfk_chain_iir_plan_create(const wfk_program* prog, const wfk_grid* grid, int
           }
           if (!p->why.empty()) break;
           if (need > par_cap) { p->why = "the parameter blocks of the pieces of one chunk do not fit its LDS buffer"; break; }
-          if (cnt > OPS_PMAX) { p->why = "more than 16 pieces in one chunk of the fused scan (8192 samples)"; break; }
+          if (cnt > OPS_PMAX) { p->why = "more than 16 pieces in one chunk of the fused scan (8192 | 16384 samples)"; break; }
         }
       }
     }
