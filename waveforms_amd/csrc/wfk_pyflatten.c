@@ -32,15 +32,20 @@ static int buf_push(Buf* b, const void* src, size_t n) {
   b->len += n;
   return 0;
 }
-#define PUSH(buf, type, value)                         \
-  do {                                                 \
-    type v_ = (type)(value);                           \
-    if (buf_push(&(buf), &v_, sizeof v_)) goto nomem;  \
+/* (the common case -- room left -- stays inline: the walk appends ~6 values per factor, 11 000 factors per channel) */
+#define PUSH(buf, type, value)                                      \
+  do {                                                              \
+    type v_ = (type)(value);                                        \
+    if ((buf).len + sizeof v_ <= (buf).cap) {                       \
+      memcpy((buf).p + (buf).len, &v_, sizeof v_);                  \
+      (buf).len += sizeof v_;                                       \
+    } else if (buf_push(&(buf), &v_, sizeof v_)) goto nomem;        \
   } while (0)
 
 /* a Python float (np.float64 is one) or int -> double; 0 on success, -1: anything else (error cleared) -- other
  * numeric types go to the Python walk: np.complex64 would answer __float__ by dropping its imaginary part */
-static int as_double(PyObject* o, double* out) {
+static inline int as_double(PyObject* o, double* out) {
+  if (PyFloat_CheckExact(o)) { *out = PyFloat_AS_DOUBLE(o); return 0; }      /* (no subtype walk for the usual case) */
   if (PyFloat_Check(o)) { *out = PyFloat_AS_DOUBLE(o); return 0; }
   if (!PyLong_Check(o) || PyBool_Check(o)) return -1;
   double v = PyLong_AsDouble(o);
@@ -89,6 +94,12 @@ static PyObject* flatten_members(PyObject* self, PyObject* args) {
     double last;
     if (as_double(PyTuple_GET_ITEM(bounds, np_ - 1), &last) || !(isinf(last) && last > 0)) { unsupported = 1; break; }
     for (Py_ssize_t ip = 0; ip < np_ && !unsupported; ++ip) {
+      /* (the walk is pointer chasing over objects touched for the first time: ask for the next piece's tuples early) */
+      if (ip + 1 < np_) {
+        PyObject* nx = PyTuple_GET_ITEM(seq, ip + 1);
+        __builtin_prefetch(nx);
+        __builtin_prefetch(PyTuple_GET_ITEM(bounds, ip + 1));
+      }
       double b;
       if (as_double(PyTuple_GET_ITEM(bounds, ip), &b)) { unsupported = 1; break; }
       PUSH(bound, double, b);
@@ -103,6 +114,10 @@ static PyObject* flatten_members(PyObject* self, PyObject* args) {
       for (Py_ssize_t it = 0; it < nt && !unsupported; ++it) {
         PyObject* term = PyTuple_GET_ITEM(terms, it);
         PyObject* amp = PyTuple_GET_ITEM(amps, it);
+        if (it + 1 < nt) {
+          __builtin_prefetch(PyTuple_GET_ITEM(terms, it + 1));
+          __builtin_prefetch(PyTuple_GET_ITEM(amps, it + 1));
+        }
         if (!PyTuple_Check(term) || PyTuple_GET_SIZE(term) != 2) { unsupported = 1; break; }
         PyObject* factors = PyTuple_GET_ITEM(term, 0);
         PyObject* powers = PyTuple_GET_ITEM(term, 1);
@@ -118,11 +133,24 @@ static PyObject* flatten_members(PyObject* self, PyObject* args) {
         if (PyTuple_GET_SIZE(powers) < nf) nf = PyTuple_GET_SIZE(powers);
         for (Py_ssize_t k = 0; k < nf; ++k) {
           PyObject* f = PyTuple_GET_ITEM(factors, k);
+          if (k + 1 < nf) {
+            __builtin_prefetch(PyTuple_GET_ITEM(factors, k + 1));
+            __builtin_prefetch(PyTuple_GET_ITEM(powers, k + 1));
+          }
           if (!PyTuple_Check(f) || PyTuple_GET_SIZE(f) < 2) { unsupported = 1; break; }
           PyObject* tid = PyTuple_GET_ITEM(f, 0);
           if (!PyLong_CheckExact(tid)) { unsupported = 1; break; }
-          const long id = PyLong_AsLong(tid);
-          if (id == -1 && PyErr_Occurred()) { PyErr_Clear(); unsupported = 1; break; }
+          long id;
+#if PY_VERSION_HEX < 0x030C0000
+          /* (type ids are small non-negative ints: one digit -- read it in place; CPython < 3.12 layout) */
+          if (Py_SIZE(tid) == 1) id = (long)((PyLongObject*)tid)->ob_digit[0];
+          else if (Py_SIZE(tid) == 0) id = 0;
+          else
+#endif
+          {
+            id = PyLong_AsLong(tid);
+            if (id == -1 && PyErr_Occurred()) { PyErr_Clear(); unsupported = 1; break; }
+          }
           if (id < 0 || id >= 64 || argc_tab[id] < 0) { unsupported = 1; break; }   /* not a plain native primitive */
           const long na = argc_tab[id];
           if (PyTuple_GET_SIZE(f) != na + 2) { unsupported = 1; break; }
