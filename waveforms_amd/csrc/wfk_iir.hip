@@ -631,13 +631,14 @@ __global__ void __launch_bounds__(64, OP_WAVES) iir_onepass(const IirCoef c, con
 //
 // What iir_onepass pays per 2048-sample chunk -- ticket, flag polls, aggregate loads: dependent memory round trips
 // that two waves per SIMD cannot hide (its 256 x 1e7 launch waits three quarters of its time) -- is paid here per chunk
-// of 8192: a lane owns a RUN of OPS_RUN = 128 consecutive samples, taken in four rounds of 32 with the sampler's op
-// state (phasor, Gaussian pair) and the filter state carried from round to round.  A sample costs ~10 VALU
+// of 64 RUN samples: a lane owns a RUN of consecutive samples -- OPS_RUN = 128 where pass 1 is a dot product (PLAIN),
+// OPS_RUN_SWEEP = 256 where it is the sweep (slow poles; double-double scans) -- taken in rounds of 32 with the sampler's
+// op state (phasor, Gaussian pair) and the filter state carried from round to round.  A sample costs ~10 VALU
 // instructions to evaluate, so the chunk is not kept between the two sweeps (that would be 64 KB per wave), it is
 // evaluated TWICE:
-//   pass 1  four rounds: evaluate 32, sweep on from the running state (zero at the run's start); then the in-wave
-//           scan of the 64 run states (TL = 128-step transition), aggregate, look-back (as iir_onepass);
-//   pass 2  four rounds again from the true state v_(l-1) + TL^l S_in: evaluate, sweep, transpose through LDS, store.
+//   pass 1  RUN / 32 rounds: evaluate 32, sweep on from the running state (zero at the run's start); then the in-wave
+//           scan of the 64 run states (TL = RUN-step transition), aggregate, look-back (as iir_onepass);
+//   pass 2  the rounds again from the true state v_(l-1) + TL^l S_in: evaluate, sweep, transpose through LDS, store.
 // All parameter blocks of the pieces a chunk overlaps are staged in LDS once per chunk (the host admits a plan only
 // if they fit).  Algorithmic traffic: the 8 (4) B/sample of the filtered output.
 #ifndef OPS_RUN
