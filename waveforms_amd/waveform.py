@@ -489,21 +489,24 @@ class WaveVStack(Waveform):
         return self._clone_meta(ret)
 
     def __add__(self, other):
-        ret = WaveVStack()
-        ret.wlist.extend(self.wlist)
+        # A sum keeps its members (reference waveform.py:771-785).  The result is a NEW stack with no pending shift and the
+        # offset the reference gives it: another stack's members join (both sides brought to absolute time first when
+        # their pending shifts differ) and the offsets add; a Waveform joins as one more member, moved back by this
+        # stack's pending shift; a number becomes the offset.
+        out = WaveVStack()
         if isinstance(other, WaveVStack):
-            if other.shift != self.shift:
-                ret.wlist = self._rshift(ret.wlist, self.shift)
-                ret.wlist.extend(self._rshift(other.wlist, other.shift))
-            else:
-                ret.wlist.extend(other.wlist)
-            ret.offset = self.offset + other.offset
+            aligned = other.shift == self.shift
+            mine = self.wlist if aligned else self._rshift(self.wlist, self.shift)
+            theirs = other.wlist if aligned else self._rshift(other.wlist, other.shift)
+            out.wlist = [*mine, *theirs]
+            out.offset = self.offset + other.offset
         elif isinstance(other, Waveform):
-            other = other << self.shift
-            ret.wlist.append((other.bounds, other.seq))
+            moved = other << self.shift
+            out.wlist = [*self.wlist, (moved.bounds, moved.seq)]
         else:
-            ret.offset += other
-        return self._clone_meta(ret)
+            out.wlist = list(self.wlist)
+            out.offset = out.offset + other
+        return self._clone_meta(out)
 
     def __radd__(self, v):
         return self + v
@@ -814,21 +817,26 @@ def interp(x, y) -> Waveform:
 
 def cut(wav: Waveform, start=None, stop=None, head=None, tail=None, min=None,
         max=None) -> Waveform:
-    offset = 0
+    # reference waveform.py:1443-1466: pin the level at one end (`head` at `start`; failing that `tail` at `stop`), gate
+    # the result to [start, stop), set the clip bounds -- always on a new Waveform (`+ 0` when nothing is pinned)
+    def level(t):
+        return wav(np.array([1.0 * t]))[0]
+
     if start is not None and head is not None:
-        offset = head - wav(np.array([1.0 * start]))[0]
+        lift = head - level(start)
     elif stop is not None and tail is not None:
-        offset = tail - wav(np.array([1.0 * stop]))[0]
-    wav = wav + offset
-    if start is not None:
-        wav = wav * (step(0) >> start)
-    if stop is not None:
-        wav = wav * ((1 - step(0)) >> stop)
+        lift = tail - level(stop)
+    else:
+        lift = 0
+    out = wav + lift
+    for edge, gate in ((start, step(0)), (stop, 1 - step(0))):
+        if edge is not None:
+            out = out * (gate >> edge)
     if min is not None:
-        wav.min = min
+        out.min = min
     if max is not None:
-        wav.max = max
-    return wav
+        out.max = max
+    return out
 
 
 def function(fun, *args, start=None, stop=None):
