@@ -46,6 +46,14 @@ static int buf_push(Buf* b, const void* src, size_t n) {
  * numeric types go to the Python walk: np.complex64 would answer __float__ by dropping its imaginary part */
 static inline int as_double(PyObject* o, double* out) {
   if (PyFloat_CheckExact(o)) { *out = PyFloat_AS_DOUBLE(o); return 0; }      /* (no subtype walk for the usual case) */
+#if PY_VERSION_HEX < 0x030C0000
+  if (PyLong_CheckExact(o)) {                                                /* powers: small ints, one digit read in place */
+    const Py_ssize_t sz = Py_SIZE(o);
+    if (sz == 0) { *out = 0.0; return 0; }
+    if (sz == 1) { *out = (double)((PyLongObject*)o)->ob_digit[0]; return 0; }
+    if (sz == -1) { *out = -(double)((PyLongObject*)o)->ob_digit[0]; return 0; }
+  }
+#endif
   if (PyFloat_Check(o)) { *out = PyFloat_AS_DOUBLE(o); return 0; }
   if (!PyLong_Check(o) || PyBool_Check(o)) return -1;
   double v = PyLong_AsDouble(o);
@@ -123,7 +131,9 @@ static PyObject* flatten_members(PyObject* self, PyObject* args) {
         PyObject* powers = PyTuple_GET_ITEM(term, 1);
         if (!PyTuple_Check(factors) || !PyTuple_Check(powers)) { unsupported = 1; break; }
         double re, im = 0.0;
-        if (PyComplex_Check(amp)) {
+        if (PyFloat_CheckExact(amp)) {
+          re = PyFloat_AS_DOUBLE(amp);
+        } else if (PyComplex_Check(amp)) {
           /* (isinstance(amp, complex): Python complex and np.complex128; np.complex64 is not one -> Python walk) */
           re = PyComplex_RealAsDouble(amp);
           im = PyComplex_ImagAsDouble(amp);
