@@ -151,6 +151,27 @@ def test_run_length_follows_the_scan_form_and_short_rows_fall_back():
         si.close()
 
 
+@pytest.mark.parametrize('n', [20000, 100000, 4097])
+def test_awg_rate_rows_through_the_chain_plan(n):
+    """Waveform.sample(filters=) at AWG sample rates (2 GS/s, 60-sample pulses: more than 16 pieces per chunk of the fused
+    scan): the chain plan runs wfk_sample_short + the IIR stage -- Gaussian + DRAG trains back to back and at 30 % duty,
+    flat tops with erf edges on an offset -- against the oracle's samples through SciPy, every single-pass shape"""
+    chans = [wl.awg_channel(wf, c, n, 2e9, duty30=(c == 1)) for c in range(3)]
+    chans.append(wl.awg_shape_channel(wf, 'flat_top', 3, n, 2e9) + 0.2)
+    grid = wl.awg_grid(n, 2e9)
+    x = _samples(chans, grid)
+    for shape in ('two_biquads', 'four_first_order', 'order3'):
+        secs = SHAPES[shape]
+        si = SampledIir(chans, grid, secs)
+        assert not si.fused and si.plan.kernel_name().startswith('wfk_sample_short<double,'), (si.plan.kernel_name(), si.why_not)
+        got, zf = si.to_host(initial=0.1, return_zf=True)
+        want = np.stack([_cascade(secs, row, 0.1)[0] for row in x])
+        assert np.max(np.abs(got - want)) <= TOL * max(1.0, np.abs(want).max()), shape
+        wzf = np.stack([_cascade(secs, row, 0.1)[1] for row in x])
+        assert np.max(np.abs(zf - wzf)) <= TOL * max(1.0, np.abs(wzf).max()), shape
+        si.close()
+
+
 def test_float_rows():
     secs = SHAPES['two_biquads']
     chans = [wl.sum_channel(wf, 20, 300 + c) for c in range(3)]
