@@ -28,11 +28,15 @@ FP32_TOL = 5e-5
 #   time lists, fused groups evaluated pointwise: the same 2.5e-10 admission on 2.4e-16 |t| rate, + the inline
 #       sincos / exp (2 ulp) -- worst of 16 000 soak scripts 1.9e-11
 #   time lists, libm tier (one device-libm call per factor on the caller's own times): 1e-11
-#   IIR stages (blocked scan against SciPy's sequential recurrence, any of the three execution forms): 1e-10
+#   IIR stages (blocked scan against SciPy's sequential recurrence, any of the three execution forms): 1e-10 for cascades
+#       of first- and second-order sections (what sample(filters=sos) and exp_decay_filter give); ONE section of order
+#       3 / 4 in direct form with clustered poles -- butter(4, 0.022) as a single (b, a) -- is ill-conditioned in any
+#       evaluation order: 5e-10 (iirchain_soak seed 12713: the scan 1.1e-10 from a long-double recursion, SciPy 1.7e-11)
 FP64_GRID_TOL = 1e-9
 FP64_TLIST_FUSED_TOL = 5e-10
 FP64_TLIST_LIBM_TOL = 1e-11
 FP64_IIR_TOL = 1e-10
+FP64_IIR_ORDER34_TOL = 5e-10
 
 
 def _ref_tolist_case(ns):          # reference tests/test_waveform.py:38-48

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from scipy.signal import butter, lfilter
 import cases
-from cases import FP32_TOL, FP64_IIR_TOL
+from cases import FP32_TOL, FP64_IIR_TOL, FP64_IIR_ORDER34_TOL
 import waveforms_amd as wf
 from oracle import c_oracle
 from waveforms_amd import _flatten, workloads as wl
@@ -71,7 +71,8 @@ for seed in range(first, first + count):
         want, wzf = zip(*[cascade(secs, r, initial, zi) for r in x])
         want, wzf = np.stack(want), np.stack(wzf)
         pk = max(1.0, float(np.abs(want).max(initial=0.0)))
-        for dt, tol in ((np.float64, TOL), (np.float32, FP32_TOL)):
+        tol64 = FP64_IIR_ORDER34_TOL if any(max(len(b), len(a)) - 1 >= 3 for b, a in secs) else TOL
+        for dt, tol in ((np.float64, tol64), (np.float32, FP32_TOL)):
             si = SampledIir(chans, grid, secs, None, dt)
             kn = si.plan.kernel_name().split('<')[0] + (' (+passes)' if 'IIR passes' in si.plan.kernel_name() else '')
             took[kn] = took.get(kn, 0) + 1
@@ -89,4 +90,4 @@ for seed in range(first, first + count):
         print('FAIL', bad[-1], flush=True)
     if (seed - first) % 100 == 99:
         print('...', seed - first + 1, 'rounds,', len(bad), 'failures, worst fp64 %.3g of peak, %.0f s' % (worst, time.time() - t0), flush=True)
-print('done %d rounds; %d failures %s; worst fp64 %.3g of peak (bound %g); kernels %s' % (count, len(bad), bad[:10], worst, TOL, took))
+print('done %d rounds; %d failures %s; worst fp64 %.3g of peak (bound %g; single sections of order 3 / 4: %g); kernels %s' % (count, len(bad), bad[:10], worst, TOL, FP64_IIR_ORDER34_TOL, took))
