@@ -31,7 +31,8 @@ FP32_TOL = 5e-5
 #   IIR stages (blocked scan against SciPy's sequential recurrence, any of the three execution forms): 1e-10 for cascades
 #       of first- and second-order sections (what sample(filters=sos) and exp_decay_filter give); ONE section of order
 #       3 / 4 in direct form with clustered poles -- butter(4, 0.022) as a single (b, a) -- is ill-conditioned in any
-#       evaluation order: 5e-10 (iirchain_soak seed 12713: the scan 1.1e-10 from a long-double recursion, SciPy 1.7e-11)
+#       evaluation order: 5e-10 (iirchain_soak seed 12713: the single-pass scan 1.1e-10 from a long-double recursion, SciPy
+#       1.7e-11; sections whose transition powers grow past 1e3 take the three-launch form since: 2.4e-11)
 FP64_GRID_TOL = 1e-9
 FP64_TLIST_FUSED_TOL = 5e-10
 FP64_TLIST_LIBM_TOL = 1e-11

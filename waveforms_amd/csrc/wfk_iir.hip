@@ -1411,7 +1411,11 @@ int wfk_iir_plan_create(int32_t n_sections, const int32_t* orders, const double*
         return iir_fail(WFK_ENOMEM, "IIR single-pass buffer allocation failed");
       }
       *p->op_fault = 0;
-      p->onepass = true;
+      // ONE section of order 3 / 4 whose transition powers grow past 1e3 (clustered poles: butter(4, 0.022) as a single
+      // (b, a), 3.2e3): the block start states this form re-injects every 32 samples as doubles cost it a digit against
+      // the three-launch form (iirchain_soak seed 12713, against a long-double recursion: 1.1e-10 vs 2.4e-11 of peak;
+      // SciPy 1.7e-11) -- such sections take that form unless WFK_IIR_ONEPASS=1 insists
+      p->onepass = (on && on[0] == '1') || !(orders[0] >= 3 && tmax > 1e3);
     }
   }
   *out = p;
