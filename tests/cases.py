@@ -38,6 +38,10 @@ FP64_TLIST_FUSED_TOL = 5e-10
 FP64_TLIST_LIBM_TOL = 1e-11
 FP64_IIR_TOL = 1e-10
 FP64_IIR_ORDER34_TOL = 5e-10
+#   FIR stage alone (LDS-FFT / rocFFT overlap-save against the time-domain definition, random kernels up to 7000 taps): 1e-11
+#   IIR stage alone on RANDOM stable sections of order <= 9 (real poles up to 0.999, tools/stage_soak.py): the contract, 1e-9
+FP64_FIR_TOL = 1e-11
+FP64_IIR_RANDOM_TOL = 1e-9
 
 
 def _ref_tolist_case(ns):          # reference tests/test_waveform.py:38-48

@@ -8,6 +8,7 @@ import numpy as np
 import waveforms_amd as ours
 from oracle import np_oracle, c_oracle
 from waveforms_amd import _flatten
+from cases import FP32_TOL, FP64_GRID_TOL, FP64_TLIST_FUSED_TOL
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 gpu = len(sys.argv) > 2 and sys.argv[2] == 'gpu'
@@ -78,7 +79,7 @@ for it in range(count):
             # the same times as an explicit list (time-list tier: pointwise fused ops / device libm)
             ptl = _engine.Plan(_flatten.flatten([w]), t=t)
             e4 = float(np.max(np.abs(ptl.run_host(np.complex128 if cplx else np.float64)[0] - want))) / pk
-            if not (e1 <= 1e-9 and e2 <= 1e-9 and e3 <= 2e-4 and e4 <= 1e-10):
+            if not (e1 <= FP64_GRID_TOL and e2 <= FP64_GRID_TOL and e3 <= FP32_TOL and e4 <= FP64_TLIST_FUSED_TOL):
                 bad.append((it, e1, e2, e3, e4)); print('FAIL', bad[-1], flush=True)
         else:
             wr, _ = build(ref, refw, np.random.default_rng(88_000 + it))
