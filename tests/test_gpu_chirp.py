@@ -150,3 +150,34 @@ def test_exponential_and_hyperbolic_chirps_at_awg_rates_are_short_tier_multiplie
     assert '16,4>' not in off.kernel_name()
     ora = c_oracle.eval_grid(_flatten.flatten([w]), _flatten.grid_from_desc(grid))
     assert np.max(np.abs(off.run_host(np.float64) - ora)) <= 1e-9
+
+
+@pytest.mark.parametrize('t0', [3e-3, -2e-3, 1e-2])
+@pytest.mark.parametrize('rate,n', [(2.4e9, 10477), (2e9, 30000), (1e8, 400000)])
+def test_linear_chirps_far_from_t_zero(t0, rate, n):
+    """Linear chirps milliseconds from t = 0 (tools/chirp_awg_soak.py, seed 5113: 4.6e-9 of peak before the fix).  The
+    fusion pass had expanded the quadratic phase about t' = 0 -- K t'^2 + W t' - Psi, three terms of 1e10 rad each 3 ms
+    out that cancel to the 80-bit rounding of the host's long double, 5e-9 rad; it is expanded about the chirp's own
+    shift now (FceGroup::corg).  Fine-grid pieces (lean family 2) and AWG-rate pieces (short tier), under squares,
+    cosine pulses and an extra carrier, real and complex amplitudes."""
+    rng = np.random.default_rng(int(abs(t0) * 1e6) + n)
+    span = n / rate
+    w = wf.zero()
+    npulse = 24
+    slot = span / npulse
+    for k in range(npulse):
+        width = slot * rng.uniform(0.5, 0.9)
+        f0 = rng.uniform(2e7, 1.2e8) * rate / 2.4e9
+        ch = wf.chirp(f0, f0 * rng.uniform(1.3, 2.5), width, rng.uniform(0, 6))
+        env = k % 3
+        p = ch * wf.square(width * 0.9) if env == 0 else (ch * wf.cosPulse(width) if env == 1 else ch * wf.cosPulse(width) * wf.cos(2 * pi * rng.uniform(-5e7, 5e7) * rate / 2.4e9))
+        amp = rng.uniform(0.2, 1) if k % 4 else complex(rng.uniform(-1, 1), rng.uniform(-1, 1))
+        w = w + ((amp * p) >> (t0 + (k + 0.5) * slot))
+    prog = _flatten.flatten([w])
+    g = _flatten.grid_from_desc(('arange', t0, t0 + span, 1.0 / rate))
+    plan = _engine.Plan(prog, grid=g)        # (fused where max |f| x ulp(t) allows it, device libm on the exact times elsewhere)
+    ora = c_oracle.eval_grid(prog, g, True)
+    pk = max(1.0, float(np.abs(ora).max()))
+    # (the reference's own rounding of t - shift is inside this: a fused chirp is admitted while max |f| x ulp(t) <= 2.5e-10)
+    assert np.max(np.abs(plan.run_host(np.complex128) - ora)) <= 6e-10 * pk, plan.kernel_name(np.complex128)
+    assert np.max(np.abs(plan.run_host(np.complex64) - ora)) <= FP32_TOL * pk

@@ -109,7 +109,9 @@ struct FceGroup {
   int own_kind = 0;             // lean kernel: this plain carrier group carries an envelope of its own (2 table, 3 mollifier) ...
   int32_t own_f = -1;           // ... the program factor of it (WFK_FCE_OWNMUL)
   bool fmul_own = false;        // short tier: the multiplier belongs to the ONE group in front of it (envelope x carrier as one op)
-  long double K = 0;            // chirp: the phase is K t'^2 + W t' - psi_ref (W, psi_ref as for a plain carrier)
+  long double K = 0;            // chirp: the phase is K u^2 + W u - psi_ref, u = t' - corg (W, psi_ref as for a plain carrier)
+  long double corg = 0;         // chirp: the origin its phase polynomial is expanded about (the chirp's own shift: about t' = 0
+                                // the three terms are 1e10 rad each 3 ms from t = 0 and cancel to 80-bit rounding, 5e-9 rad)
   long double Wl = 0;           // chirp: W before its rounding to double (|W| ~ 2 K |shift|: 2^-53 of it times t' shows in the phase)
   bool chirp = false;
   double tref = 0;              // chirp: reference time inside the piece (the device works in t' - tref)
@@ -711,7 +713,13 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     bool has_lin = false, has_env = false, env32 = false;
     double slin = 0, sigma = 0, sg = 0;
     double first_cos_shift = 0;
-    struct Car { long double c, W, Psi, K = 0.0L; };   // c * cos(K t'^2 + W t' - Psi),  t' = t - tshift
+    // c * cos(K u^2 + W u - Psi),  u = t' - o,  t' = t - tshift; o = 0 for every plain carrier (K == 0), a chirp's own
+    // shift for a chirp -- and for whatever it has been multiplied with
+    struct Car { long double c, W, Psi, K = 0.0L, o = 0.0L; };
+    auto rebase = [](Car r, long double o_new) -> Car {     // the same carrier expanded about another origin
+      const long double d = o_new - r.o;                    // t' - r.o = (t' - o_new) + d
+      return Car{r.c, r.W + 2 * r.K * d, r.Psi - r.K * d * d - r.W * d, r.K, o_new};
+    };
     struct ExpV { long double c, a, b; };    // c * exp(a t' + b): EXP factors, COSH / SINH as two of them
     SmallVec<ExpV, 8> evs;
     evs.push_back({1.0L, 0.0L, 0.0L});
@@ -727,10 +735,15 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       if (cars.empty()) { for (const Car& r : f) cars.push_back(r); return true; }
       if (cars.size() * f.size() * 2 > 32) return false;
       SmallVec<Car, 32> nx;
-      for (const Car& q : cars)
-        for (const Car& r : f) {
-          nx.push_back({q.c * r.c / 2, q.W + r.W, q.Psi + r.Psi, q.K + r.K});
-          nx.push_back({q.c * r.c / 2, q.W - r.W, q.Psi - r.Psi, q.K - r.K});
+      for (const Car& q0 : cars)
+        for (const Car& r0 : f) {
+          Car q = q0, r = r0;
+          if (q.o != r.o) {                  // (never for plain carriers: both at 0)
+            if (q.K != 0.0L) r = rebase(r, q.o);
+            else q = rebase(q, r.o);
+          }
+          nx.push_back({q.c * r.c / 2, q.W + r.W, q.Psi + r.Psi, q.K + r.K, q.o});
+          nx.push_back({q.c * r.c / 2, q.W - r.W, q.Psi - r.Psi, q.K - r.K, q.o});
         }
       cars.swap(nx);
       return true;
@@ -834,7 +847,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           const long double W0 = 2 * PI * (long double)a[0];
           ++ncos;
           ++ncos;      // (never a single COS factor: the group's phase reference is the term's own)
-          if (!times({{1.0L, W0 - 2 * Kq * sh, -(Kq * sh * sh - W0 * sh + (long double)a[3] - PI / 2), Kq}})) return false;
+          if (!times({{1.0L, W0, -((long double)a[3] - PI / 2), Kq, (long double)sh}})) return false;
           break;
         }
         case WFK_DRAG: {
@@ -874,7 +887,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     for (const Car& q : cars) {
       if (q.K != 0.0L) {
         // a chirp: largest instantaneous frequency over the piece; no rounding correction for it
-        const double wmax = (double)std::max(fabsl(q.W + 2 * q.K * tpa), fabsl(q.W + 2 * q.K * tpb));
+        const double wmax = (double)std::max(fabsl(q.W + 2 * q.K * (tpa - q.o)), fabsl(q.W + 2 * q.K * (tpb - q.o)));
         if (!std::isfinite(wmax) || !rate_safe(wmax, s0, s1)) return false;
         continue;
       }
@@ -951,7 +964,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       for (const CosF& cf : cosf) thm = std::max(thm, cf.thmax);
       const bool heavy = 2.3e-16 * thm * weight > WFK_JITTER_TOL;   // its own phase rounding must be mimicked
       for (FceGroup& g : staged)
-        if (g.W == W && (double)g.K == (double)q.K && g.imag == imag && g.has_env == has_env && g.has_exp == has_exp &&
+        if (g.W == W && (double)g.K == (double)q.K && g.corg == q.o && g.imag == imag && g.has_env == has_env && g.has_exp == has_exp &&
             (!has_env || (g.sigma == sigma && g.sg == sg))) {
           // a corrected group mimics ONE reference factor: a heavy term with another factor founds
           // its own group (same carrier, own op) instead of joining
@@ -964,7 +977,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         G = &staged.back();
         G->W = W; G->has_env = has_env; G->has_exp = has_exp; G->sigma = sigma; G->sg = sg; G->env32 = env32;
         G->imag = imag;
-        G->K = q.K; G->chirp = is_chirp; G->Wl = q.W;
+        G->K = q.K; G->chirp = is_chirp; G->Wl = q.W; G->corg = q.o;
         G->corr = !is_chirp && W != 0.0 && !rate_safe(W, s0, s1);
         G->wm = wm; G->sm = sm;
         G->sref = W == 0.0 ? 0.0 : (ncos == 1 ? cs[0] : (double)(q.Psi / q.W));
@@ -1194,7 +1207,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       // phase about tref:  K tau^2 + W' tau + phi0,  tau = t' - tref;  the per-stride rotation advances by
       // the constant phasor exp(i 2 K D^2)
       const long double PI2 = 6.283185307179586476925286766559005768L;
-      const long double tr = G.tref;
+      const long double tr = G.tref - G.corg;           // the reference time, from the origin of the phase polynomial
       rec[WFK_FCE_W] = (double)(G.Wl + 2 * G.K * tr);
       rec[WFK_FCE_SREF] = G.tref;
       rec[WFK_FCE_WM] = (double)G.K;
@@ -1405,8 +1418,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           //   th0 + k d1 + k^2 d2,  th0 = K x0^2 + W x0 - psi_ref,  d1 = (2 K x0 + W) dt,  d2 = K dt^2
           // [1] th0 / pi (reduced), [2] d1 / pi, [12] d2 / pi, [3] / [4] (cos, sin)(2 d2): the constant the step phasor advances by
           const long double dt = (long double)grid->step;
-          const long double th0 = G.K * x0 * x0 + G.Wl * x0 - G.psi_ref;
-          const long double d1 = (2 * G.K * x0 + G.Wl) * dt, d2 = G.K * dt * dt;
+          const long double xo = x0 - G.corg;           // from the origin of the phase polynomial (the chirp's own shift)
+          const long double th0 = G.K * xo * xo + G.Wl * xo - G.psi_ref;
+          const long double d1 = (2 * G.K * xo + G.Wl) * dt, d2 = G.K * dt * dt;
           o[1] = (double)remainderl(th0 / PIl, 2.0L);
           o[2] = (double)(d1 / PIl);
           o[12] = (double)(d2 / PIl);
