@@ -348,3 +348,25 @@ def test_linear_chirps_at_awg_rates_run_on_the_short_tier(monkeypatch):
     off = _engine.Plan(prog, grid=g)
     assert not off.kernel_name(np.complex128).startswith('wfk_sample_short<double,true,false,16,1>') or ' + ' in off.kernel_name(np.complex128)
     assert np.max(np.abs(off.run_host(np.complex128) - ref)) <= 1e-9 * pk
+
+
+@pytest.mark.parametrize('shape', ['flat_top', 'linear_chirp', 'ten_tones', 'exp_chirp'])
+def test_bench_awg_shapes_tiled_batches_against_the_oracle(shape):
+    """the `also.awg_shapes` workloads as bench.py launches them -- BatchSampler with tiled copies -- at a size the oracle
+    finishes in a second: every row (copies included) against its channel, fp64 and fp32"""
+    import torch
+    n = 30000
+    chans = [wl.awg_shape_channel(wf, shape, c, n, 2e9) for c in range(5)]
+    grid = wl.awg_grid(n, 2e9)
+    ref = c_oracle.eval_grid(_flatten.flatten(chans), _flatten.grid_from_desc(grid))
+    pk = max(1.0, float(np.abs(ref).max()))
+    for tdt, tol in ((torch.float64, cases.FP64_GRID_TOL), (torch.float32, FP32_TOL)):
+        bs = BatchSampler(chans, grid, tile=3)
+        out = torch.empty((bs.n_channels, bs.n), dtype=tdt, device='cuda')
+        bs.launch_torch(out)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().astype(np.float64)
+        assert bs.plan.kernel_name().startswith('wfk_sample_short<'), bs.plan.kernel_name()
+        for r in range(bs.n_channels):
+            assert np.max(np.abs(got[r] - ref[r % 5])) <= tol * pk, (shape, r, str(tdt))
+        bs.close()
