@@ -139,9 +139,10 @@ def test_every_case_fused_and_unfused_agree_on_scattered_times(name):
 
 
 def test_far_from_the_origin_is_fused_only_where_the_phase_noise_allows():
-    # 0.4 ms out under a 300 MHz carrier: W |t| = 7.5e5 rad -> ulp-level phase noise 1.8e-10: fused;
-    # 4 ms out: 1.8e-9 -> the terms stay on libm at the exact times (what the reference computes)
-    for t0, fused in ((0.4e-3, True), (4e-3, False)):
+    # 0.1 ms out under a 300 MHz carrier: W |t| = 1.9e5 rad -> ulp-level phase noise 4.5e-11, inside the budget the three
+    # terms of the pulse share (2.5e-10 / 3): fused; 0.4 ms (1.8e-10) and 4 ms out (1.8e-9): the terms stay on libm at the
+    # exact times (what the reference computes)
+    for t0, fused in ((0.1e-3, True), (0.4e-3, False), (4e-3, False)):
         I, _ = wf.mixing(wf.gaussian(200e-9) >> (t0 + 300e-9), freq=300e6, phase=0.3, DRAGScaling=1e-10)
         t = np.sort(t0 + np.random.default_rng(1).uniform(0, 600e-9, 40_000))
         got, name, info = run([I], t)

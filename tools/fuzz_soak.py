@@ -1,6 +1,8 @@
 """Long differential fuzz (not part of the suite): random scripts x grids, HIP vs the C oracle.
-usage: python tools/fuzz_soak.py [first_seed] [count] [awg]   -> prints failing seeds
-(awg: pulse trains on 1-5 GS/s grids, tests/cases.py random_awg_channel; also counts the tiers taken)"""
+usage: python tools/fuzz_soak.py [first_seed] [count] [awg | far | awgfar]   -> prints failing seeds
+(awg: pulse trains on 1-5 GS/s grids, tests/cases.py random_awg_channel; also counts the tiers taken;
+ far: the same scripts and grids moved 10 us .. 10 ms away from t = 0 -- the generators place everything within a few
+ pulse widths of the origin, where no expansion about t = 0 can lose anything)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -13,13 +15,18 @@ from waveforms_amd import _engine, _flatten
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-awg = len(sys.argv) > 3 and sys.argv[3] == 'awg'
+awg = len(sys.argv) > 3 and sys.argv[3] in ('awg', 'awgfar')
+far = len(sys.argv) > 3 and sys.argv[3] in ('far', 'awgfar')
 tiers = {}
 bad, t0 = [], time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(10_000 + seed)
     try:
         ch, grid = cases.random_awg_channel(wf, rng) if awg else cases.random_channel(wf, rng)
+        if far:
+            T = float(rng.choice([1e-5, 1e-4, 1e-3, 3e-3, -2e-3, 1e-2]))
+            ch = ch >> T
+            grid = (grid[0], grid[1] + T, grid[2] + T) + tuple(grid[3:])
         prog = _flatten.flatten([ch])
         g = _flatten.grid_from_desc(grid)
         ora = c_oracle.eval_grid(prog, g)[0]
