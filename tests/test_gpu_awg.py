@@ -370,3 +370,66 @@ def test_bench_awg_shapes_tiled_batches_against_the_oracle(shape):
         for r in range(bs.n_channels):
             assert np.max(np.abs(got[r] - ref[r % 5])) <= tol * pk, (shape, r, str(tdt))
         bs.close()
+
+
+@pytest.mark.parametrize('t0', [1e-3, -2e-3, 1e-2])
+def test_pulse_trains_milliseconds_from_zero_stay_on_the_short_tier(t0):
+    """AWG-rate rows far from t = 0 (a 1 ms sequence at 2 GS/s): W |t| ulp is past the rounding budget, the carriers take
+    the per-sample grid-rounding correction -- family 6 of the short tier (wfk_short_dev.h: short_op_corr; before it such
+    plans fell to the pointwise tier: 14.2 -> 1.3 ms for 128 rows x 2e6).  Real, complex and float launches, an endpoint
+    grid (overridden last sample), a time slice of the grid (wfk_grid.i0 != 0), clip, tiled copies; and the fallback for
+    what family 6 does not hold (a channel with a pending shift, flat tops)."""
+    import torch
+    rate, n = 2e9, 40000
+    rng = np.random.default_rng(3)
+    def train(cplx):
+        w = wf.zero()
+        for k in range(n // 60 - 1):
+            I, Q = wf.mixing(wf.gaussian(20e-9), freq=rng.uniform(-3e8, 3e8), phase=rng.uniform(0, 6), DRAGScaling=1e-10)
+            amp = complex(rng.uniform(-1, 1), rng.uniform(-1, 1)) if (cplx and k % 3 == 0) else rng.uniform(0.2, 1)
+            w = w + ((amp * (I if k % 2 else Q)) >> (t0 + (k + 0.5) * 30e-9))
+        return w
+    chans = [train(False), train(True), train(False)]
+    chans[2].min, chans[2].max = -0.3, 0.5
+    for grid in (('arange', t0, t0 + n / rate, 1 / rate), ('linspace', t0, t0 + (n - 1) / rate, n, True)):
+        prog = _flatten.flatten(chans)
+        g = _flatten.grid_from_desc(grid)
+        plan = _engine.Plan(prog, grid=g)
+        assert plan.kernel_name(np.complex128) == 'wfk_sample_short<double,true,false,16,6>' and plan.info.n_generic == 0, plan.kernel_name(np.complex128)
+        ora = c_oracle.eval_grid(prog, g, True)
+        pk = max(1.0, float(np.abs(ora).max()))
+        assert np.max(np.abs(plan.run_host(np.complex128) - ora)) <= cases.FP64_GRID_TOL * pk
+        assert np.max(np.abs(plan.run_host(np.float64) - ora.real)) <= cases.FP64_GRID_TOL * pk
+        assert np.max(np.abs(plan.run_host(np.complex64) - ora)) <= FP32_TOL * pk
+        assert plan.kernel_name(np.float32) == 'wfk_sample_short<float,false,false,16,6>'
+        # a slice of the grid is a grid of its own: the same samples
+        lo, hi = 12345, 31000
+        ps = _engine.Plan(prog, grid=_flatten.grid_slice(g, lo, hi))
+        assert ps.kernel_name() == 'wfk_sample_short<double,false,false,16,6>'
+        assert np.max(np.abs(ps.run_host(np.float64) - ora.real[:, lo:hi])) <= cases.FP64_GRID_TOL * pk
+        # without the correction (WFK_NO_SHORT_CORR=1) the plan leaves the tier and stays exact
+        os.environ['WFK_NO_SHORT_CORR'] = '1'
+        try:
+            pn = _engine.Plan(prog, grid=g)
+        finally:
+            del os.environ['WFK_NO_SHORT_CORR']
+        assert not pn.kernel_name().endswith(',6>')
+        assert np.max(np.abs(pn.run_host(np.float64) - ora.real)) <= cases.FP64_GRID_TOL * pk
+    # tiled copies through the batched API
+    bs = BatchSampler(chans[:1], ('arange', t0, t0 + n / rate, 1 / rate), tile=3)
+    out = torch.empty((bs.n_channels, bs.n), dtype=torch.float64, device='cuda')
+    bs.launch_torch(out)
+    torch.cuda.synchronize()
+    ref0 = c_oracle.eval_grid(_flatten.flatten(chans[:1]), _flatten.grid_arange(t0, t0 + n / rate, 1 / rate))[0]
+    assert np.max(np.abs(out.cpu().numpy() - ref0[None, :])) <= cases.FP64_GRID_TOL * max(1.0, np.abs(ref0).max())
+    bs.close()
+    # what family 6 does not hold goes back to the other tiers, exact all the same
+    shifted = wf.WaveVStack([chans[0]]) >> 3e-9
+    flat = chans[0] + ((wf.square(30e-9, edge=4e-9) * wf.cos(2 * np.pi * 2.1e8)) >> (t0 + 5e-6))
+    for w in (shifted, flat):
+        prog = _flatten.flatten([w])
+        g = _flatten.grid_arange(t0, t0 + n / rate, 1 / rate)
+        plan = _engine.Plan(prog, grid=g)
+        assert not plan.kernel_name().endswith(',6>'), plan.kernel_name()
+        ora = c_oracle.eval_grid(prog, g)
+        assert np.max(np.abs(plan.run_host(np.float64) - ora)) <= cases.FP64_GRID_TOL * max(1.0, float(np.abs(ora).max()))

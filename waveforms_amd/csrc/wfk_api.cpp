@@ -448,6 +448,9 @@ static int plan_launch_part(wfk_plan* p, void* out_dev, int64_t ch_stride, int o
     sa.accumulate = (flags & WFK_ACCUMULATE) ? 1 : 0;
     sa.lds_samples = p->h.s_lds_samples;
     sa.fam = p->h.short_fam;
+    sa.t0 = p->h.t0; sa.last = p->h.last;
+    sa.dlast = p->h.has_last ? (double)(p->h.i0 + p->h.n - 1) : -1.0;
+    sa.di0 = (double)p->h.i0;
     { const char* e = std::getenv("WFK_SH_NO_PK"); sa.pk = (e && e[0] == '1') ? 0 : 1; }
     sa.step = p->h.step;
     sa.pool = p->d_pool;

@@ -133,6 +133,7 @@ struct BlockBuilder {
 
 }  // namespace
 
+static thread_local bool g_no_short_corr = false;   // second attempt at a short plan whose corrected carriers met ops family 6 does not hold
 static thread_local bool g_no_short_fmul = false;   // the FIR chain's sampler plan: fir_short has no table / mollifier multipliers, such pieces stay with the general kernel
 void wfk_internal_no_short_fmul(bool on) { g_no_short_fmul = on; }
 static thread_local bool g_no_chirp = false;   // second compile of a plan that mixes corrected carriers and chirps
@@ -210,6 +211,14 @@ int wfk_compile(const wfk_program* P, const wfk_grid* grid, const double* tlist,
   // compiled for the contiguous-lane geometry of wfk_short.hip first; a piece that tier cannot take
   // (generic terms, erf edges, corrected carriers) sends the whole plan back to the standard tiers.
   int rc = compile_impl(P, grid, tlist, n_tlist, H, err, true, 64, 0, -1);
+  if (rc == WFK_OK && H.shortp && H.short_corr && H.short_fam != 6) {
+    // corrected carriers next to closing ops / chirps / tables: no family of the short tier holds both -- the attempt
+    // again without the tier's correction (those carriers' pieces then go the way they went before family 6)
+    g_no_short_corr = true;
+    H = HostPlan();
+    rc = compile_impl(P, grid, tlist, n_tlist, H, err, true, 64, 0, -1);
+    g_no_short_corr = false;
+  }
   const bool gave_up = rc == WFK_RETRY_STD;
   const double mean_len = H.mean_piece_len;      // (of the first compile: the later ones do not take the short-tier decision)
   if (rc == WFK_RETRY_STD) rc = compile_impl(P, grid, tlist, n_tlist, H, err, true);
@@ -286,6 +295,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   const char* const env_tlsmall_limit = std::getenv("WFK_TLSMALL_LIMIT");
   const bool env_no_short_xchirp = std::getenv("WFK_NO_SHORT_XCHIRP") != nullptr;
   const bool env_no_short_erftab = std::getenv("WFK_NO_SHORT_ERFTAB") != nullptr;
+  const bool env_no_short_corr = std::getenv("WFK_NO_SHORT_CORR") != nullptr || g_no_short_corr;
   // validation / A-B switch: evaluate every factor with device libm even on a grid
   const char* nofast_env = std::getenv("WFK_DISABLE_FAST");
   const bool nofast = nofast_env && nofast_env[0] == '1';
@@ -480,7 +490,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
   // after the correction is d^2 / 2.  (fl(x - s_m) is not exact when the carrier is referenced to
   // t = 0, as mixing()'s is: what the subtraction rounds away is recovered with a TwoSum.)
   const char* nocorr_env = std::getenv("WFK_DISABLE_CORR");
-  const bool corr_enabled = allow_corr && !shortm && !H.tlist && !(nocorr_env && nocorr_env[0] == '1');
+  // (short tier: family 6 evaluates corrected carriers of degree <= 1 on channels without a pending shift)
+  const bool corr_enabled = allow_corr && (!shortm || !env_no_short_corr) && !H.tlist && !(nocorr_env && nocorr_env[0] == '1');
   bool piece_corr_ok = true;   // cleared for the second attempt at a piece that turned out not to be lean
   const char* nochirp_env = std::getenv("WFK_DISABLE_CHIRP");
   const bool chirp_base = !H.tlist && ns_override == 0 && !g_no_chirp && !(nochirp_env && nochirp_env[0] == '1');
@@ -905,8 +916,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         continue;
       }
       if (!rate_safe_n((double)q.W, s0, s1)) {
-        if (shortm) H.short_needs_corr = true;
-        if (!corr_safe((double)q.W, s0, s1)) return false;
+        if (shortm && (tshift != 0.0 || p > 1 || env_no_short_corr || !corr_enabled)) {
+          H.short_needs_corr = true;       // (only the lean kernel corrects these: a shifted channel, a polynomial of degree > 1)
+          return false;
+        }
+        if (!corr_safe((double)q.W, s0, s1)) { if (shortm) H.short_needs_corr = true; return false; }
         any_corr = true;
       }
     }
@@ -1307,7 +1321,7 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     int32_t rec_len = 0;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       if (gi > 0 && own_pair(gi - 1)) continue;
-      rec_len += (groups[gi].deg > 1 || groups[gi].fmul || groups[gi].chirp) ? WFK_SH_OP3 : WFK_SH_OP1;
+      rec_len += (groups[gi].deg > 1 || groups[gi].fmul || groups[gi].chirp || groups[gi].corr) ? WFK_SH_OP3 : WFK_SH_OP1;
     }
     // one carrier (or a constant) under a flat-top edge of at most WFK_SH_ERFTAB samples: ONE own-term op over the edge's
     // sampled table (erf_table above), read at whole knots -- position k, step 1 (not for the FIR chain's sampler plan:
@@ -1425,8 +1439,9 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         }
         const int env = G.has_exp ? 2 : (G.has_env ? 1 : 0);
         // (a chirp: degree field 2 -- a 16-double record -- and bit 9; its polynomials are of degree <= 1)
-        const uint64_t word = (uint64_t)(uint32_t)((G.chirp ? 2 : (G.deg & 3)) | (((G.W != 0.0 || G.chirp) ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (env << 4) |
-                                                   (&G == &groups.back() ? WFK_SH_LAST : 0) | (G.chirp ? 512 : 0)) |
+        // (a corrected carrier: degree field 2 as well -- a 16-double record --, bit 12, [12..15] w_m, s_m, W, x_ref)
+        const uint64_t word = (uint64_t)(uint32_t)(((G.chirp || G.corr) ? 2 : (G.deg & 3)) | (((G.W != 0.0 || G.chirp) ? 1 : 0) << 2) | ((G.imag ? 1 : 0) << 3) | (env << 4) |
+                                                   (&G == &groups.back() ? WFK_SH_LAST : 0) | (G.chirp ? 512 : 0) | (G.corr ? 4096 : 0)) |
                               ((uint64_t)(uint32_t)r0 << 32);
         std::memcpy(&o[0], &word, sizeof word);
         if (G.chirp) {
@@ -1445,7 +1460,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           H.short_has_fmul = true;      // (an op fir_short does not evaluate: the chain's sampler plan keeps such pieces off the short tier)
           H.short_fam = std::max(H.short_fam, 1);
         } else if (G.W != 0.0) {
-          const long double th0 = (long double)G.W * x0 - G.psi_ref;
+          // (a corrected carrier is referenced to a time inside its piece with psi_ref = W_exact s_ref: its phase is
+          //  W (x - s_ref) with the ROUNDED W the kernel rotates by -- W x0 - psi_ref would put the rounding of W times
+          //  |t| into the seed: 1.3e-8 rad at t = -122 s, the far golden case 31)
+          const long double th0 = G.corr ? (long double)G.W * (x0 - (long double)G.sref) : (long double)G.W * x0 - G.psi_ref;
           o[1] = (double)remainderl(th0 / PIl, 2.0L);
           const long double dth = (long double)G.W * (long double)grid->step;
           o[2] = (double)(dth / PIl);
@@ -1504,7 +1522,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           o += WFK_SH_OP1;
           continue;
         }
-        if (G.chirp) {
+        if (G.corr) {
+          o[12] = G.wm; o[13] = G.sm; o[14] = G.W; o[15] = x;
+          H.short_corr = true;
+          o += WFK_SH_OP3;
+        } else if (G.chirp) {
           o += WFK_SH_OP3;
         } else if (G.deg > 1) {
           o[12] = (double)Ar[2]; o[13] = (double)Ar[3]; o[14] = (double)Br[2]; o[15] = (double)Br[3];
@@ -1887,7 +1909,8 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           // piece that tier cannot take (generic terms: erf edges, chirps, ...) is built again for the
           // general kernel, in the standard geometry: the plan then runs as two launches (mixed).
           bool ok = generic.empty() && !groups.empty() && groups.size() <= 255 && !multi_bad;
-          for (const FceGroup& G : groups) ok = ok && !G.corr && !(G.chirp && G.deg > 1);
+          for (const FceGroup& G : groups)
+            ok = ok && !(G.corr && (G.deg > 1 || G.chirp || G.fmul || G.erfmul || G.envmul || C.tshift != 0.0)) && !(G.chirp && G.deg > 1);
           if (!ok) {
             H.params.resize(snap.params); H.pool.resize(snap.pool);
             H.n_fast = snap.nf; H.n_direct = snap.nd; H.n_fused = snap.nu; H.n_generic = snap.ng; H.n_corr = snap.nc;
@@ -2070,6 +2093,10 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
     if (n_foreign_samples > n_short_samples || (n_short_pieces == 0 && n_foreign_pieces > 0)) return WFK_RETRY_STD;
     H.shortp = true;
     H.lean = false;
+    // corrected carriers live in family 6 = family 0 + the correction: with closing ops, chirps or tables in the same plan
+    // the carriers go back to the tiers that have both
+    if (H.short_corr && H.short_fam != 0) H.short_needs_corr = true;
+    if (H.short_corr && H.short_fam == 0) H.short_fam = 6;
     H.mixed = n_foreign_pieces > 0;       // foreign pieces: a second launch of the general kernel
     H.foreign_frac = n_short_samples > 0 ? (double)n_foreign_samples / (double)(n_short_samples + n_foreign_samples) : 0.0;
     H.tile = 64 * WFK_SH_R;
@@ -2252,6 +2279,15 @@ int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads,
         B.f32_tiles_per_chunk != A.f32_tiles_per_chunk || B.f32_chunks_per_ch != A.f32_chunks_per_ch ||
         (B.n_corr > 0) != (A.n_corr > 0))
       return WFK_RETRY_STD;
+  {
+    // corrected carriers (family 6) in one block, closing ops / tables (families 1, 2, 4) in another: no build has both
+    bool any_corr = false, any_other = false;
+    for (const HostPlan& B : parts) {
+      any_corr = any_corr || B.short_corr;
+      any_other = any_other || (B.shortp && B.short_fam != 0 && B.short_fam != 6);
+    }
+    if (any_corr && any_other) return WFK_RETRY_STD;
+  }
   H = HostPlan();
   H.tlist = false; H.n_channels = P->n_channels; H.n = A.n;
   H.t0 = A.t0; H.step = A.step; H.last = A.last; H.has_last = A.has_last; H.i0 = A.i0;
@@ -2306,6 +2342,7 @@ int wfk_compile_blocks(const wfk_program* P, const wfk_grid* grid, int nthreads,
     H.short_has_fmul = H.short_has_fmul || B.short_has_fmul;
     H.short_fam = std::max(H.short_fam, B.short_fam);
     H.short_needs_corr = H.short_needs_corr || B.short_needs_corr;
+    H.short_corr = H.short_corr || B.short_corr;
     len_sum += B.mean_piece_len * (double)B.n_channels; frac_sum += B.foreign_frac * (double)B.n_channels;
   }
   H.mean_piece_len = len_sum / (double)P->n_channels;

@@ -220,6 +220,8 @@ struct SArgs {                // short-tier launch (wfk_short.hip)
   double step;
   const double* pool;         // INTERP tables of the closing multipliers ((value, difference) pairs)
   int32_t pk, pad2;           // real float launches of family 0: the packed-fp32 build (WFK_SH_NO_PK=1: the double-arithmetic one)
+  double t0, last, dlast, di0;   // family 6 (corrected carriers): the grid's t0, its overridden last sample and that sample's index
+                                 // in the caller's full grid (-1: none), the slice offset i0 -- as doubles
 };
 
 struct KArgs {
@@ -298,6 +300,7 @@ struct HostPlan {
   int32_t short_fam = 0;           // instantiation of wfk_sample_short the plan needs: 0 carrier-envelope ops only, 1 + erf edges, chirps and
                                    // shared Gaussians, 2 + table / mollifier envelopes (closing multipliers, own-term ops), 4 + exponential / hyperbolic chirp
                                    // multipliers (3 is family 0 in packed fp32, picked at launch)
+  bool short_corr = false;         // some short op carries the grid-rounding correction (family 6: wfk_short_dev.h short_op_corr)
   bool short_needs_corr = false;   // some carrier wanted the grid-rounding correction, which only the lean kernel has
   bool pool_real = false;          // `pool` holds tables the parameter blocks point into (INTERP / mollifier / SAMPLED)
   std::vector<ShortUnit> s_units;

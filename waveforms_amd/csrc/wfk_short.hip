@@ -151,6 +151,8 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
   // F2 table / mollifier envelopes, F4 exponential / hyperbolic chirp multipliers (libm log behind a call: a family of
   // its own, so that the table envelopes keep their register allocation)
   constexpr bool F1 = FAM == 1 || FAM == 2 || FAM == 4, F2 = FAM == 2 || FAM == 4, F4 = FAM == 4;
+  // family 6 = family 0 + carriers with the grid-rounding correction (pulse trains milliseconds from t = 0: short_op_corr)
+  constexpr bool F6 = FAM == 6;
   static_assert(!PK || (std::is_same<T, float>::value && !CPLX), "packed arithmetic: real float launches only");
   __shared__ __attribute__((aligned(16))) E s_out[kStage];
   const int lane = threadIdx.x;
@@ -230,7 +232,7 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
         const bool closing = ((w >> 4) & 3) == 3;       // closing multiplier (erf edge, table, mollifier)
         const bool mine = lv && !closing && (CPLX || !(w & 8));   // op of the imaginary part: a real launch keeps .real
         const bool chirp = F1 && (w & 512) != 0;  // quadratic phase (16-double record, polynomials of degree <= 1)
-        const bool cubic = __any(mine && !chirp && (w & 3) > 1);
+        const bool cubic = __any(mine && !chirp && (w & 3) > 1 && !(F6 && (w & 4096)));
         if constexpr (PK) {
           if (mine) {
             if (cubic) short_op_pk<R, true>(rc, opp, w, kf, a.step, accp);
@@ -250,7 +252,19 @@ __global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(
             if (mine && bare) short_op_bare<R, CPLX>(rc, w, kf, acc, acci);
           }
         }
-        if (mine && !chirp && !bare) {
+        bool corr = false;
+        if constexpr (F6) {
+          corr = (w & 4096) != 0;
+          if (__any(mine && corr)) {
+            if (mine && corr) {
+              ShortCorr cc;
+              cc.dj0 = a.di0 + (double)seg.j;
+              cc.step = a.step; cc.t0 = a.t0; cc.last = a.last; cc.dlast = a.dlast;
+              short_op_corr<R, CPLX>(rc, opp, w, kf, cc, acc, acci);
+            }
+          }
+        }
+        if (mine && !chirp && !bare && !corr) {
 #ifndef WFK_SH_SKIP0
 #define WFK_SH_SKIP0 0
 #endif
@@ -402,10 +416,10 @@ int launch_short(const SArgs& a, hipStream_t s) {
   constexpr bool kPk = std::is_same<T, float>::value && !CPLX;
   if (a.accumulate) {
     if (a.fam <= 0) { if constexpr (kPk) { if (a.pk) SH_LAUNCH(true, 3); else SH_LAUNCH(true, 0); } else SH_LAUNCH(true, 0); }
-    else if (a.fam == 1) SH_LAUNCH(true, 1); else if (a.fam == 2) SH_LAUNCH(true, 2); else SH_LAUNCH(true, 4);
+    else if (a.fam == 1) SH_LAUNCH(true, 1); else if (a.fam == 2) SH_LAUNCH(true, 2); else if (a.fam == 6) SH_LAUNCH(true, 6); else SH_LAUNCH(true, 4);
   } else {
     if (a.fam <= 0) { if constexpr (kPk) { if (a.pk) SH_LAUNCH(false, 3); else SH_LAUNCH(false, 0); } else SH_LAUNCH(false, 0); }
-    else if (a.fam == 1) SH_LAUNCH(false, 1); else if (a.fam == 2) SH_LAUNCH(false, 2); else SH_LAUNCH(false, 4);
+    else if (a.fam == 1) SH_LAUNCH(false, 1); else if (a.fam == 2) SH_LAUNCH(false, 2); else if (a.fam == 6) SH_LAUNCH(false, 6); else SH_LAUNCH(false, 4);
   }
 #undef SH_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;

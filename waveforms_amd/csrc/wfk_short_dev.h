@@ -170,6 +170,78 @@ __device__ __forceinline__ void short_op(const OpRec& o, const double* op, int w
   SH_END
 }
 
+// short_op with the grid-rounding correction of the lean kernel's CORR builds (wfk_kernels.hip: corr_delta), for pulse
+// trains milliseconds from t = 0: the reference evaluates at NumPy's rounded grid time x_k = fl(fl(j step) + t0) and rounds
+// its phase, fl(w fl(x_k - shift)); W |t| ulp is 2e-10 rad at 300 MHz 1 ms out, and the recurrences stand for the ideal
+// times.  Per sample: e_k = (x_k - x_ref) - (kf + k) dt, the rounding rho_k of ONE reference COS factor (w_m, s_m: the
+// group's heaviest term's, host), d = W e_k - w_m eu + rho_k, and the phasor is turned by d to first order.  16-double
+// record (word bit 12; degree <= 1): [12] w_m  [13] s_m  [14] W  [15] x_ref.  Channels without a pending shift only.
+struct ShortCorr {
+  double dj0;            // index of the lane's first sample in the caller's full grid, exact
+  double step, t0, last, dlast;
+};
+template <int R, bool CPLX>
+__device__ __forceinline__ void short_op_corr(const OpRec& o, const double* op, int w, double kf, const ShortCorr& cc,
+                                              double (&acc)[R], double (&acci)[CPLX ? R : 1]) {
+#pragma clang fp contract(off)
+  const int env = (w >> 4) & 3;
+  const double C1 = o.b.y, S1 = o.c.x, Hh = o.d.x, q = o.d.y;
+  const double A0 = o.e.x, A1 = o.e.y, B0 = o.f.x, B1 = o.f.y;
+  const double wm = op[12], sm = op[13], W = op[14], xref = op[15];
+  double c, s;
+  {
+    const double x = __builtin_fma(kf, o.b.x, o.a.y);       // phase / pi
+    const double n = rint(x);
+    sincospi_small(x - n, &s, &c);
+    if (((int)n) & 1) { c = -c; s = -s; }
+  }
+  double g = 1.0, r = 1.0;
+  if (__any(env != 0)) {
+    const double vv = __builtin_fma(kf, Hh, o.c.y);
+    const double ea = env == 1 ? -(vv * vv) : (env == 2 ? vv : 0.0);
+    const double eb = env == 1 ? -Hh * (2.0 * vv + Hh) : (env == 2 ? Hh : 0.0);
+    g = exp_small(ea);
+    r = exp_small(eb);
+  }
+  double u = kf * cc.step;
+  double mr = 1.0, mi = 0.0;
+  if constexpr (CPLX) {
+    if (w & 8) { mr = 0.0; mi = 1.0; }
+  }
+  SH_EACH(R, k)
+    // the reference's time of this sample, its distance from the ideal one, its rounded phase
+    const double dj = cc.dj0 + (double)k;
+    const double m = dj * cc.step;
+    double t = m + cc.t0;
+    if (dj == cc.dlast) t = cc.last;
+    const double eps = (t - xref) - (kf + (double)k) * cc.step;
+    const double um = t - sm;
+    const double bb = um - t;
+    const double eu = (t - (um - bb)) + (-sm - bb);
+    const double pm = wm * um;
+    const double rho = -__builtin_fma(wm, um, -pm);
+    const double d = __builtin_fma(W, eps, __builtin_fma(-wm, eu, rho));
+    const double ck = __builtin_fma(-d, s, c), sk = __builtin_fma(d, c, s);
+    const double pa = __builtin_fma(A1, u, A0), pb = __builtin_fma(B1, u, B0);
+    const double val = __builtin_fma(pa, ck, pb * sk);
+    if constexpr (CPLX) {
+      const double tv = val * g;
+      acc[k] = __builtin_fma(mr, tv, acc[k]);
+      acci[k] = __builtin_fma(mi, tv, acci[k]);
+    } else {
+      acc[k] = __builtin_fma(val, g, acc[k]);
+    }
+    if constexpr (k + 1 < R) {
+      g *= r;
+      r *= q;
+      const double cn = __builtin_fma(c, C1, -(s * S1));
+      s = __builtin_fma(s, C1, c * S1);
+      c = cn;
+      u += cc.step;
+    }
+  SH_END
+}
+
 // short_op for a BARE carrier (degree 0, no envelope: the tones of a multi-tone piece whose shared Gaussian is a closing
 // op, the plateau of a flat top): acc[k] += A0 c_k + B0 s_k -- 6 instructions per sample instead of 12, no envelope seeds.
 template <int R, bool CPLX>
