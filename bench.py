@@ -902,6 +902,21 @@ def run_rank(args):
         b2.close()
         del o2
         shapes = {}
+        # the `also.awg` rows 1 ms from t = 0 (the tail of a 1 ms sequence): carriers with the grid-rounding correction,
+        # family 6 of the short tier
+        try:
+            far_g = ('arange', 1e-3, 1e-3 + 1e5 / 2e9, 1.0 / 2e9)
+            b2 = BatchSampler([wl.awg_channel(wfm, c) >> 1e-3 for c in range(16)], far_g, tile=128)
+            o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)
+            ms = timed(lambda: b2.launch_torch(o2), 20, 5)
+            nb = b2.n_channels * b2.n * 8
+            shapes['far_1ms'] = {'kernel': b2.plan.kernel_name(), 'kernel_ms': ms, 'msamples_per_s': b2.n_channels * b2.n / (ms * 1e-3) / 1e6,
+                                 'frac': nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'fused_ops': int(b2.plan.info.n_fused),
+                                 'generic_terms': int(b2.plan.info.n_generic)}
+            b2.close()
+            del o2
+        except Exception as e:
+            shapes['far_1ms'] = {'error': repr(e)}
         for shape in ('flat_top', 'linear_chirp', 'ten_tones', 'exp_chirp'):
             b2 = BatchSampler([wl.awg_shape_channel(wfm, shape, c) for c in range(16)], wl.awg_grid(), tile=128)
             o2 = torch.empty((b2.n_channels, b2.n), device='cuda', dtype=torch.float64)

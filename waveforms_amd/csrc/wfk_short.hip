@@ -139,7 +139,9 @@ constexpr int kStage = 68 * 16 + 16;
 //     have been acknowledged (measured: 6 us per unit).
 // FAM: the op family the plan needs (HostPlan::short_fam) -- 0: carrier-envelope ops and nothing else (the plain pulse train:
 // the body of round 3); 1: + the closing ops of flat-top edges (erf) and multi-tone pieces (shared Gaussian), linear chirps,
-// envelope seeds skipped where no lane has an envelope; 2: + table / mollifier envelopes (closing multipliers, own-term ops).  Separate instantiations, so that a shape added to one family cannot move the code generation of the others (the
+// envelope seeds skipped where no lane has an envelope; 2: + table / mollifier envelopes (closing multipliers, own-term ops); 3: family 0
+// in packed fp32 (real float launches); 4: + exponential / hyperbolic chirp multipliers; 6: family 0 + carriers with the
+// grid-rounding correction (pulse trains milliseconds from t = 0).  Separate instantiations, so that a shape added to one family cannot move the code generation of the others (the
 // chirp / cmul / shared-envelope ops of round 4, inlined into the one body, cost the plain pulse train 23 % more VALU
 // instructions and 113-120 spilled SGPRs).
 template <typename T, bool CPLX, bool ACC, int R, int FAM>
