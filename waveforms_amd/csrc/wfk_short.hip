@@ -144,8 +144,11 @@ constexpr int kStage = 68 * 16 + 16;
 // grid-rounding correction (pulse trains milliseconds from t = 0).  Separate instantiations, so that a shape added to one family cannot move the code generation of the others (the
 // chirp / cmul / shared-envelope ops of round 4, inlined into the one body, cost the plain pulse train 23 % more VALU
 // instructions and 113-120 spilled SGPRs).
+#ifndef WFK_SH_WAVES6
+#define WFK_SH_WAVES6 2       // family 6 (corrected carriers): 219 registers and no spill at two waves per SIMD against 168 + 46 spilled
+#endif                        // at three -- rows 1 ms from t = 0, same box: 1.06 -> 0.835 ms
 template <typename T, bool CPLX, bool ACC, int R, int FAM>
-__global__ void __launch_bounds__(64, CPLX ? 2 : WFK_SH_WAVES) wfk_sample_short(const SArgs a) {
+__global__ void __launch_bounds__(64, CPLX ? 2 : (FAM == 6 ? WFK_SH_WAVES6 : WFK_SH_WAVES)) wfk_sample_short(const SArgs a) {
   using E = typename std::conditional<CPLX, typename ShOut<T>::Cplx, T>::type;
   // float launches of the plain pulse train (family 3 = family 0 in packed fp32 arithmetic, wfk_short_dev.h: short_op_pk)
   constexpr bool PK = FAM == 3;
