@@ -19,6 +19,9 @@ LIN = ('linspace', -10.0, 10.0, 1001, True)
 # round once on the store, so what remains is float rounding of the result (6e-8) plus the float phasor /
 # envelope recurrences of the fused tiers (worst observed over the soaks: 3.03e-5, chain_soak seed 29703).
 FP32_TOL = 5e-5
+# float launches of scripts moved 10 us .. 10 ms from t = 0 (tools/fuzz_soak.py far / awgfar): the lean kernel's float phasor /
+# envelope recurrences on terms that cancel reach 1.6e-4 of peak in 1 of 3000-6000 scripts (worst observed); contract 1e-3
+FP32_FAR_TOL = 2e-4
 
 # THE fp64 bounds, one per tier, as fractions of max(1, peak) of the fp64 oracle (north_star's contract: < 1e-9 absolute
 # on O(1) waveforms).  Tests and soaks (tools/*_soak.py) hold THESE numbers; a test may assert something tighter for a
