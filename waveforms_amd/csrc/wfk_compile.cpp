@@ -916,8 +916,11 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
         continue;
       }
       if (!rate_safe_n((double)q.W, s0, s1)) {
-        if (shortm && (tshift != 0.0 || p > 1 || env_no_short_corr || !corr_enabled)) {
-          H.short_needs_corr = true;       // (only the lean kernel corrects these: a shifted channel, a polynomial of degree > 1)
+        if (shortm && (!cur_short || tshift != 0.0 || p > 1 || env_no_short_corr || !corr_enabled)) {
+          // (only the lean kernel corrects these: a shifted channel, a polynomial of degree > 1 -- and a piece of a short
+          //  plan that is built again for the GENERAL kernel, which has no correction: 3e-9 on such a piece, found by the
+          //  far fuzz)
+          H.short_needs_corr = true;
           return false;
         }
         if (!corr_safe((double)q.W, s0, s1)) { if (shortm) H.short_needs_corr = true; return false; }
