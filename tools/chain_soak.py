@@ -1,6 +1,6 @@
 """Long differential fuzz of the sampler -> FIR chain (not part of the suite): random pulse trains on 1-5 GS/s
 grids (tests/cases.py random_awg_channel) and random BASELINE-style channels through SampledFir, fp64 and fp32,
-against the C oracle (sampler) + direct convolution.   usage: python tools/chain_soak.py [first_seed] [count]"""
+against the C oracle (sampler) + direct convolution.   usage: python tools/chain_soak.py [first_seed] [count] [far]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -14,11 +14,16 @@ from waveforms_amd.distortion import SampledFir
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+FAR = len(sys.argv) > 3 and sys.argv[3] == 'far'
 took, bad, t0 = {}, [], time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(70_000 + seed)
     try:
         ch, grid = cases.random_awg_channel(wf, rng) if seed % 4 else cases.random_channel(wf, rng)
+        if FAR:        # the same trains 0.1 .. 3 ms from t = 0 (corrected carriers: family 6 plans must stay out of fir_short)
+            T_ = float(rng.choice([1e-4, 1e-3, 3e-3, -2e-3]))
+            ch = ch >> T_
+            grid = (grid[0], grid[1] + T_, grid[2] + T_) + tuple(grid[3:])
         nch = int(rng.integers(1, 4))
         chans = [ch] + [(ch * float(rng.uniform(0.2, 1.5)) + float(rng.uniform(-0.3, 0.3))) for _ in range(nch - 1)]
         prog = _flatten.flatten(chans)

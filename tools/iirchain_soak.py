@@ -2,7 +2,7 @@
 trains on fine grids (whatever the chain does with them: sampler inside the IIR scan, or sampler then filter) and random
 trains at AWG rates, through SampledIir with random cascades (Butterworth SOS, exponential-correction sections, single
 sections of order 3 / 4), random initial levels and states, fp64 and fp32, against the C oracle (sampler) + SciPy.
-usage: python tools/iirchain_soak.py [first_seed] [count]"""
+usage: python tools/iirchain_soak.py [first_seed] [count] [far]   (far: the trains 0.1 .. 3 ms from t = 0; the sampler's own bound then applies)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -17,6 +17,7 @@ from waveforms_amd.distortion import SampledIir, exp_decay_filter
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+FAR = len(sys.argv) > 3 and sys.argv[3] == 'far'
 TOL = FP64_IIR_TOL   # the IIR stages' fp64 bound (tests/cases.py); contract 1e-9
 took, bad, t0, worst = {}, [], time.time(), 0.0
 
@@ -45,6 +46,10 @@ for seed in range(first, first + count):
             n = int(rng.integers(33000, 400000))
             ch = wl.sum_channel(wf, nseg, int(rng.integers(1 << 30)), spacing=wl.SPAN * float(rng.choice([1.0, 1.0, 1.5])))
             grid = ('linspace', 0.0, nseg * wl.SPAN * 1.5, n, bool(rng.integers(2)))
+        if FAR:
+            T_ = float(rng.choice([1e-4, 1e-3, 3e-3, -2e-3]))
+            ch = ch >> T_
+            grid = (grid[0], grid[1] + T_, grid[2] + T_) + tuple(grid[3:])
         nch = int(rng.integers(1, 4))
         chans = [ch] + [ch * float(rng.uniform(0.2, 1.5)) for _ in range(nch - 1)]
         prog = _flatten.flatten(chans)
@@ -72,6 +77,7 @@ for seed in range(first, first + count):
         want, wzf = np.stack(want), np.stack(wzf)
         pk = max(1.0, float(np.abs(want).max(initial=0.0)))
         tol64 = FP64_IIR_ORDER34_TOL if any(max(len(b), len(a)) - 1 >= 3 for b, a in secs) else TOL
+        if FAR: tol64 = max(tol64, cases.FP64_GRID_TOL)      # (milliseconds out the sampler itself uses its budget)
         for dt, tol in ((np.float64, tol64), (np.float32, FP32_TOL)):
             si = SampledIir(chans, grid, secs, None, dt)
             kn = si.plan.kernel_name().split('<')[0] + (' (+passes)' if 'IIR passes' in si.plan.kernel_name() else '')

@@ -2540,6 +2540,7 @@ int wfk_chain_windows(const HostPlan& H, int64_t n, int64_t hop, int64_t lead, i
   bad.clear();
   if (!H.shortp) { bad = "not a short plan"; return WFK_EINVAL; }
   if (H.short_has_fmul) { bad = "table / mollifier envelopes (closing multipliers the fused chain does not evaluate)"; return WFK_EINVAL; }
+  if (H.short_corr) { bad = "carriers with the grid-rounding correction (family 6 of the short tier: fir_short does not evaluate them)"; return WFK_EINVAL; }
   if (half_len <= 0 || half_len > 4096 || hop <= 0 || npairs < 0) { bad = "window geometry"; return WFK_EINVAL; }
   const int32_t nch = (int32_t)H.channels.size();
   wins.assign((size_t)npairs * nch * 2, ShortWin{});
