@@ -376,3 +376,20 @@ def test_one_kernel_per_channel():
     st.close(); dx.close(); dy.close()
     with pytest.raises(ValueError):
         FirStage(kers, 40000, 4)
+
+
+@pytest.mark.parametrize('t0', [1e-3, -2e-3])
+def test_awg_trains_milliseconds_from_zero_through_the_chain(t0):
+    """AWG-rate rows far from t = 0 through predistort(wav(t), ker): the sampler's plan carries corrected carriers there
+    (family 6 of the short tier), which fir_short does not evaluate -- the chain must run sampler + FIR (tools/chain_soak.py
+    far: a family-6 plan inside fir_short was 1e-7 off)"""
+    rate, n = 2e9, 30000
+    chans = [wl.awg_channel(wf, c, n, rate) >> t0 for c in range(2)]
+    grid = ('arange', t0, t0 + n / rate, 1 / rate)
+    ker = _kernel(1024)
+    sf = SampledFir(chans, grid, ker)
+    assert 'fir_short' not in sf.plan.kernel_name(), sf.plan.kernel_name()
+    assert sf.plan.kernel_name().startswith('wfk_sample_short<double,false,false,16,6>'), sf.plan.kernel_name()
+    want = _oracle_chain(chans, grid, ker)
+    assert np.max(np.abs(sf.to_host() - want)) <= 1e-9 * max(1.0, np.abs(want).max())
+    sf.close()
