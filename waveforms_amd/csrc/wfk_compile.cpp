@@ -966,6 +966,18 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
           const double ar = (double)e.a;
           if (!std::isfinite(ref) || !(fabsl(lg) <= 600.0L) || !(std::fabs(ar) * half <= 600.0) || !rate_safe(ar, s0, s1))
             return false;
+          {
+            // an exponential of amplitude >> 1 (coshPulse with a small eps is 23 cos - 22 cos cosh, cancelling to O(1))
+            // turns the envelope's share of the grid jitter into that many times the value error: 1.5e-9 of peak 1 ms
+            // out (tools/fuzz_soak.py awgfar) -- the envelope's rate is weighed with the term's amplitude there
+            double wamp = (std::fabs(P->tm_amp_re[k]) + std::fabs(P->tm_amp_im[k])) * (double)fabsl(e.c * expl(lg));
+            if (has_lin) {
+              const double ua = (ax.at(s0) - tshift) - slin, ub = (ax.at(s1 - 1) - tshift) - slin;
+              wamp *= std::pow(std::max(std::fabs(ua), std::fabs(ub)), p);
+            }
+            wamp *= std::exp(std::fabs(ar) * 0.5 * std::fabs(ax.at(s1 - 1) - ax.at(s0)));      // its largest value over the piece
+            if (std::isfinite(wamp) && wamp > 1.0 && !rate_safe_n(2.0 * ar * wamp, s0, s1)) return false;   // (2: seed and sample both rounded)
+          }
           v.amp *= expl(lg); v.has_env = true; v.has_exp = true; v.sigma = ar; v.sg = ref;
           v.env32 = std::fabs(ar) * half <= 80.0;
         }
