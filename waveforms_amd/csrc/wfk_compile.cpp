@@ -1136,11 +1136,22 @@ static int compile_impl(const wfk_program* P, const wfk_grid* grid, const double
       //  double next to |s_ref| -- half an ulp of a time 100 s from the origin is 7e-15 s, 3e-9 rad
       //  under a 60 kHz carrier.  The degree-0 loop has no B term: such an op runs as degree 1.)
       if (B0 != 0.0L) deg = 1;
-    } else if (G.deg == 0 && G.W != 0.0) {
-      // A cos(th) + B sin(th) = R cos(th - phi): fold B into the reference shift
+    } else if (G.deg == 0 && G.W != 0.0 && B0 != 0.0L) {
+      // A cos(th) + B sin(th) = R cos(th - phi): fold B into the reference shift -- unless the folded shift, ROUNDED to a
+      // double next to |s_ref|, would cost more than 1e-12 of the group's amplitude in phase (W ulp(s_ref) / 2: 8e-11 rad
+      // at 1 ms under 120 MHz): the op then runs as degree 1 with A and B, like a corrected carrier.  (A group with
+      // B == 0 is left alone: folding a NEGATIVE A as phi = pi moved its reference by pi / W for nothing -- 7e-12 of
+      // relative error per ms from t = 0 on every term with a negative amplitude, 3e-9 on coshPulse's 23 cos - 22 cos cosh:
+      // the far-from-zero fuzz's last class.)
       long double R = hypotl(A0, B0), phi = atan2l(B0, A0);
-      sref = (double)((long double)G.sref + phi / (long double)G.W);
-      A0 = R; B0 = 0.0L;
+      const double folded = (double)((long double)G.sref + phi / (long double)G.W);
+      const double ulp = std::nextafter(std::fabs(folded), INFINITY) - std::fabs(folded);
+      if (G.bank > 0 || G.own_kind || 0.5 * ulp * std::fabs(G.W) * std::max(1.0, (double)R) <= 1e-12) {   // (tone loops and own-term ops are degree 0 by construction)
+        sref = folded;
+        A0 = R; B0 = 0.0L;
+      } else {
+        deg = 1;
+      }
     }
     if (G.erfmul) {
       // closing erf multiplier (wfk_kernels.hip: fce_erfmul): step series about the midpoint,
