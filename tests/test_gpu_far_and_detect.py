@@ -142,3 +142,25 @@ def test_x_of_several_grids_is_sampled_run_by_run(monkeypatch):
     monkeypatch.setattr(_sampling, '_RUNS_ON', False)
     one_list = x_wav(t)
     assert np.max(np.abs(one_list - ora)) <= 1e-9 * pk
+
+
+@pytest.mark.parametrize('t0', [1e-4, 1e-3])
+def test_negative_amplitudes_far_from_t_zero(t0):
+    """A term with a NEGATIVE amplitude milliseconds from t = 0 (found by tools/fuzz_soak.py awgfar through coshPulse's
+    23 cos - 22 cos cosh, 3e-9 of peak): the host folded A < 0, B = 0 into the group's reference shift as phi = pi, and the
+    moved shift, rounded to a double next to |t|, cost W ulp(t) / 2 of phase -- 7e-12 of relative error per ms on every
+    such term.  Positive and negative amplitudes are equally exact now: bare carriers, under exponential and Gaussian
+    envelopes, the coshPulse itself; fine grids (lean kernel) and AWG-rate grids."""
+    for rate, n in ((2e9, 140), (4e10, 2800)):
+        g = _flatten.grid_arange(t0 + 4e-7, t0 + 4e-7 + n / rate, 1 / rate)
+        shapes = (lambda a: a * (wf.cos(7.7e8) * wf.square(4.9e-8)) >> (t0 + 4.4e-7),
+                  lambda a: a * (wf.exp(1.2e7) * wf.cos(7.7e8) * wf.square(4.9e-8)) >> (t0 + 4.4e-7),
+                  lambda a: a * (wf.gaussian(4e-8) * wf.cos(7.7e8, 0.4)) >> (t0 + 4.4e-7),
+                  lambda a: a * (wf.coshPulse(4.9e-8, eps=0.6) * wf.cos(7.7e8, 1.1)) >> (t0 + 4.4e-7))
+        for mk in shapes:
+            for a in (1.0, -1.0, 40.0, -40.0):
+                prog = _flatten.flatten([mk(a)])
+                ora = c_oracle.eval_grid(prog, g)[0]
+                got = _engine.Plan(prog, grid=g).run_host(np.float64)[0]
+                pk = float(np.abs(ora).max())
+                assert np.max(np.abs(got - ora)) <= 2e-12 * max(pk, abs(a)), (rate, a, np.max(np.abs(got - ora)) / pk)
